@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the REAL reference (build container only).
+
+    make -C oracle ref            # compiles /root/reference in place -> oracle/_ref/
+    python tools/make_golden.py   # ~3-5 min on 8 cores
+
+Sources of truth:
+  oracle/_ref/gortt      the reference CLI, unmodified                    (text, %f)
+  oracle/_ref/gortt_fp   same program, printf -> "%.17g" (oracle/ref_capture.c)
+  oracle/_ref/libgortt_ref.so  reference objects + oracle/ref_shim.c      (function level)
+
+Only inputs and expected outputs are stored (data); no reference source text.
+The GPU box never runs this script and never sees /root/reference.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+GOLD = os.path.join(ROOT, "tests", "golden")
+GORTT = os.path.join(REFDIR, "gortt")
+GORTT_FP = os.path.join(REFDIR, "gortt_fp")
+D = C.c_double
+
+
+def run(binary, args, stdin_text, timeout=600):
+    p = subprocess.run([binary] + list(args), input=stdin_text.encode(), capture_output=True,
+                       timeout=timeout)
+    return p.returncode, p.stdout.decode("latin-1"), p.stderr.decode("latin-1")
+
+
+def stream_text(angles, wl):
+    head = "%d %d %s\n" % (len(angles), len(wl), " ".join(repr(float(w)) if float(w) != int(w) else str(int(w)) for w in wl))
+    assert len(head) < 999, len(head)
+    body = "".join("%r %r %r %r\n" % tuple(float(x) for x in a) for a in angles)
+    return head + body
+
+
+def parse_rows(stdout, nw, prnspec=False, prnprop=False, energy=False):
+    """Rows of a gortt_fp run -> dict of arrays (header line skipped)."""
+    lines = stdout.strip("\n").split("\n")[1:]
+    rs, sc, K, en = [], [], [], []
+    for ln in lines:
+        tok = ln.replace("{", " ").replace("}", " ").replace("[", " ").replace("]", " ").split()
+        v = [float(t) for t in tok]
+        i = 4
+        r, s = [], []
+        for _ in range(nw):
+            r.append(v[i]); i += 1
+            if prnspec:
+                s.append(v[i:i + 4]); i += 4
+        rs.append(r)
+        if prnspec: sc.append(s)
+        if prnprop:
+            K.append(v[i:i + 4]); i += 4
+        if energy:
+            en.append(np.array(v[i:i + 3 * nw]).reshape(nw, 3)); i += 3 * nw
+        assert i == len(v), (i, len(v))
+    out = {"rsurf": np.array(rs)}
+    if prnspec: out["scomp"] = np.array(sc)
+    if prnprop: out["K"] = np.array(K)
+    if energy: out["energy"] = np.array(en)
+    return out
+
+
+def fp_stream(args, angles, wl, **kw):
+    flags = list(args)
+    if kw.get("prnspec"): flags.append("-prnspec")
+    if kw.get("prnprop"): flags.append("-prnprop")
+    if kw.get("energy"): flags.append("-energy")
+    rc, out, err = run(GORTT_FP, flags, stream_text(angles, wl))
+    assert rc == 0, (rc, err)
+    return parse_rows(out, len(wl), **kw)
+
+
+def fp_lut(args):
+    rc, out, err = run(GORTT_FP, list(args) + ["-W"], "")
+    assert rc == 0, (rc, err)
+    rows = [ln.split() for ln in out.strip().split("\n")]
+    pn0 = np.array([float(r[1]) for r in rows[:90]])
+    ep = np.array([float(r[2]) for r in rows[:90]])
+    assert rows[90][0] == "-1"
+    return pn0, ep, float(rows[90][1]), float(rows[90][2])
+
+
+# ------------------------------------------------------------------ CLI cases
+def cli_cases():
+    readme = "1 4 450 600 800 1000\n10 0 30 20\n"
+    two = "2 3 550 670 865\n0 0 45 0\n-30 0 45 0\n"
+    cases = [
+        ("readme", ["-LAI", "4.0"], readme),
+        ("readme_prnprop", ["-LAI", "4.0", "-prnprop"], readme),
+        ("readme_prnspec", ["-LAI", "4.0", "-prnspec"], readme),
+        ("readme_energy", ["-LAI", "4.0", "-energy"], readme),
+        ("readme_all", ["-LAI", "4.0", "-prnspec", "-prnprop", "-energy"], readme),
+        ("readme_q08", ["-LAI", "4.0", "-q08_pn_kopen"], readme),
+        ("lut_default", ["-LAI", "4.0", "-W"], ""),
+        ("lut_q08", ["-LAI", "4.0", "-q08_pn_kopen", "-W"], ""),
+        ("lut_newstyle", ["-HB", "2.0", "-BR", "2.0", "-PCC", "0.6", "-LAI", "3.3", "-W"], ""),
+        ("newstyle", ["-HB", "2.0", "-BR", "2.0", "-PCC", "0.6", "-LAI", "3.3", "-prnprop"], two),
+        ("overrides", ["-LAI", "2", "-alb_leaf", "0.9", "-alb_soil", "0.2", "-diffuse", "0.3", "-beta", "0.5"],
+         "1 2 550 865\n25 40 35 170\n"),
+        ("oldstyle", ["-favd", "0.6", "-h1", "2.5", "-h2", "9", "-lambda", "0.3", "-r", "1.1", "-b", "2.0", "-prnprop"],
+         "3 2 500.5 1650.25\n20 10 40 250\n-20 350 -40 10\n60 400 10 -30\n"),
+        ("prospect_flags", ["-LAI", "3", "-N", "1.8", "-cab", "45", "-car", "8", "-canth", "2", "-cbrown", "0.1",
+                            "-cw", "0.01", "-cm", "0.005", "-rsl1", "0.3", "-rsl2", "0.05", "-rsl3", "0.01",
+                            "-rsl4", "0.001", "-prnspec"],
+         "2 5 400 555.5 1200 2100 2500\n15 20 25 200\n0 0 0 0\n"),
+        ("case_insensitive", ["-FAVD", "0.7", "-H1", "3.5", "-Cab", "20", "-n", "1.5"], readme),
+        ("prefix_flags", ["-LAI", "4.0", "-prnspecXYZ", "-prnpropABC", "-diffusion", "0.2", "-betaX", "0.3"], readme),
+        ("horizon", ["-LAI", "4.0", "-prnprop"], "5 1 800\n89 0 30 0\n89.5 0 30 180\n90 0 30 0\n30 0 90 0\n-90 0 0 0\n"),
+        ("azimuth_wrap", ["-LAI", "4.0", "-prnprop"],
+         "6 1 650\n30 200 40 0\n30 0 40 200\n30 -45 40 45\n30 725 40 -370\n-30 10 -40 20\n30 180 40 0\n"),
+        ("extra_columns", ["-LAI", "4.0"], "1 1 700\n10 0 30 20 99 98 junk\n"),
+        ("header_spacing", ["-LAI", "4.0"], "  1   2\t450   600  \n10 0 30 20\n"),
+        ("count_mismatch", ["-LAI", "4.0"], "3 1 800\n10 0 30 20\n"),
+        ("usage", ["-u"], ""),
+        ("unknown_option", ["-Anth", "1"], readme),
+        ("unknown_argument", ["-LAI", "4.0", "foo"], readme),
+        ("empty_stdin", ["-LAI", "4.0"], ""),
+        ("bad_header_nw", ["-LAI", "4.0"], "1 3 450 600\n10 0 30 20\n"),
+        ("bad_angle_line", ["-LAI", "4.0"], "2 1 800\n10 0 30 20\n10 0 thirty 20\n"),
+        ("wl_out_of_range", ["-LAI", "4.0"], "1 1 399\n10 0 30 20\n"),
+        ("missing_lut_file", ["-LAI", "4.0", "-P", "/nonexistent/lut.dat"], readme),
+        ("header_only_na", ["-LAI", "4.0"], "1\n"),
+    ]
+    out = []
+    for name, args, stdin in cases:
+        rc, so, se = run(GORTT, args, stdin)
+        rc2, so2, se2 = run(GORTT_FP, args, stdin)
+        se = se.replace(GORTT, "gortt"); se2 = se2.replace(GORTT_FP, "gortt")
+        assert rc == rc2
+        out.append({"name": name, "args": args, "stdin": stdin, "rc": rc, "stdout": so,
+                    "stdout_fp": so2, "stderr": se})
+        print("cli", name, "rc", rc, "| out", len(so), "| err", se.strip().split("\n")[0][:70])
+    # -P round trip: BRDF through a LUT file written by -W
+    rc, lut, _ = run(GORTT, ["-LAI", "4.0", "-W"], "")
+    lut_path = "/tmp/gort_golden_lut.dat"
+    open(lut_path, "w").write(lut)
+    pp = "4 3 450 800 1600\n10 0 30 20\n60 0 30 180\n88.5 0 30 0\n30 0 89 0\n"
+    rc, so, se = run(GORTT, ["-LAI", "4.0", "-P", lut_path, "-prnprop"], pp)
+    rc2, so2, _ = run(GORTT_FP, ["-LAI", "4.0", "-P", lut_path, "-prnprop"], pp)
+    out.append({"name": "lut_roundtrip", "args": ["-LAI", "4.0", "-P", "@LUT@", "-prnprop"], "stdin": pp,
+                "rc": rc, "stdout": so, "stdout_fp": so2, "stderr": se, "lut_text": lut})
+    json.dump(out, open(os.path.join(GOLD, "cli_cases.json"), "w"), indent=1)
+
+
+# ------------------------------------------------------- function-level dumps
+def shim():
+    L = C.CDLL(os.path.join(REFDIR, "libgortt_ref.so"))
+    return L
+
+
+def p(a):
+    return a.ctypes.data_as(C.POINTER(D))
+
+
+def shim_canopy(L, flags):
+    argv = [b"gortt"] + [f.encode() for f in flags]
+    arr = (C.c_char_p * len(argv))(*argv)
+    L.refshim_canopy(len(argv), arr)
+    sc = np.zeros(32)
+    L.refshim_canopy_scalars(p(sc))
+    pn0 = np.zeros(15 * 91); ps0 = np.zeros(15 * 91); vg = np.zeros(15 * 91)
+    ep = np.zeros(91); th = np.zeros(91); thp = np.zeros(91); hh = np.zeros(15); hp = np.zeros(15)
+    kk = np.zeros(2)
+    L.refshim_gap_tables(p(pn0), p(ps0), p(vg), p(ep), p(th), p(thp), p(hh), p(hp), p(kk))
+    return dict(scalars=sc, p_n0=pn0.reshape(15, 91), p_s0=ps0.reshape(15, 91), v_g=vg.reshape(15, 91),
+                epgap0=ep, theta=th, theta_p=thp, height=hh, height_p=hp, kk=kk)
+
+
+CANOPIES = {
+    "default_lai4": ["-LAI", "4.0"],
+    "newstyle": ["-HB", "2.0", "-BR", "2.0", "-PCC", "0.6", "-LAI", "3.3"],
+    "q08_lai4": ["-LAI", "4.0", "-q08_pn_kopen"],
+    "sparse": ["-HB", "1.2", "-BR", "3.4", "-PCC", "0.25", "-LAI", "0.7"],
+    "dense_flat": ["-HB", "2.9", "-BR", "1.0", "-PCC", "0.78", "-LAI", "5.8"],
+    "oldstyle": ["-favd", "0.6", "-h1", "2.5", "-h2", "9", "-lambda", "0.3", "-r", "1.1", "-b", "2.0"],
+}
+
+
+def c5_members(n):
+    """SURVEY.md 8(d) C5 draw: numpy default_rng(12345); HB,BR,PCC,LAI through float32."""
+    rng = np.random.default_rng(12345)
+    m = []
+    for _ in range(n):
+        hb, br, pcc, lai = rng.uniform(1, 3), rng.uniform(1, 3.5), rng.uniform(0.2, 0.8), rng.uniform(0.5, 6)
+        cab, cw, cm = rng.uniform(10, 60), rng.uniform(0.005, 0.03), rng.uniform(0.002, 0.015)
+        N, rsl1 = rng.uniform(1, 2.5), rng.uniform(0.05, 0.4)
+        m.append(dict(hb=float(np.float32(hb)), br=float(np.float32(br)), pcc=float(np.float32(pcc)),
+                      lai=float(np.float32(lai)), cab=cab, cw=cw, cm=cm, N=N, rsl1=rsl1))
+    return m
+
+
+def member_flags(m):
+    return ["-HB", repr(m["hb"]), "-BR", repr(m["br"]), "-PCC", repr(m["pcc"]), "-LAI", repr(m["lai"]),
+            "-cab", repr(m["cab"]), "-cw", repr(m["cw"]), "-cm", repr(m["cm"]), "-N", repr(m["N"]),
+            "-rsl1", repr(m["rsl1"])]
+
+
+def canopies_and_spectra():
+    L = shim()
+    store = {}
+    for tag, flags in CANOPIES.items():
+        d = shim_canopy(L, flags)
+        for k, v in d.items():
+            store["%s/%s" % (tag, k)] = v
+        print("canopy", tag, "kopen", d["kk"])
+    np.savez_compressed(os.path.join(GOLD, "canopies.npz"), **store)
+    json.dump(CANOPIES, open(os.path.join(GOLD, "canopies_flags.json"), "w"), indent=1)
+
+    # spectra: raw PROSPECT-D for several parameter sets, all 2101 bands
+    sp = {}
+    psets = {
+        "default": (1.2, 30., 10., 1.0, 0.0, 0.015, 0.009),
+        "dry": (2.5, 5., 2., 0.0, 0.6, 0.0005, 0.012),
+        "dense": (1.0, 80., 20., 5.0, 0.0, 0.04, 0.002),
+        "zero_abs": (1.5, 0., 0., 0., 0., 0., 0.),
+        "opaque": (1.3, 100., 30., 10., 2.0, 0.05, 0.02),
+    }
+    for tag, ps in psets.items():
+        out = np.zeros(4202)
+        L.refshim_prospect_raw(*[D(x) for x in ps], p(out))
+        sp["prospect/%s/params" % tag] = np.array(ps)
+        sp["prospect/%s/RT" % tag] = out
+    # interpolated spectra through the reference's C glue (float fraction!), incl. non-integer nm
+    shim_canopy(L, ["-LAI", "4.0", "-q08_pn_kopen"])
+    wl = np.concatenate([np.arange(400., 2501., 1.0), np.array([400.25, 555.5, 1650.75, 2499.99, 703.1, 1000.000001])])
+    rs = np.zeros(wl.size); rl = np.zeros(wl.size); tl = np.zeros(wl.size)
+    L.refshim_spectra(p(wl), wl.size, p(rs), p(rl), p(tl))
+    sp["interp/default/wl"] = wl; sp["interp/default/rsoil"] = rs
+    sp["interp/default/rleaf"] = rl; sp["interp/default/tleaf"] = tl
+    shim_canopy(L, ["-LAI", "4.0", "-q08_pn_kopen", "-rsl1", "0.31", "-rsl2", "-0.02", "-rsl3", "0.05", "-rsl4", "0.004",
+                    "-N", "1.9", "-cab", "12.5"])
+    rs2 = np.zeros(wl.size); rl2 = np.zeros(wl.size); tl2 = np.zeros(wl.size)
+    L.refshim_spectra(p(wl), wl.size, p(rs2), p(rl2), p(tl2))
+    sp["interp/alt/wl"] = wl; sp["interp/alt/rsoil"] = rs2; sp["interp/alt/rleaf"] = rl2; sp["interp/alt/tleaf"] = tl2
+    sp["interp/alt/rsl"] = np.array([0.31, -0.02, 0.05, 0.004]); sp["interp/alt/prospect"] = np.array([1.9, 12.5, 10., 1.0, 0.0, 0.015, 0.009])
+    x = np.zeros(32); w = np.zeros(32)
+    L.refshim_gauleg(p(x), p(w), 32)
+    sp["gauleg32/x"] = x; sp["gauleg32/w"] = w
+    np.savez_compressed(os.path.join(GOLD, "spectra.npz"), **sp)
+    print("spectra done")
+
+
+# ----------------------------------------------------------- config goldens
+def chunks(seq, n):
+    for i in range(0, len(seq), n):
+        yield seq[i:i + n]
+
+
+def config_goldens():
+    pool = ThreadPoolExecutor(8)
+    lai4 = ["-LAI", "4.0"]
+
+    # C2: principal plane, 181 view zeniths, sza=30, 800 nm (and with K's)
+    ang = [(float(v), 0.0, 30.0, 0.0) for v in range(-90, 91)]
+    r = fp_stream(lai4, ang, [800], prnprop=True, prnspec=True)
+    np.savez_compressed(os.path.join(GOLD, "c2_principal_plane.npz"), angles=np.array(ang), wl=np.array([800.]),
+                        rsurf=r["rsurf"], K=r["K"], scomp=r["scomp"])
+    print("C2 done; nan rows:", int(np.isnan(r["rsurf"]).any(axis=1).sum()))
+
+    # C3 subgrid: stream order "vza phi sza 0" (SURVEY 8d), 800 nm
+    zen = [0, 1, 7, 15, 30, 45, 60, 75, 85, 88, 89, 90]
+    phi = list(range(0, 361, 15)) + [1, 89, 91, 179, 181, 269, 271, 359]
+    ang = [(float(v), float(f), float(s), 0.0) for s in zen for v in zen for f in phi]
+    parts = list(pool.map(lambda a: fp_stream(lai4, a, [800], prnprop=True), chunks(ang, 600)))
+    np.savez_compressed(os.path.join(GOLD, "c3_subgrid.npz"), angles=np.array(ang), wl=np.array([800.]),
+                        rsurf=np.concatenate([q["rsurf"] for q in parts]), K=np.concatenate([q["K"] for q in parts]))
+    print("C3 subgrid done", len(ang))
+
+    # second canopy, random off-grid angles x 24 wavelengths (incl. non-integer nm), all outputs
+    rng = np.random.default_rng(7)
+    ang = np.stack([rng.uniform(-89, 89, 400), rng.uniform(-400, 400, 400), rng.uniform(-89, 89, 400),
+                    rng.uniform(-400, 400, 400)], axis=1)
+    wl = sorted(set(np.round(rng.uniform(400, 2500, 20), 2).tolist() + [400.0, 2500.0, 700.5, 1400.0]))
+    ns = CANOPIES["newstyle"]
+    parts = list(pool.map(lambda a: fp_stream(ns, a, wl, prnprop=True, prnspec=True), chunks(ang.tolist(), 50)))
+    np.savez_compressed(os.path.join(GOLD, "random_stream_newstyle.npz"), angles=ang, wl=np.array(wl),
+                        rsurf=np.concatenate([q["rsurf"] for q in parts]), K=np.concatenate([q["K"] for q in parts]),
+                        scomp=np.concatenate([q["scomp"] for q in parts]))
+    print("random stream done")
+
+    # C4: albedo / favegt / fasoil. (a) all 2101 bands at 5 sun zeniths, (b) 21 bands at all 91 sun zeniths
+    def energy_run(args):
+        szas, wl = args
+        a = [(0.0, 0.0, float(s), 0.0) for s in szas]
+        return fp_stream(lai4, a, wl, energy=True)["energy"]
+    wl_all = list(range(400, 2501))
+    sz_a = [0, 30, 60, 80, 89]
+    parts = list(pool.map(energy_run, [(sz_a, c) for c in chunks(wl_all, 32)]))
+    en_a = np.concatenate(parts, axis=1)            # [5][2101][3]
+    wl_b = list(range(400, 2501, 105))
+    sz_b = list(range(0, 91))
+    parts = list(pool.map(energy_run, [(c, wl_b) for c in chunks(sz_b, 12)]))
+    en_b = np.concatenate(parts, axis=0)            # [91][21][3]
+    np.savez_compressed(os.path.join(GOLD, "c4_albedo.npz"), sza_a=np.array(sz_a, float), wl_a=np.array(wl_all, float),
+                        energy_a=en_a, sza_b=np.array(sz_b, float), wl_b=np.array(wl_b, float), energy_b=en_b)
+    print("C4 done", en_a.shape, en_b.shape)
+
+
+
+def c5_goldens():
+    pool = ThreadPoolExecutor(8)
+    wl_all = list(range(400, 2501))
+    # C5: first 8 ensemble members; LUT + BRDF at sza=30 on a (vza,phi) subgrid x 2101 bands (12 CLI chunks)
+    mem = c5_members(8)
+    vz = [0, 45, 89, 90]
+    ph = [0, 90, 180, 300]
+    ang = [(float(v), float(f), 30.0, 0.0) for v in vz for f in ph]
+    store = {"angles": np.array(ang), "wl": np.array(wl_all, float)}
+    for i, m in enumerate(mem):
+        fl = member_flags(m)
+        pn0, ep, ko, kep = fp_lut(fl)
+        parts = list(pool.map(lambda c: fp_stream(fl, ang, c)["rsurf"], chunks(wl_all, 180)))
+        store["m%d/rsurf" % i] = np.concatenate(parts, axis=1)
+        store["m%d/p_n0" % i] = pn0; store["m%d/epgap0" % i] = ep; store["m%d/kk" % i] = np.array([ko, kep])
+        store["m%d/params" % i] = np.array([m[k] for k in ("hb", "br", "pcc", "lai", "cab", "cw", "cm", "N", "rsl1")])
+        print("C5 member", i, "kopen", ko, kep)
+    np.savez_compressed(os.path.join(GOLD, "c5_members.npz"), **store)
+
+
+def main():
+    for b in (GORTT, GORTT_FP):
+        if not os.path.exists(b):
+            sys.exit("missing %s: run `make -C oracle ref` first" % b)
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["cli", "func", "config", "c5"]
+    if "cli" in what: cli_cases()
+    if "func" in what: canopies_and_spectra()
+    if "config" in what: config_goldens()
+    if "c5" in what: c5_goldens()
+
+
+if __name__ == "__main__":
+    main()
