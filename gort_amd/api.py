@@ -1,0 +1,278 @@
+"""ctypes binding of libgort_amd.so (include/gort_amd.h).
+
+Python here is plumbing for tests and bench.py: the product is the C-ABI shared library
+and the `gortt` executable.  Device buffers come from torch (`tensor.data_ptr()`); no
+numerics happen in Python.  Importing this module never touches the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libgort_amd.so")
+GORTT_BIN = os.path.join(PKG, "bin", "gortt")
+D = C.c_double
+NTH, NLAYERS, NBANDS, COEF_STRIDE = 91, 15, 2101, 16
+
+OK, EINVAL, ERANGE, ENODEVICE, EIO, ENOMEM = 0, -1, -2, -3, -4, -5
+
+
+class GortError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("gort_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Canopy(C.Structure):
+    """struct gort_canopy"""
+    _fields_ = [
+        ("r", D), ("b", D), ("h1", D), ("h2", D), ("lambda_", D), ("favd", D),
+        ("beta", D), ("use_user_beta", C.c_int32), ("use_user_fd", C.c_int32),
+        ("fd_user", D), ("use_q08", C.c_int32), ("reserved0", C.c_int32),
+        ("ell", D), ("rr", D), ("rrr", D), ("h", D), ("k", D), ("elai", D), ("tau", D),
+        ("z1", D), ("z2", D), ("lv", D),
+        ("favd_p", D), ("tau_p", D), ("lv_p", D), ("z1_p", D), ("z2_p", D), ("h1_p", D), ("h2_p", D),
+        ("dz", D), ("ds", D), ("dz_p", D), ("dth", D),
+        ("height_p", D * NLAYERS), ("theta", D * NTH), ("theta_p", D * NTH),
+        ("p_n0", D * NTH), ("epgap", D * NTH), ("k_open", D), ("k_openep", D),
+    ]
+
+
+class LeafSoil(C.Structure):
+    """struct gort_leaf_soil"""
+    _fields_ = [
+        ("N", D), ("Cab", D), ("Car", D), ("Anth", D), ("Cbrown", D), ("Cw", D), ("Cm", D),
+        ("rsl", D * 4), ("use_alb_leaf", C.c_int32), ("use_alb_soil", C.c_int32),
+        ("alb_leaf", D), ("alb_soil", D),
+    ]
+
+
+class Grid(C.Structure):
+    """struct gort_grid"""
+    _fields_ = [
+        ("sza0", D), ("dsza", D), ("nsza", C.c_int32), ("pad0", C.c_int32),
+        ("vza0", D), ("dvza", D), ("nvza", C.c_int32), ("pad1", C.c_int32),
+        ("phi0", D), ("dphi", D), ("nphi", C.c_int32), ("pad2", C.c_int32),
+    ]
+
+
+DECLARED_SYMBOLS = [
+    "gort_last_error", "gort_version", "gort_canopy_defaults", "gort_leaf_soil_defaults",
+    "gort_canopy_newstyle", "gort_canopy_set_lai", "gort_canopy_init", "gort_price_soil",
+    "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_lut_format", "gort_lut_read",
+    "gort_device_count", "gort_gap_probabilities", "gort_gap_probabilities_dev",
+    "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",
+    "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
+    "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
+    "gort_energy_stream", "gort_energy_stream_dev",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libgort_amd.so; fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s missing: run `python -m gort_amd.build` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.gort_last_error.restype = C.c_char_p
+        L.gort_version.restype = C.c_char_p
+        L.gort_lut_format.restype = C.c_long
+        L.gort_engine_stream.restype = C.c_void_p
+        L.gort_engine_last_expand_ms.restype = D
+        L.gort_engine_create.argtypes = [C.POINTER(C.c_void_p)]
+        for name in ("gort_engine_destroy", "gort_engine_synchronize", "gort_engine_stream", "gort_engine_nw",
+                     "gort_engine_last_expand_ms"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.gort_engine_set_canopy.argtypes = [C.c_void_p, C.POINTER(Canopy)]
+        L.gort_engine_set_spectra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gort_rsurf_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.gort_rsurf_stream_dev.argtypes = L.gort_rsurf_stream.argtypes
+        L.gort_rsurf_grid_dev.argtypes = [C.c_void_p, C.POINTER(Grid), C.c_long, C.c_long, C.c_void_p]
+        L.gort_energy_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        L.gort_energy_stream_dev.argtypes = L.gort_energy_stream.argtypes
+        L.gort_gap_probabilities.argtypes = [C.c_void_p, C.c_int]
+        L.gort_gap_probabilities_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.gort_canopy_newstyle.argtypes = [C.POINTER(Canopy), C.c_float, C.c_float, C.c_float]
+        L.gort_canopy_set_lai.argtypes = [C.POINTER(Canopy), C.c_float]
+        L.gort_prospect_d.argtypes = [D] * 7 + [C.c_void_p]
+        L.gort_gauleg.argtypes = [D, D, C.c_void_p, C.c_void_p, C.c_int]
+        L.gort_lut_read.argtypes = [C.c_char_p, C.POINTER(Canopy)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise GortError(rc, lib().gort_last_error().decode())
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    """host numpy array or torch tensor -> void*"""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ------------------------------------------------------------------ host side
+def make_canopy(lai=None, newstyle=None, favd=None, r=None, b=None, h1=None, h2=None, lam=None,
+                beta=None, diffuse=None, q08=False):
+    """Canopy record the way the gortt flags build it (gortt.c:1026-1131), initialised."""
+    L = lib()
+    c = Canopy()
+    L.gort_canopy_defaults(C.byref(c))
+    for name, v in (("favd", favd), ("r", r), ("b", b), ("h1", h1), ("h2", h2), ("lambda_", lam)):
+        if v is not None:
+            setattr(c, name, v)
+    if newstyle is not None:
+        L.gort_canopy_newstyle(C.byref(c), *[C.c_float(x) for x in newstyle])
+    if lai is not None:
+        L.gort_canopy_set_lai(C.byref(c), C.c_float(lai))
+    if beta is not None:
+        c.use_user_beta, c.beta = 1, beta
+    if diffuse is not None:
+        c.use_user_fd, c.fd_user = 1, 1.0 - diffuse
+    c.use_q08 = 1 if q08 else 0
+    _check(L.gort_canopy_init(C.byref(c)))
+    return c
+
+
+def leaf_soil(prospect=None, rsl=None, alb_leaf=None, alb_soil=None):
+    s = LeafSoil()
+    lib().gort_leaf_soil_defaults(C.byref(s))
+    for k, v in (prospect or {}).items():
+        setattr(s, k, v)
+    if rsl is not None:
+        for i in range(4):
+            s.rsl[i] = rsl[i]
+    if alb_leaf is not None:
+        s.use_alb_leaf, s.alb_leaf = 1, alb_leaf
+    if alb_soil is not None:
+        s.use_alb_soil, s.alb_soil = 1, alb_soil
+    return s
+
+
+def spectra(wl, ls=None):
+    wl = _f64(wl)
+    ls = ls or leaf_soil()
+    rs, rl, tl = np.zeros(wl.size), np.zeros(wl.size), np.zeros(wl.size)
+    _check(lib().gort_spectra(C.byref(ls), _ptr(wl), wl.size, _ptr(rs), _ptr(rl), _ptr(tl)))
+    return rs, rl, tl
+
+
+def prospect_d(N=1.2, Cab=30., Car=10., Anth=1.0, Cbrown=0.0, Cw=0.015, Cm=0.009):
+    RT = np.zeros(2 * NBANDS)
+    _check(lib().gort_prospect_d(N, Cab, Car, Anth, Cbrown, Cw, Cm, _ptr(RT)))
+    return RT
+
+
+def gauleg(n=32):
+    x, w = np.zeros(n), np.zeros(n)
+    lib().gort_gauleg(-1.0, 1.0, _ptr(x), _ptr(w), n)
+    return x, w
+
+
+def lut_text(c):
+    buf = C.create_string_buffer(1 << 15)
+    n = lib().gort_lut_format(C.byref(c), buf, len(buf))
+    if n < 0:
+        _check(int(n))
+    return buf.raw[:n].decode()
+
+
+def lut_read(path, c):
+    _check(lib().gort_lut_read(path.encode(), C.byref(c)))
+
+
+def device_count():
+    return lib().gort_device_count()
+
+
+# ---------------------------------------------------------------- device side
+def gap_probabilities(members):
+    """In place, for one Canopy or a list of them (one workgroup per member)."""
+    single = isinstance(members, Canopy)
+    arr = (Canopy * (1 if single else len(members)))(*([members] if single else members))
+    _check(lib().gort_gap_probabilities(arr, len(arr)))
+    if single:
+        C.memmove(C.byref(members), C.byref(arr[0]), C.sizeof(Canopy))
+        return members
+    for i, m in enumerate(members):
+        C.memmove(C.byref(m), C.byref(arr[i]), C.sizeof(Canopy))
+    return members
+
+
+class Engine:
+    def __init__(self):
+        h = C.c_void_p()
+        _check(lib().gort_engine_create(C.byref(h)))
+        self.h = h
+        self.nw = 0
+
+    def close(self):
+        if self.h:
+            lib().gort_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_canopy(self, c):
+        _check(lib().gort_engine_set_canopy(self.h, C.byref(c)))
+
+    def set_spectra(self, rsoil, rleaf, tleaf):
+        rs, rl, tl = _f64(rsoil), _f64(rleaf), _f64(tleaf)
+        _check(lib().gort_engine_set_spectra(self.h, rs.size, _ptr(rs), _ptr(rl), _ptr(tl)))
+        self.nw = rs.size
+
+    def synchronize(self):
+        _check(lib().gort_engine_synchronize(self.h))
+
+    def rsurf_stream(self, angles_deg, want_scomp=False, want_K=True):
+        ang = _f64(angles_deg).reshape(-1, 4)
+        nA = ang.shape[0]
+        out = np.zeros((nA, self.nw))
+        sc = np.zeros((nA, self.nw, 4)) if want_scomp else None
+        K = np.zeros((nA, 4)) if want_K else None
+        _check(lib().gort_rsurf_stream(self.h, _ptr(ang), nA, _ptr(out), _ptr(sc), _ptr(K)))
+        return out, sc, K
+
+    def rsurf_stream_dev(self, angles_t, rsurf_t, scomp_t=None, K_t=None):
+        _check(lib().gort_rsurf_stream_dev(self.h, _ptr(angles_t), angles_t.shape[0], _ptr(rsurf_t),
+                                           _ptr(scomp_t), _ptr(K_t)))
+
+    def rsurf_grid_dev(self, grid, row_begin, row_end, lut_t):
+        _check(lib().gort_rsurf_grid_dev(self.h, C.byref(grid), row_begin, row_end, _ptr(lut_t)))
+
+    def last_expand_ms(self):
+        return lib().gort_engine_last_expand_ms(self.h)
+
+    def energy_stream(self, angles_deg):
+        ang = _f64(angles_deg).reshape(-1, 4)
+        out = np.zeros((ang.shape[0], self.nw, 3))
+        _check(lib().gort_energy_stream(self.h, _ptr(ang), ang.shape[0], _ptr(out)))
+        return out
+
+    def energy_stream_dev(self, angles_t, energy_t):
+        _check(lib().gort_energy_stream_dev(self.h, _ptr(angles_t), angles_t.shape[0], _ptr(energy_t)))
+
+
+def hemisphere_grid(nsza=91, nvza=91, nphi=361):
+    """Integer-degree full-hemisphere grid of SURVEY.md 8(d) C3."""
+    g = Grid()
+    g.sza0, g.dsza, g.nsza = 0.0, 1.0, nsza
+    g.vza0, g.dvza, g.nvza = 0.0, 1.0, nvza
+    g.phi0, g.dphi, g.nphi = 0.0, 1.0, nphi
+    return g

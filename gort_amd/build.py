@@ -1,0 +1,80 @@
+"""Build libgort_amd.so (HIP kernels + C ABI, gfx950) and the `gortt` drop-in executable.
+
+    python -m gort_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  Everything is built in-tree:
+gort_amd/libgort_amd.so and gort_amd/bin/gortt travel to the GPU box with the
+repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+SRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "csrc", "build")
+LIB = os.path.join(PKG, "libgort_amd.so")
+BIN = os.path.join(PKG, "bin", "gortt")
+ARCH = "gfx950"
+
+# (source, extra flags).  The gap kernel and the host precompute keep IEEE operation order
+# (-ffp-contract=off): they feed integer truncations / are compared to the last bits.
+UNITS = [
+    ("gort_gap.hip", ["-ffp-contract=off"]),
+    ("gort_brdf.hip", []),
+    ("gort_api.hip", []),
+    ("gort_host.cpp", ["-ffp-contract=off", '-DGORT_DATA_DIR="%s"' % os.path.join(PKG, "data")]),
+]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required)")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    print("[gort_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build(force=False, verbose_resources=False):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    cc = hipcc()
+    headers = [os.path.join(ROOT, "include", "gort_amd.h"), os.path.join(SRC, "gort_internal.h"),
+               os.path.abspath(__file__)]
+    data = [os.path.join(PKG, "data", f) for f in ("prospect_d_coeffs.f32", "price_soil_eofs.f64")]
+    common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
+              "-I" + SRC, "--offload-arch=" + ARCH]
+    if verbose_resources:
+        common.append("-Rpass-analysis=kernel-resource-usage")
+    objs = []
+    for src, extra in UNITS:
+        s = os.path.join(SRC, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        deps = [s] + headers + (data if src == "gort_host.cpp" else [])
+        if force or _newer(o, deps):
+            _run([cc] + common + extra + ["-c", s, "-o", o])
+        objs.append(o)
+    if force or _newer(LIB, objs):
+        _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+    main = os.path.join(SRC, "gortt_main.cpp")
+    if os.path.exists(main) and (force or _newer(BIN, [main, LIB] + headers)):
+        _run([cc, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), main, "-o", BIN,
+              "-L" + PKG, "-lgort_amd", "-Wl,-rpath,$ORIGIN/.."])
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose_resources="--resources" in sys.argv)

@@ -1,0 +1,341 @@
+// gort_api.hip -- C-ABI entry points of libgort_amd.so that touch the device.
+//
+// Host memory in, host memory out for the `gortt` CLI; `_dev` variants take device
+// pointers so that a caller which already owns HBM buffers (bench.py, an ensemble
+// driver) pays no PCIe traffic.  No CPU fallback: every entry point fails with
+// GORT_ENODEVICE when HIP is unusable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gort_internal.h"
+
+namespace gort {
+
+#define GORT_HIP(call)                                                                              \
+    do {                                                                                            \
+        hipError_t err__ = (call);                                                                  \
+        if (err__ != hipSuccess)                                                                    \
+            return fail(GORT_ENODEVICE, "%s: %s", #call, hipGetErrorString(err__));                 \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return GORT_OK;
+        if (p) GORT_HIP(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        GORT_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return GORT_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace gort
+
+using namespace gort;
+
+struct gort_engine {
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;          // start/stop pairs around the LUT expansion kernel
+    size_t ev_used = 0;
+    DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
+    gort_canopy host_canopy;
+    bool have_canopy = false, have_spectra = false, have_nodes = false;
+    int nw = 0;
+    std::vector<double> h_rsoil, h_rleaf, h_tleaf;
+};
+
+extern "C" int gort_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------ gap probabilities
+
+extern "C" int gort_gap_probabilities_dev(gort_canopy *members_dev, int n_members, void *stream)
+{
+    if (!members_dev || n_members < 0) return fail(GORT_EINVAL, "gort_gap_probabilities_dev: bad argument");
+    return launch_gap_probabilities(members_dev, n_members, stream);
+}
+
+extern "C" int gort_gap_probabilities(gort_canopy *members, int n_members)
+{
+    if (!members || n_members < 0) return fail(GORT_EINVAL, "gort_gap_probabilities: bad argument");
+    if (n_members == 0) return GORT_OK;
+    if (gort_device_count() <= 0) return fail(GORT_ENODEVICE, "gort_gap_probabilities: no HIP device");
+    gort_canopy *dev = nullptr;
+    const size_t bytes = sizeof(gort_canopy) * (size_t)n_members;
+    GORT_HIP(hipMalloc((void **)&dev, bytes));
+    int rc = GORT_OK;
+    hipError_t e = hipMemcpy(dev, members, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = launch_gap_probabilities(dev, n_members, nullptr);
+        if (rc == GORT_OK) e = hipMemcpy(members, dev, bytes, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(GORT_ENODEVICE, "gort_gap_probabilities: %s", hipGetErrorString(e));
+    return rc;
+}
+
+// ----------------------------------------------------------------------- engine
+
+extern "C" int gort_engine_create(gort_engine **out)
+{
+    if (!out) return fail(GORT_EINVAL, "gort_engine_create: null out");
+    *out = nullptr;
+    if (gort_device_count() <= 0) return fail(GORT_ENODEVICE, "gort_engine_create: no HIP device");
+    gort_engine *e = new (std::nothrow) gort_engine();
+    if (!e) return fail(GORT_ENOMEM, "gort_engine_create: out of memory");
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        gort_engine_destroy(e);
+        return fail(GORT_ENODEVICE, "gort_engine_create: cannot create stream");
+    }
+    *out = e;
+    return GORT_OK;
+}
+
+extern "C" void gort_engine_destroy(gort_engine *e)
+{
+    if (!e) return;
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
+                      &e->out2})
+        b->release();
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" void *gort_engine_stream(gort_engine *e) { return e ? (void *)e->stream : nullptr; }
+extern "C" int gort_engine_nw(const gort_engine *e) { return e ? e->nw : 0; }
+
+extern "C" int gort_engine_synchronize(gort_engine *e)
+{
+    if (!e) return fail(GORT_EINVAL, "gort_engine_synchronize: null engine");
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    return GORT_OK;
+}
+
+static int refresh_lambda_table(gort_engine *e)
+{
+    if (!e->have_canopy || !e->have_spectra) return GORT_OK;
+    const int nw = e->nw;
+    int rc = e->L.reserve(sizeof(double) * L_NSLOT * (size_t)nw);
+    if (rc) return rc;
+    const double *sp = e->spectra.as<double>();
+    return launch_lambda_table(e->canopy.as<gort_canopy>(), nw, sp, sp + nw, sp + 2 * nw, e->L.as<double>(),
+                               e->stream);
+}
+
+extern "C" int gort_engine_set_canopy(gort_engine *e, const gort_canopy *c)
+{
+    if (!e || !c) return fail(GORT_EINVAL, "gort_engine_set_canopy: bad argument");
+    int rc = e->canopy.reserve(sizeof(gort_canopy));
+    if (rc) return rc;
+    // the stream may still be reading the previous record
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    e->host_canopy = *c;
+    GORT_HIP(hipMemcpyAsync(e->canopy.p, &e->host_canopy, sizeof(gort_canopy), hipMemcpyHostToDevice, e->stream));
+    e->have_canopy = true;
+    return refresh_lambda_table(e);
+}
+
+extern "C" int gort_engine_set_spectra(gort_engine *e, int nw, const double *rsoil, const double *rleaf,
+                                       const double *tleaf)
+{
+    if (!e || nw <= 0 || !rsoil || !rleaf || !tleaf) return fail(GORT_EINVAL, "gort_engine_set_spectra: bad argument");
+    int rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw);
+    if (rc) return rc;
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    e->h_rsoil.assign(rsoil, rsoil + nw);
+    e->h_rleaf.assign(rleaf, rleaf + nw);
+    e->h_tleaf.assign(tleaf, tleaf + nw);
+    double *sp = e->spectra.as<double>();
+    const size_t b = sizeof(double) * (size_t)nw;
+    GORT_HIP(hipMemcpyAsync(sp, e->h_rsoil.data(), b, hipMemcpyHostToDevice, e->stream));
+    GORT_HIP(hipMemcpyAsync(sp + nw, e->h_rleaf.data(), b, hipMemcpyHostToDevice, e->stream));
+    GORT_HIP(hipMemcpyAsync(sp + 2 * nw, e->h_tleaf.data(), b, hipMemcpyHostToDevice, e->stream));
+    e->nw = nw;
+    e->have_spectra = true;
+    return refresh_lambda_table(e);
+}
+
+static int require_ready(const gort_engine *e, const char *who)
+{
+    if (!e) return fail(GORT_EINVAL, "%s: null engine", who);
+    if (!e->have_canopy) return fail(GORT_EINVAL, "%s: no canopy set", who);
+    if (!e->have_spectra) return fail(GORT_EINVAL, "%s: no spectra set", who);
+    return GORT_OK;
+}
+
+// ----------------------------------------------------------------- BRDF stream
+
+extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *rsurf_dev,
+                                     double *scomp_dev, double *K_dev)
+{
+    int rc = require_ready(e, "gort_rsurf_stream_dev");
+    if (rc) return rc;
+    if (nA < 0 || (nA > 0 && (!angles_dev || !rsurf_dev))) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
+    if (nA == 0) return GORT_OK;
+    rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA);
+    if (rc) return rc;
+    const gort_canopy *c = e->canopy.as<gort_canopy>();
+    rc = launch_geometry_stream(c, angles_dev, nA, e->coef.as<double>(), K_dev, e->stream);
+    if (rc) return rc;
+    return launch_expand_stream(c, e->L.as<double>(), e->nw, e->coef.as<double>(), nA, rsurf_dev, scomp_dev, e->stream);
+}
+
+extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, double *rsurf, double *scomp,
+                                 double *K)
+{
+    int rc = require_ready(e, "gort_rsurf_stream");
+    if (rc) return rc;
+    if (nA < 0 || (nA > 0 && (!angles || !rsurf))) return fail(GORT_EINVAL, "gort_rsurf_stream: bad argument");
+    if (nA == 0) return GORT_OK;
+    const size_t nw = (size_t)e->nw, n = (size_t)nA;
+    if ((rc = e->angles.reserve(sizeof(double) * 4 * n))) return rc;
+    if ((rc = e->out.reserve(sizeof(double) * n * nw))) return rc;
+    if (scomp && (rc = e->out2.reserve(sizeof(double) * 4 * n * nw))) return rc;
+    if (K && (rc = e->K.reserve(sizeof(double) * 4 * n))) return rc;
+    GORT_HIP(hipMemcpyAsync(e->angles.p, angles, sizeof(double) * 4 * n, hipMemcpyHostToDevice, e->stream));
+    rc = gort_rsurf_stream_dev(e, e->angles.as<double>(), nA, e->out.as<double>(),
+                               scomp ? e->out2.as<double>() : nullptr, K ? e->K.as<double>() : nullptr);
+    if (rc) return rc;
+    GORT_HIP(hipMemcpyAsync(rsurf, e->out.p, sizeof(double) * n * nw, hipMemcpyDeviceToHost, e->stream));
+    if (scomp) GORT_HIP(hipMemcpyAsync(scomp, e->out2.p, sizeof(double) * 4 * n * nw, hipMemcpyDeviceToHost, e->stream));
+    if (K) GORT_HIP(hipMemcpyAsync(K, e->K.p, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, e->stream));
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    return GORT_OK;
+}
+
+// ------------------------------------------------------------------ LUT (grid)
+
+extern "C" int gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, long row_end, double *lut_dev)
+{
+    int rc = require_ready(e, "gort_rsurf_grid_dev");
+    if (rc) return rc;
+    if (!g || g->nsza <= 0 || g->nvza <= 0 || g->nphi <= 0) return fail(GORT_EINVAL, "gort_rsurf_grid_dev: bad grid");
+    const long rows_total = (long)g->nsza * g->nvza;
+    if (row_begin < 0 || row_end > rows_total || row_begin > row_end)
+        return fail(GORT_EINVAL, "gort_rsurf_grid_dev: rows [%ld,%ld) outside [0,%ld)", row_begin, row_end, rows_total);
+    if (row_begin == row_end) return GORT_OK;
+    if (!lut_dev) return fail(GORT_EINVAL, "gort_rsurf_grid_dev: null output");
+    const long rows = row_end - row_begin, nA = rows * g->nphi;
+    const int nw = e->nw;
+    if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
+    const gort_canopy *c = e->canopy.as<gort_canopy>();
+    if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), e->stream))) return rc;
+    if (nw < 128 || nw > 9 * 256) {
+        // few bands: one thread per sample straight from the angle records
+        return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, e->stream);
+    }
+    const int is0 = (int)(row_begin / g->nvza), is1 = (int)((row_end - 1) / g->nvza) + 1;
+    if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(is1 - is0)))) return rc;
+    if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, is0, is1, e->sun.as<double>(), e->stream))) return rc;
+    // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to
+    // 512 launches are kept between two gort_engine_last_expand_ms() calls
+    const bool timed = e->ev_used + 2 <= 1024;
+    if (timed) {
+        while (e->ev.size() < e->ev_used + 2) {
+            hipEvent_t ev;
+            GORT_HIP(hipEventCreate(&ev));
+            e->ev.push_back(ev);
+        }
+        GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
+    }
+    rc = launch_expand_grid(e->sun.as<double>(), is0, e->coef.as<double>(), nw, g->nvza, g->nphi, row_begin, row_end,
+                            lut_dev, e->stream);
+    if (timed) {
+        GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
+        e->ev_used += 2;
+    }
+    return rc;
+}
+
+extern "C" double gort_engine_last_expand_ms(gort_engine *e)
+{
+    if (!e || e->ev_used == 0) return -1.0;
+    double sum = 0.0;
+    const size_t n = e->ev_used / 2;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e->ev[2 * i + 1]) != hipSuccess ||
+            hipEventElapsedTime(&ms, e->ev[2 * i], e->ev[2 * i + 1]) != hipSuccess)
+            return -1.0;
+        sum += ms;
+    }
+    e->ev_used = 0;
+    return sum / (double)n;
+}
+
+// ---------------------------------------------------------------------- energy
+
+static int ensure_nodes(gort_engine *e)
+{
+    if (e->have_nodes) return GORT_OK;
+    const int np = GORT_NPOINTS;
+    double x[GORT_NPOINTS], w[GORT_NPOINTS];
+    gort_gauleg(-1., 1., x, w, np);
+    // outer: azimuth nodes vaa = pi + pi*x_i; inner: zenith nodes from the positive half of the
+    // same rule, vza = acos(x_j), weight w_j |x_j| (gortt_albedo.c:82-133), result / pi (:136)
+    const double xm = 0.5 * (1. - 1.), xr = 0.5 * (1. + 1.);
+    const double ym = 0.5 * (2. * M_PI - 0.), yr = 0.5 * (2. * M_PI + 0.);
+    std::vector<double> nodes(3 * 512);
+    int n = 0;
+    for (int i = 0; i < np; ++i)
+        for (int j = np / 2; j < np; ++j, ++n) {
+            const double xx = xm + xr * x[j];
+            nodes[3 * n] = ym + yr * x[i];
+            nodes[3 * n + 1] = std::acos(xx);
+            nodes[3 * n + 2] = (w[j] * std::fabs(xx) * xr) * (w[i] * yr) / M_PI;
+        }
+    int rc = e->nodes.reserve(sizeof(double) * nodes.size());
+    if (rc) return rc;
+    GORT_HIP(hipMemcpy(e->nodes.p, nodes.data(), sizeof(double) * nodes.size(), hipMemcpyHostToDevice));
+    e->have_nodes = true;
+    return GORT_OK;
+}
+
+extern "C" int gort_energy_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *energy_dev)
+{
+    int rc = require_ready(e, "gort_energy_stream_dev");
+    if (rc) return rc;
+    if (nA < 0 || (nA > 0 && (!angles_dev || !energy_dev))) return fail(GORT_EINVAL, "gort_energy_stream_dev: bad argument");
+    if (nA == 0) return GORT_OK;
+    if ((rc = ensure_nodes(e))) return rc;
+    return launch_energy(e->canopy.as<gort_canopy>(), e->L.as<double>(), e->nw, angles_dev, nA,
+                         e->nodes.as<double>(), energy_dev, e->stream);
+}
+
+extern "C" int gort_energy_stream(gort_engine *e, const double *angles, long nA, double *energy)
+{
+    int rc = require_ready(e, "gort_energy_stream");
+    if (rc) return rc;
+    if (nA < 0 || (nA > 0 && (!angles || !energy))) return fail(GORT_EINVAL, "gort_energy_stream: bad argument");
+    if (nA == 0) return GORT_OK;
+    const size_t n = (size_t)nA, nw = (size_t)e->nw;
+    if ((rc = e->angles.reserve(sizeof(double) * 4 * n))) return rc;
+    if ((rc = e->out.reserve(sizeof(double) * 3 * n * nw))) return rc;
+    GORT_HIP(hipMemcpyAsync(e->angles.p, angles, sizeof(double) * 4 * n, hipMemcpyHostToDevice, e->stream));
+    if ((rc = gort_energy_stream_dev(e, e->angles.as<double>(), nA, e->out.as<double>()))) return rc;
+    GORT_HIP(hipMemcpyAsync(energy, e->out.p, sizeof(double) * 3 * n * nw, hipMemcpyDeviceToHost, e->stream));
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    return GORT_OK;
+}

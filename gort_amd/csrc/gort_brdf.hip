@@ -1,0 +1,617 @@
+// gort_brdf.hip -- per-sample GORT BRDF and hemispherical albedo on gfx950.
+//
+// The reference evaluates, per (angle line, wavelength), a tree of ~40 tiny functions
+// (gortt.c:385-578 + gortt_brdf.c) that recompute the same exponentials dozens of
+// times.  Here the work is factored by what each term depends on:
+//
+//   wavelength only      L[11][nw]          lambda_table_kernel      (once per spectra set)
+//   angle tuple only     coef[nA][16]       geometry_*_kernel        (Kc,Kg,Kt,Kz, hot spot, ...)
+//   (sun zenith, band)   C0,B,Z,G,T         sun_terms()              (5 numbers)
+//   sample               rsurf = aC*C0 + aB*B + aZ*Z + aG*G + aT*T   (5 FMAs, 8 B stored)
+//
+// which is an exact regrouping of gortt.c:484-557 (no approximation; rounding differs
+// at the 1e-16 level).  The LUT kernel keeps the five (sun zenith, band) numbers of its
+// bands in registers, reads the five angle coefficients through the scalar cache and
+// does nothing else but FMA + store: it is bound by HBM write bandwidth (8 B/sample).
+//
+// No MFMA: K=5 is not a matrix-core shape and the kernel is store-bound anyway.
+#include <hip/hip_runtime.h>
+
+#include "gort_internal.h"
+
+namespace gort {
+namespace {
+
+constexpr double PI = 3.14159265358979323846;
+constexpr double INV_PI = 0.318309886183790671538;   // M_1_PI
+
+// reference MAX/MIN macros (gortt.h:9-10): a NaN in the second slot survives
+__device__ inline double ref_max(double x, double y) { return x > y ? x : y; }
+__device__ inline double ref_min(double x, double y) { return x < y ? x : y; }
+
+struct SunScalars { double fd, mu, t0, tp0, eps, pn0; };
+
+// ------------------------------------------------------------------ geometry
+
+// linear interpolation in the 1-degree gap tables (gortt.c:872-915).  The reference
+// indexes past the table for zenith > 90 deg; defined here as NaN.
+__device__ inline void gap_lookup(const gort_canopy &c, double za, double &pn0, double &epg)
+{
+    const double pos = fabs(za) / c.dth;
+    const double cf = ceil(pos), ff = floor(pos);
+    if (!(cf <= (double)(GORT_NTH - 1))) { pn0 = epg = __builtin_nan(""); return; }
+    const int ci = (int)cf, fi = (int)ff;
+    const double d = pos - ff;
+    pn0 = d * c.p_n0[ci] + (1.0 - d) * c.p_n0[fi];
+    epg = d * c.epgap[ci] + (1.0 - d) * c.epgap[fi];
+}
+
+// sign / azimuth conventions of main() (gortt.c:240-279); degrees in, radians out
+__device__ inline void normalise_angles(double vza_deg, double vaa_deg, double sza_deg, double saa_deg,
+                                        double &vza, double &sza, double &saa, double &raa)
+{
+#pragma clang fp contract(off)
+    vza = vza_deg * PI / 180.0;
+    double vaa = vaa_deg * PI / 180.0;
+    sza = sza_deg * PI / 180.0;
+    saa = saa_deg * PI / 180.0;
+    if (sza < 0.0) { saa += PI; sza *= -1.0; }
+    if (vza < 0.0) { vaa += PI; vza *= -1.0; }
+    // the reference wraps by repeated subtraction; beyond +-64 turns fold first so that
+    // absurd inputs cannot stall a wavefront (documented deviation)
+    if (fabs(saa) > 128 * PI) saa = fmod(saa, 2 * PI);
+    if (fabs(vaa) > 128 * PI) vaa = fmod(vaa, 2 * PI);
+    while (saa > 2 * PI) saa -= 2 * PI;
+    while (vaa > 2 * PI) vaa -= 2 * PI;
+    while (saa < 0) saa += 2 * PI;
+    while (vaa < 0) vaa += 2 * PI;
+    raa = saa - vaa;
+    raa = fabs((raa - 2 * PI * (int)(0.5 + raa * INV_PI * 0.5)));    // C truncation toward zero
+}
+
+struct Primed { double ang, s, c, sec, t; };     // theta' = atan((b/r) tan theta)  (gortt.c:581-588)
+
+__device__ inline Primed prime(double ell, double tan_za)
+{
+    Primed p;
+    p.ang = atan(ell * tan_za);
+    sincos(p.ang, &p.s, &p.c);
+    p.sec = 1.0 / p.c;
+    p.t = p.s / p.c;
+    return p;
+}
+
+// mutual-shadowing overlap O(theta_s', theta_v', phi)  (gortt_brdf.c:23-100)
+__device__ inline double overlap(double hb, const Primed &s, const Primed &v, double cphi, double sphi)
+{
+    const double d = s.t * s.t + v.t * v.t - 2.0 * s.t * v.t * cphi;
+    const double D = sqrt(ref_max(0.0, d));
+    const double x = s.t * v.t * sphi;
+    const double t2 = sqrt(D * D + x * x);
+    const double t1 = s.sec + v.sec;
+    double cos_t = hb * t2 / t1;
+    cos_t = ref_max(-1.0, cos_t);
+    cos_t = ref_min(1.0, cos_t);
+    const double t = acos(cos_t);
+    return ref_max(0.0, (t - sin(t) * cos_t) * t1 / PI);
+}
+
+struct GeomOut {
+    double Kc, Kg, Kt, Kz, Kpg, Kpz, A;    // A = kuusk / (2 cos(sza') cos(vza'))
+    SunScalars sun;
+};
+
+// areal proportions + hot spot for one normalised geometry.
+// Restates gortt_kg/gortt_kc/gortt_kc_fFbeta (gortt_brdf.c:7-238), the angle part of
+// gortt_rsurf (gortt.c:424-449) and gortt_kuusk (gortt_brdf.c:638-702).
+__device__ void geometry_core(const gort_canopy &c, double vza, double sza, double raa, GeomOut &o)
+{
+    const double ell = c.b / c.r;
+    double sin_vz, cos_vz, sin_sz, cos_sz;
+    sincos(vza, &sin_vz, &cos_vz);
+    sincos(sza, &sin_sz, &cos_sz);
+    const Primed v = prime(ell, sin_vz / cos_vz);
+    const Primed s = prime(ell, sin_sz / cos_sz);
+    double sin_r, cos_r;
+    sincos(raa, &sin_r, &cos_r);
+
+    const double cov = c.lambda * PI * c.rr;              // lambda pi r^2
+    const double hb = c.h / c.b;
+    const double t1 = s.sec + v.sec;
+
+    // three azimuths: the actual one, 0 and pi (Kc is interpolated between the
+    // principal-plane values, gortt_brdf.c:143-159)
+    const double O_r = overlap(hb, s, v, cos_r, sin_r);
+    const double O_0 = overlap(hb, s, v, 1.0, 0.0);
+    const double O_pi = overlap(hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
+    const double Kg = exp(-(cov * (t1 - O_r)));
+    const double Kg0 = exp(-(cov * (t1 - O_0)));
+    const double Kgpi = exp(-(cov * (t1 - O_pi)));
+
+    const double xs = cov * s.sec, xv = cov * v.sec;
+    const double es = exp(-xs), ev = exp(-xv);
+    const double Mi = 1.0 - (1.0 - es) / xs;
+    const double Mv = 1.0 - (1.0 - ev) / xv;
+    const double theta_Mi = acos(1.0 - 2.0 * Mi);
+    const double Gv = PI * c.rr * v.sec;
+
+    // F at the actual azimuth
+    const double ph_r = v.c * s.c + v.s * s.s * cos_r;
+    const double F_r = (Gv * 0.5 * (1.0 + ph_r)) / (PI * c.rr * (t1 - O_r));
+
+    // f*F on the principal plane, phi = 0 and phi = pi
+    const bool view_steeper = fabs(vza) > fabs(sza);
+    double fF[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double cphi = q ? -1.0 : 1.0;
+        const double Oq = q ? O_pi : O_0, Kgq = q ? Kgpi : Kg0;
+        const double ph = v.c * s.c + v.s * s.s * cphi;
+        const double Gam = PI * c.rr * (t1 - Oq);
+        const double Gc = Gv * 0.5 * (1.0 + ph);
+        const double F = Gc / Gam;
+        const double M = 1.0 - (1.0 - Kgq) / (c.lambda * Gam);
+        const double PiMi = (1 - cos(theta_Mi * (1 - (s.ang - v.ang * cphi) / PI))) / 2.0;
+        const double PvMv = Mv - (1.0 - cos(v.ang * cphi - s.ang)) / 2.0;
+        // phi = pi lies in (90,270) deg -> Po = PvMv; phi = 0 -> by steepness (gortt_brdf.c:219-221)
+        const double Po = (q == 1) ? PvMv : (view_steeper ? PiMi : PvMv);
+        const double f = F * (1.0 - Gv * (PvMv + PiMi - Po) / Gc) / (1.0 - M);
+        fF[q] = f * F;
+    }
+
+    double beta;
+    if (c.use_user_beta) {
+        beta = c.beta;
+    } else if (s.ang < 0.000000001) {
+        beta = 0.0;
+    } else {
+        const double Dd = c.r * (1.0 / tan(s.ang / 2.0));
+        const double dh = (c.h2 - c.h1) / Dd;
+        const double lg = c.lambda * Gv;
+        beta = lg / (lg + dh) * (1.0 - exp(-lg - dh)) / (1.0 - exp(-lg));
+    }
+    double frac = raa / PI;
+    if (frac > 1.0) frac = 2.0 - frac;
+    double f = (1. - frac) * fF[0] + frac * fF[1];
+    f = beta * f + (1.0 - beta) * F_r;
+    const double Kc = f * (1.0 - Kg);
+
+    const double Kz = ev - Kg;                               // gortt.c:439
+    const double Kt = ref_max(0.0, 1.0 - Kc - Kz - Kg);      // gortt.c:443-444
+    const double Kpg = es - Kg;                              // gortt.c:448
+    const double Kpz = 1.0 - ev - Kpg;                       // gortt.c:449
+
+    // zenith-dependent gap probabilities and Kuusk's hot spot (unprimed angles in cos xi)
+    double pn0_s, eps_s, pn0_v, eps_v;
+    gap_lookup(c, sza, pn0_s, eps_s);
+    gap_lookup(c, vza, pn0_v, eps_v);
+    const double cos_xi = cos_sz * cos_vz + sin_sz * sin_vz * cos_r;
+    const double kf = c.k * c.favd;
+    const double ls = -log(eps_s) / kf;
+    const double lv = -log(eps_v) / (0.5 * c.favd);
+    const double q2 = ls * ls + lv * lv - 2. * ls * lv * cos_xi;
+    double h2 = 1.0;
+    if (q2 > 0.0) {
+        const double lsv = sqrt(q2) / c.r;
+        h2 = (1.0 - exp(-lsv)) / lsv;
+    }
+    const double h1 = (ls * lv) > 0.0 ? sqrt(ls * lv) : 0.0;
+    const double kuusk = eps_s * eps_v * exp(kf * h1 * h2);
+
+    o.Kc = Kc;  o.Kg = Kg;  o.Kt = Kt;  o.Kz = Kz;  o.Kpg = Kpg;  o.Kpz = Kpz;
+    o.A = kuusk / (2.0 * s.c * v.c);
+    o.sun.fd = c.use_user_fd ? c.fd_user : cos_sz / (cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291
+    o.sun.mu = s.c;
+    o.sun.t0 = exp(-(c.k * c.elai * s.sec));
+    o.sun.tp0 = pn0_s + eps_s;
+    o.sun.eps = eps_s;
+    o.sun.pn0 = pn0_s;
+}
+
+__device__ inline void store_coef(double *rec, const gort_canopy &c, const GeomOut &g)
+{
+    const double fd = g.sun.fd, kep = c.k_openep;
+    rec[C_FDA] = fd * g.A;
+    rec[C_KPZ] = fd * kep * g.Kpz;
+    rec[C_KPG] = fd * kep * g.Kpg;
+    rec[A_C] = g.Kc;
+    rec[A_B] = g.Kc * rec[C_FDA];
+    rec[A_Z] = g.Kc * rec[C_KPZ] + g.Kz;
+    rec[A_G] = g.Kc * rec[C_KPG] + g.Kg;
+    rec[A_T] = g.Kt;
+    rec[S_FD] = fd;  rec[S_MU] = g.sun.mu;  rec[S_T0] = g.sun.t0;  rec[S_TP0] = g.sun.tp0;
+    rec[S_EPS] = g.sun.eps;  rec[S_PN0] = g.sun.pn0;
+    rec[C_PAD0] = 0.0;  rec[C_PAD1] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy *__restrict__ canopy,
+                                                               const double *__restrict__ angles, long nA,
+                                                               double *__restrict__ coef, double *__restrict__ K)
+{
+    const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nA) return;
+    const gort_canopy &c = *canopy;
+    double vza, sza, saa, raa;
+    normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
+    GeomOut g;
+    geometry_core(c, vza, sza, raa, g);
+    store_coef(coef + a * GORT_COEF_STRIDE, c, g);
+    if (K) { K[4 * a] = g.Kc;  K[4 * a + 1] = g.Kg;  K[4 * a + 2] = g.Kt;  K[4 * a + 3] = g.Kz; }
+}
+
+// grid nodes generated from indices; identical to streaming "vza phi sza 0" 
+__global__ __launch_bounds__(256) void geometry_grid_kernel(const gort_canopy *__restrict__ canopy, gort_grid g,
+                                                             long row_begin, long n_angles,
+                                                             double *__restrict__ coef)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_angles) return;
+    const long row = row_begin + i / g.nphi;
+    const int l = (int)(i % g.nphi);
+    const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
+    double vza, sza, saa, raa;
+    normalise_angles(g.vza0 + ivza * g.dvza, g.phi0 + l * g.dphi, g.sza0 + isza * g.dsza, 0.0, vza, sza, saa, raa);
+    GeomOut o;
+    geometry_core(*canopy, vza, sza, raa, o);
+    store_coef(coef + i * GORT_COEF_STRIDE, *canopy, o);
+}
+
+// ------------------------------------------------------- wavelength-only table
+
+// Two-stream closed forms that depend on the band only (gortt_brdf.c:348-634 hoisted)
+__global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__restrict__ canopy, int nw,
+                                                            const double *__restrict__ rsoil,
+                                                            const double *__restrict__ rleaf,
+                                                            const double *__restrict__ tleaf,
+                                                            double *__restrict__ L)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const gort_canopy &c = *canopy;
+    const double rs = rsoil[i], rl = rleaf[i], tl = tleaf[i];
+    const double omega = rl + tl;
+    const double gam = sqrt(1 - omega);
+    const double Rff = (1.0 - gam) / (1.0 + gam);
+    const double Tff = exp(-(2.0 * gam * c.k * c.elai));
+    const double RT = Rff * Tff;
+    const double tff = Tff * (1. - Rff * Rff) / (1. - RT * RT);
+    const double pff = Rff * (1. - Tff * Tff) / (1. - RT * RT);
+    const double kopen = c.k_open + c.k_openep;
+    const double tpff = tff * (1.0 - kopen) + kopen;
+    const double gfun = -(4.0 / 9.0) * (rl - tl) / omega;
+    const double mgk = (rs / (1.0 - rs * pff)) * (tpff - c.k_open);
+    L[L_GAMMA * nw + i] = gam;
+    L[L_OMEGA * nw + i] = omega;
+    L[L_RFF * nw + i] = Rff;
+    L[L_TFF * nw + i] = Tff;
+    L[L_tFF * nw + i] = tff;
+    L[L_PFF * nw + i] = pff;
+    L[L_RS * nw + i] = rs;
+    L[L_MGK * nw + i] = mgk;
+    L[L_ZF * nw + i] = (tpff - c.k_openep) * rs;
+    L[L_TF * nw + i] = tpff * mgk;
+    L[L_B * nw + i] = (1.0 - omega) * omega * (1.0 - gfun);
+}
+
+struct SunTerms { double C0, B, Z, G, T; };
+
+// the five (sun zenith, band) numbers
+__device__ inline SunTerms sun_terms(const double *__restrict__ L, int nw, int i, const SunScalars &s,
+                                     double ko, double kep)
+{
+    const double gam = L[L_GAMMA * nw + i], omega = L[L_OMEGA * nw + i];
+    const double Rff = L[L_RFF * nw + i], Tff = L[L_TFF * nw + i];
+    const double tff = L[L_tFF * nw + i], pff = L[L_PFF * nw + i];
+    const double rs = L[L_RS * nw + i], mgk = L[L_MGK * nw + i];
+    const double Zf = L[L_ZF * nw + i], Tf = L[L_TF * nw + i];
+    const double mu = s.mu, fd = s.fd;
+    const double Rdf = (1.0 - gam) / (1.0 + 2.0 * mu * gam);                   // gortt_brdf.c:552
+    const double g2 = 2. * gam * mu;
+    const double Tdf = (omega / 2.0) * ((1. + 2. * mu) / (1. - g2 * g2)) * (Tff - s.t0);   // :467-471
+    const double X = s.t0 * Rdf + Tdf * Rff;
+    const double tdf = Tdf - pff * X;                                           // :423-424
+    const double pdf = Rdf - tff * X;                                           // :628-630
+    const double tpdf = tdf * (1 - s.tp0);                                      // :361
+    SunTerms o;
+    o.B = L[L_B * nw + i];
+    o.G = fd * rs + (1 - fd) * rs;                                              // gortt.c:481-484
+    o.Z = fd * ((tpdf + s.eps) * rs) + (1 - fd) * Zf;                           // gortt.c:491-494
+    const double Td = (tpdf + s.tp0) * mgk;                                     // gortt.c:541-543
+    o.T = fd * Td + (1 - fd) * Tf;                                              // gortt.c:550
+    const double kk = kep + ko;
+    const double CfG = (kk * o.G + (1 - kk) * o.Z) * kep;                       // gortt.c:516-517
+    o.C0 = fd * (pdf + Td) + (1 - fd) * (pff + CfG + Tf);
+    return o;
+}
+
+__device__ inline SunScalars load_sun(const double *__restrict__ rec)
+{
+    SunScalars s;
+    s.fd = rec[S_FD];  s.mu = rec[S_MU];  s.t0 = rec[S_T0];  s.tp0 = rec[S_TP0];
+    s.eps = rec[S_EPS];  s.pn0 = rec[S_PN0];
+    return s;
+}
+
+// ------------------------------------------------ stream expansion (any angles)
+
+// one thread per (angle line, band); consecutive lanes = consecutive bands
+template <bool WITH_SCOMP>
+__global__ __launch_bounds__(256) void expand_stream_kernel(const gort_canopy *__restrict__ canopy,
+                                                             const double *__restrict__ L, int nw,
+                                                             const double *__restrict__ coef, long n_samples,
+                                                             double *__restrict__ rsurf, double *__restrict__ scomp)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_samples) return;
+    const long a = idx / nw;
+    const int i = (int)(idx - a * nw);
+    const double *rec = coef + a * GORT_COEF_STRIDE;
+    const SunScalars s = load_sun(rec);
+    const SunTerms b = sun_terms(L, nw, i, s, canopy->k_open, canopy->k_openep);
+    rsurf[idx] = rec[A_C] * b.C0 + rec[A_B] * b.B + rec[A_Z] * b.Z + rec[A_G] * b.G + rec[A_T] * b.T;
+    if (WITH_SCOMP) {
+        double4 o;
+        o.x = b.C0 + rec[C_FDA] * b.B + rec[C_KPZ] * b.Z + rec[C_KPG] * b.G;    // C
+        o.y = b.G;
+        o.z = b.T;
+        o.w = b.Z;
+        reinterpret_cast<double4 *>(scomp)[idx] = o;
+    }
+}
+
+// ------------------------------------------------------------ LUT (grid) path
+
+// sun[isza][5][nw]
+__global__ __launch_bounds__(256) void sun_table_kernel(const gort_canopy *__restrict__ canopy,
+                                                         const double *__restrict__ L, int nw, gort_grid g,
+                                                         int isza_begin, int n_sza, double *__restrict__ sun)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int js = blockIdx.y;
+    if (i >= nw || js >= n_sza) return;
+    const gort_canopy &c = *canopy;
+    // sun-only scalars exactly as geometry_core derives them for "vza phi sza 0"
+    double vza, sza, saa, raa;
+    normalise_angles(0.0, 0.0, g.sza0 + (isza_begin + js) * g.dsza, 0.0, vza, sza, saa, raa);
+    double sin_sz, cos_sz;
+    sincos(sza, &sin_sz, &cos_sz);
+    const Primed sp = prime(c.b / c.r, sin_sz / cos_sz);
+    SunScalars s;
+    gap_lookup(c, sza, s.pn0, s.eps);
+    s.fd = c.use_user_fd ? c.fd_user : cos_sz / (cos_sz + 0.09);
+    s.mu = sp.c;
+    s.t0 = exp(-(c.k * c.elai * sp.sec));
+    s.tp0 = s.pn0 + s.eps;
+    const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
+    double *o = sun + (long)js * 5 * nw;
+    o[0 * nw + i] = b.C0;
+    o[1 * nw + i] = b.B;
+    o[2 * nw + i] = b.Z;
+    o[3 * nw + i] = b.G;
+    o[4 * nw + i] = b.T;
+}
+
+// The hot kernel.  One workgroup per (sun zenith, view zenith) row of the LUT; thread
+// `tid` owns bands tid, tid+256, ... (NP passes) and keeps their five sun terms in
+// registers for the whole row; the loop over the relative-azimuth nodes reads the five
+// angle coefficients (workgroup-uniform -> scalar loads) and streams 8 B per lane,
+// 512 contiguous bytes per wave-instruction, to lut[row][phi][band].
+constexpr int EXPAND_THREADS = 256;
+template <int NP>
+__global__ __launch_bounds__(EXPAND_THREADS) void expand_grid_kernel(const double *__restrict__ sun, int isza_base,
+                                                                      const double *__restrict__ coef, int nw,
+                                                                      int nvza, int nphi, long row_begin,
+                                                                      double *__restrict__ lut)
+{
+    const long row = row_begin + blockIdx.x;
+    const int isza = (int)(row / nvza) - isza_base;
+    const int tid = threadIdx.x;
+    const double *__restrict__ b = sun + (long)isza * 5 * nw;
+    double bC[NP], bB[NP], bZ[NP], bG[NP], bT[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int i = tid + p * EXPAND_THREADS;
+        const bool ok = i < nw;
+        bC[p] = ok ? b[0 * nw + i] : 0.0;
+        bB[p] = ok ? b[1 * nw + i] : 0.0;
+        bZ[p] = ok ? b[2 * nw + i] : 0.0;
+        bG[p] = ok ? b[3 * nw + i] : 0.0;
+        bT[p] = ok ? b[4 * nw + i] : 0.0;
+    }
+    const double *__restrict__ rec = coef + (long)blockIdx.x * nphi * GORT_COEF_STRIDE;
+    double *__restrict__ out = lut + (long)blockIdx.x * nphi * nw;
+    // launch_expand_grid picks NP = ceil(nw/256): passes 0..NP-2 are full, only the last is ragged
+    const bool last_ok = tid + (NP - 1) * EXPAND_THREADS < nw;
+    for (int l = 0; l < nphi; ++l, rec += GORT_COEF_STRIDE, out += nw) {
+        const double aC = rec[A_C], aB = rec[A_B], aZ = rec[A_Z], aG = rec[A_G], aT = rec[A_T];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = tid + p * EXPAND_THREADS;
+            const double v = aC * bC[p] + aB * bB[p] + aZ * bZ[p] + aG * bG[p] + aT * bT[p];
+            if (p < NP - 1 || last_ok) __builtin_nontemporal_store(v, out + i);
+        }
+    }
+}
+
+// ------------------------------------------------------------- albedo / energy
+
+// One 512-thread workgroup per angle line = the 32 x 16 Gauss-Legendre nodes of the
+// viewing hemisphere (gortt_albedo.c:89-134), one node per thread.  By linearity of
+// rsurf in the five angle coefficients the quadrature is applied to the coefficients
+// (wavefront shuffle + LDS reduction), then every band costs 5 FMAs:
+//   albedo(band) = sum_k [sum_nodes w_node a_k(node)] b_k(sun zenith, band).
+constexpr int ENERGY_THREADS = 512;
+
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopy,
+                                                                 const double *__restrict__ L, int nw,
+                                                                 const double *__restrict__ angles,
+                                                                 const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
+                                                                 double *__restrict__ energy)
+{
+    __shared__ double s_part[5][ENERGY_THREADS / 64];
+    __shared__ double s_abar[5];
+    __shared__ double s_sun[6];
+    const gort_canopy &c = *canopy;
+    const long a = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    double vza, sza, saa, raa;
+    normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
+    // node geometry (gortt_albedo.c:91-105): vaa = pi + pi x_i in (0, 2pi); vza = acos(x_j)
+    {
+#pragma clang fp contract(off)
+        const double vaa = nodes[3 * tid];
+        raa = saa - vaa;
+        raa = fabs((raa - 2 * PI * (int)(0.5 + raa * INV_PI * 0.5)));
+    }
+    vza = nodes[3 * tid + 1];
+    const double w = nodes[3 * tid + 2];
+    GeomOut g;
+    geometry_core(c, vza, sza, raa, g);
+    double rec[GORT_COEF_STRIDE];
+    store_coef(rec, c, g);
+    double part[5] = {w * rec[A_C], w * rec[A_B], w * rec[A_Z], w * rec[A_G], w * rec[A_T]};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        part[k] = wave_sum(part[k]);
+        if (lane == 0) s_part[k][wave] = part[k];
+    }
+    if (tid == 0) {
+        s_sun[0] = g.sun.fd;  s_sun[1] = g.sun.mu;  s_sun[2] = g.sun.t0;
+        s_sun[3] = g.sun.tp0; s_sun[4] = g.sun.eps; s_sun[5] = g.sun.pn0;
+    }
+    __syncthreads();
+    if (tid < 5) {
+        double t = 0.0;
+        for (int q = 0; q < ENERGY_THREADS / 64; ++q) t += s_part[tid][q];
+        s_abar[tid] = t;
+    }
+    __syncthreads();
+    SunScalars s;
+    s.fd = s_sun[0];  s.mu = s_sun[1];  s.t0 = s_sun[2];  s.tp0 = s_sun[3];  s.eps = s_sun[4];  s.pn0 = s_sun[5];
+    const double aC = s_abar[0], aB = s_abar[1], aZ = s_abar[2], aG = s_abar[3], aT = s_abar[4];
+    for (int i = tid; i < nw; i += ENERGY_THREADS) {
+        const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
+        const double albedo = aC * b.C0 + aB * b.B + aZ * b.Z + aG * b.G + aT * b.T;
+        const double rs = L[L_RS * nw + i];
+        // energy balance, Lambertian background (gortt_albedo.c:39-52)
+        const double Fu2 = b.G * s.pn0 + b.Z * (1. - s.pn0);
+        const double Fd2 = s.pn0 + b.Z * (1. - s.pn0) / rs;
+        double *o = energy + (a * nw + i) * 3;
+        o[0] = albedo;
+        o[1] = 1. - albedo - Fd2 + Fu2;
+        o[2] = Fd2 - Fu2;
+    }
+}
+
+inline int check_launch(const char *what)
+{
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(GORT_ENODEVICE, "%s: %s", what, hipGetErrorString(err));
+    return GORT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------- launchers
+
+int launch_lambda_table(const gort_canopy *canopy_dev, int nw, const double *rsoil_dev, const double *rleaf_dev,
+                        const double *tleaf_dev, double *L_dev, void *stream)
+{
+    if (nw <= 0) return GORT_OK;
+    hipLaunchKernelGGL(lambda_table_kernel, dim3((nw + 255) / 256), dim3(256), 0, (hipStream_t)stream, canopy_dev, nw,
+                       rsoil_dev, rleaf_dev, tleaf_dev, L_dev);
+    return check_launch("lambda_table_kernel");
+}
+
+int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA, double *coef_dev,
+                           double *K_dev, void *stream)
+{
+    if (nA <= 0) return GORT_OK;
+    hipLaunchKernelGGL(geometry_stream_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       canopy_dev, angles_dev, nA, coef_dev, K_dev);
+    return check_launch("geometry_stream_kernel");
+}
+
+int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
+                         double *coef_dev, void *stream)
+{
+    const long n = (row_end - row_begin) * g.nphi;
+    if (n <= 0) return GORT_OK;
+    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       canopy_dev, g, row_begin, n, coef_dev);
+    return check_launch("geometry_grid_kernel");
+}
+
+int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
+                         double *rsurf_dev, double *scomp_dev, void *stream)
+{
+    const long n = nA * nw;
+    if (n <= 0) return GORT_OK;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (scomp_dev)
+        hipLaunchKernelGGL(expand_stream_kernel<true>, grid, block, 0, (hipStream_t)stream, canopy_dev, L_dev, nw,
+                           coef_dev, n, rsurf_dev, scomp_dev);
+    else
+        hipLaunchKernelGGL(expand_stream_kernel<false>, grid, block, 0, (hipStream_t)stream, canopy_dev, L_dev, nw,
+                           coef_dev, n, rsurf_dev, scomp_dev);
+    return check_launch("expand_stream_kernel");
+}
+
+int launch_sun_table(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g, int isza_begin,
+                     int isza_end, double *sun_dev, void *stream)
+{
+    const int n = isza_end - isza_begin;
+    if (n <= 0 || nw <= 0) return GORT_OK;
+    hipLaunchKernelGGL(sun_table_kernel, dim3((nw + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, canopy_dev,
+                       L_dev, nw, g, isza_begin, n, sun_dev);
+    return check_launch("sun_table_kernel");
+}
+
+int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
+                       long row_begin, long row_end, double *lut_dev, void *stream)
+{
+    const long rows = row_end - row_begin;
+    if (rows <= 0) return GORT_OK;
+    const int np = (nw + EXPAND_THREADS - 1) / EXPAND_THREADS;
+    const dim3 grid((unsigned)rows), block(EXPAND_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+#define GORT_EXPAND_CASE(N)                                                                                         \
+    case N:                                                                                                         \
+        hipLaunchKernelGGL(expand_grid_kernel<N>, grid, block, 0, s, sun_dev, isza_base, coef_dev, nw, nvza, nphi,  \
+                           row_begin, lut_dev);                                                                     \
+        break;
+    switch (np) {
+        GORT_EXPAND_CASE(1)
+        GORT_EXPAND_CASE(2)
+        GORT_EXPAND_CASE(3)
+        GORT_EXPAND_CASE(4)
+        GORT_EXPAND_CASE(5)
+        GORT_EXPAND_CASE(6)
+        GORT_EXPAND_CASE(7)
+        GORT_EXPAND_CASE(8)
+        GORT_EXPAND_CASE(9)
+    default:
+        return fail(GORT_EINVAL, "expand_grid: nw=%d exceeds %d bands", nw, 9 * EXPAND_THREADS);
+    }
+#undef GORT_EXPAND_CASE
+    return check_launch("expand_grid_kernel");
+}
+
+int launch_energy(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev, long nA,
+                  const double *nodes_dev, double *energy_dev, void *stream)
+{
+    if (nA <= 0 || nw <= 0) return GORT_OK;
+    hipLaunchKernelGGL(energy_kernel, dim3((unsigned)nA), dim3(ENERGY_THREADS), 0, (hipStream_t)stream, canopy_dev,
+                       L_dev, nw, angles_dev, nodes_dev, energy_dev);
+    return check_launch("energy_kernel");
+}
+
+}  // namespace gort

@@ -1,0 +1,68 @@
+// gort_internal.h -- shared between the host translation units and the HIP kernels.
+#ifndef GORT_INTERNAL_H
+#define GORT_INTERNAL_H
+
+#include "gort_amd.h"
+
+namespace gort {
+
+int fail(int code, const char *fmt, ...);
+
+// ---- wavelength-only table L[k][nw] (SoA, k-major so that lanes read consecutive bands) ----
+enum LambdaSlot {
+    L_GAMMA = 0,   // sqrt(1-omega)                         gortt.c:470
+    L_OMEGA,       // rleaf+tleaf                           gortt.c:469
+    L_RFF,         // R_inf_ff                              gortt_brdf.c:574
+    L_TFF,         // T_inf_ff                              gortt_brdf.c:492
+    L_tFF,         // t_ff                                  gortt_brdf.c:401-403
+    L_PFF,         // p_ff (= CfC)                          gortt_brdf.c:510-512
+    L_RS,          // rsoil
+    L_MGK,         // rs/(1-rs*p_ff) * (t'_ff - k_open)     gortt.c:519-525
+    L_ZF,          // (t'_ff - k_openep) * rs               gortt.c:492
+    L_TF,          // t'_ff * MGK                           gortt.c:545-547
+    L_B,           // (1-omega)*omega*(1-g)                 gortt.c:504-506
+    L_NSLOT
+};
+
+// ---- per-angle record written by the geometry kernel (GORT_COEF_STRIDE doubles) ----
+// rsurf = aC*C0 + aB*B + aZ*Z + aG*G + aT*T   (exact regrouping of gortt.c:484-557)
+enum CoefSlot {
+    A_C = 0,       // Kc
+    A_B,           // Kc*fd*kuusk/(2 cos(sza') cos(vza'))
+    A_Z,           // Kc*fd*k_openep*K'z + Kz
+    A_G,           // Kc*fd*k_openep*K'g + Kg
+    A_T,           // Kt
+    S_FD,          // fd
+    S_MU,          // cos(sza')
+    S_T0,          // exp(-k*elai*sec(sza'))                gortt_brdf.c:534
+    S_TP0,         // Pn0(sza)+EPgap(sza)                   gortt_brdf.c:447
+    S_EPS,         // EPgap(sza)
+    S_PN0,         // Pn0(sza)                              (albedo, gortt_albedo.c:37)
+    C_FDA,         // fd*kuusk/(2 cos cos)     (component spectra only)
+    C_KPZ,         // fd*k_openep*K'z
+    C_KPG,         // fd*k_openep*K'g
+    C_PAD0,
+    C_PAD1
+};
+static_assert(C_PAD1 + 1 == GORT_COEF_STRIDE, "record size");
+
+// ---- launchers implemented in the .hip files; all asynchronous on `stream` ----
+// (void* stream is a hipStream_t)
+int launch_gap_probabilities(gort_canopy *members_dev, int n_members, void *stream);
+int launch_lambda_table(const gort_canopy *canopy_dev, int nw, const double *rsoil_dev,
+                        const double *rleaf_dev, const double *tleaf_dev, double *L_dev, void *stream);
+int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA,
+                           double *coef_dev, double *K_dev, void *stream);
+int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
+                         double *coef_dev, void *stream);
+int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
+                         long nA, double *rsurf_dev, double *scomp_dev, void *stream);
+int launch_sun_table(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g,
+                     int isza_begin, int isza_end, double *sun_dev, void *stream);
+int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
+                       long row_begin, long row_end, double *lut_dev, void *stream);
+int launch_energy(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev, long nA,
+                  const double *nodes_dev, double *energy_dev, void *stream);
+
+}  // namespace gort
+#endif

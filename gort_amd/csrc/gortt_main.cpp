@@ -1,0 +1,354 @@
+// gortt_main.cpp -- `gortt [options] < angles.dat > output.dat`, the drop-in executable.
+//
+// Keeps the command line, stdin/stdout formats, -W/-P probability LUT files, messages
+// and exit codes of the reference's main() / gortt_cl_parser (gortt.c:9-382,1003-1136);
+// all numerics run on the GPU through libgort_amd.so (include/gort_amd.h).  Angle lines
+// are batched to the device instead of being evaluated one by one.
+//
+// Deliberate deviations (DESIGN.md "CLI deviations"):
+//   * a value flag given as the last argument is an error (the reference reads argv[argc]
+//     and crashes);
+//   * the header line may be longer than 999 characters (the reference cannot take more
+//     than ~190 wavelengths per run);
+//   * -energy works for any number of wavelengths (the reference overflows its heap
+//     beyond 32);
+//   * -soil_spectra, which in the reference only dumps a table and exits with failure,
+//     is rejected with a message.
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <strings.h>
+#include <vector>
+
+#include "gort_amd.h"
+
+namespace {
+
+const char *g_prog = "gortt";
+
+[[noreturn]] void die(const char *fmt, const char *a = nullptr, const char *b = nullptr)
+{
+    std::fflush(stdout);
+    std::fprintf(stderr, fmt, a, b);
+    std::exit(EXIT_FAILURE);
+}
+
+void usage(const char *bin)
+{
+    // text of gortt_usage (gortt.c:1140-1234), printed on stderr
+    std::fprintf(stderr, "usage: %s [options] < angles.dat\n\n", bin);
+    std::fputs(
+        "The first line of the input data reads:\nN M W_1 W_2 [...] W_M\n"
+        "where N is the number of view--illumination geometries\nM is the number of wavelengths and\n"
+        "W_i (i=1,M) are the wavelengths at which to predict the canopy reflectance\n"
+        "The rest of the input data is four columns of ascii:\nview_zenith view_azimuth solar_zenith solar azimuth\n\n"
+        "The command line options are:\n"
+        "\n============ Crown geometry options:\n"
+        "-beta arg\tforce the proportion of mutual shadowing to arg\n"
+        "         \t[n.b. if beta is not set gortt uses the model by Li and Strahler (IGARSS'92) to determine mutual shadowing]\n"
+        "\n------------ EITHER (old style):\n"
+        "-h1 arg    \tset the lower boundary of the crown centres (m) to arg\n"
+        "-h2 arg    \tset the upper boundary of the crown centres (m) to arg\n"
+        "-b arg     \tset the vertical crown radius (m) to arg\n"
+        "-r arg     \tset the horizontal crown radius (m) to arg\n"
+        "-lambda arg\tset the tree stem density (1/m2) to arg\n"
+        "\n------------ OR (new style):\n"
+        "-HB  arg\tset the ratio of the centroid height range to the vertical crown radius to arg\n"
+        "-BR  arg\tset the ratio of the vertical to horizontal crown radius to arg\n"
+        "-PCC arg\tset the projected crown cover (at nadir) to arg\n"
+        "\nThe above old style options refer to the original GORT paper and the \n"
+        "new style options are as they are expressed in the Quaife et al. (2008) \n"
+        "DALEC paper. As soon as a new style option is specified all old style \n"
+        "options are ignored. Note that they are same thing - the code simply uses\n"
+        "the new style options to calculate the old ones but the new ones are \n"
+        "preferred because it reduces equifinality. \n"
+        "\n============ Amount of leaf material:\n"
+        "------------ EITHER:\n"
+        "-favd arg\tset the foliage volume area density (1/m2) within crown to arg\n"
+        "\n------------ OR:\n"
+        "-LAI  arg\tset the leaf area index (m2/m2) for the scene to arg\n"
+        "\n============ Prospect leaf options:\n"
+        "-N arg  \tset the leaf structure variable to arg\n"
+        "-Cab arg\tset the leaf chlorophyl content (\xc2\xb5g.cm-2) to arg\n"
+        "-Cw arg \tset the equivelant leaf water thickness (cm) to arg\n"
+        "-Car arg \tset the carotenoid content (\xc2\xb5g.cm-2) to arg\n"
+        "-Anth arg \tset the anthocyanin content (\xc2\xb5g.cm-2) to arg\n"
+        "-Cbrown arg \tset the /brown pigment content (arbitrary units) to arg\n"
+        "-Cm arg \tset the leaf mass per unit area (g.cm-2) to arg\n"
+        "\n============ Price soil spectra options:\n"
+        "-rsl1 arg \tset the weight of the first soil vector to arg\n"
+        "-rsl2 arg \tset the weight of the second soil vector to arg\n"
+        "-rsl3 arg \tset the weight of the third soil vector to arg\n"
+        "-rsl4 arg \tset the weight of the fourth soil vector to arg\n"
+        "\n============ User override for spectral properties:\n"
+        "-alb_leaf     arg \tset leaf albedo to arg (turns prospect off)**\n"
+        "-alb_soil     arg \tset soil albedo to arg (turns price off)**\n"
+        "-soil_spectra arg \tread soil spectra from file arg (turns price off)\n"
+        "                  \t[** n.b. use only one of the above soil options]\n"
+        "\n============ Read/write gap probabilities:\n"
+        "-W       \tgo as far as calculating the gap probabilities and write these to the stdout and exit\n"
+        "-P file  \tread gap probabilities from file that have been written using the -W option\n"
+        "         \tn.b. the above two options are included to allow fast BRF calculation based on\n"
+        "         \tpre-computed gap probabilities. The model must be run using the same crown and canopy\n"
+        "         \tgeometry options for the read and write. Spectral options (i.e. Prospect and Price options)\n"
+        "         \tmay be varied whist running using a give probability file.\n"
+        "\n============ Input/output options:\n"
+        "-prnspec\tprint the scene component spectra for each wavelength inside {}\n"
+        "-prnprop\tprint the viewed proportions of scene components inside []\n"
+        "-energy \tprint the spectral albedo, absoption by veg and absorption by soil for each wavelength after other outputs.\n"
+        "-u      \tprint this message and exit\n"
+        "\n",
+        stderr);
+}
+
+struct Options {
+    gort_canopy canopy;
+    gort_leaf_soil leaf;
+    bool prnspec = false, prnprop = false, energy = false, write_lut = false, read_lut = false;
+    std::string lut_file;
+};
+
+// Prefix rules and their ORDER are those of gortt_cl_parser (gortt.c:1022-1115).
+void parse_args(int argc, char **argv, Options &o)
+{
+    bool use_true_p = false, use_lai = false;
+    float hb = 2.0f, br = 1.0f, pcc = 0.5f, lai = 2.0f;
+    auto ci = [](const char *a, const char *flag, size_t n) { return !strncasecmp(a, flag, n); };
+    auto cs = [](const char *a, const char *flag, size_t n) { return !strncmp(a, flag, n); };
+    for (int i = 1; i < argc; ++i) {
+        const char *a = argv[i];
+        if (*a != '-') {
+            // (sic) the reference reports argv[1], not the offending argument
+            std::fprintf(stderr, "%s: unknown argument on command line: %s\n", argv[0], argv[1]);
+            std::fprintf(stderr, "(use the option -u to see brief usage instructions)\n");
+            std::exit(EXIT_FAILURE);
+        }
+        auto val = [&]() -> const char * {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "%s: option %s needs a value\n", argv[0], a);
+                std::exit(EXIT_FAILURE);
+            }
+            return argv[++i];
+        };
+        if (ci(a, "-favd", 5)) o.canopy.favd = atof(val());
+        else if (ci(a, "-h1", 3)) o.canopy.h1 = atof(val());
+        else if (ci(a, "-h2", 3)) o.canopy.h2 = atof(val());
+        else if (ci(a, "-lambda", 7)) o.canopy.lambda = atof(val());
+        else if (cs(a, "-HB", 3)) { use_true_p = true; hb = (float)atof(val()); }
+        else if (cs(a, "-BR", 3)) { use_true_p = true; br = (float)atof(val()); }
+        else if (cs(a, "-PCC", 7)) { use_true_p = true; pcc = (float)atof(val()); }
+        else if (cs(a, "-LAI", 7)) { use_lai = true; lai = (float)atof(val()); }
+        else if (ci(a, "-beta", 5)) { o.canopy.use_user_beta = 1; o.canopy.beta = atof(val()); }
+        else if (ci(a, "-diffuse", 5)) { o.canopy.use_user_fd = 1; o.canopy.fd_user = 1.0 - atof(val()); }
+        else if (cs(a, "-alb_leaf", 9)) { o.leaf.use_alb_leaf = 1; o.leaf.alb_leaf = atof(val()); }
+        else if (cs(a, "-alb_soil", 9)) { o.leaf.use_alb_soil = 1; o.leaf.alb_soil = atof(val()); }
+        else if (cs(a, "-soil_spectra", 10)) {
+            std::fprintf(stderr, "%s: -soil_spectra is not supported (in the reference it only dumps the table and fails)\n", argv[0]);
+            std::exit(EXIT_FAILURE);
+        }
+        else if (cs(a, "-prnspec", 7)) o.prnspec = true;
+        else if (cs(a, "-prnprop", 7)) o.prnprop = true;
+        else if (cs(a, "-energy", 7)) o.energy = true;
+        else if (cs(a, "-q08_pn_kopen", 7)) o.canopy.use_q08 = 1;
+        else if (cs(a, "-lidar", 6)) { /* accepted; the reference's lidar routine is an empty stub */ }
+        else if (cs(a, "-P", 2)) { o.read_lut = true; o.lut_file = val(); }
+        else if (cs(a, "-W", 2)) o.write_lut = true;
+        else if (ci(a, "-N", 2)) o.leaf.N = atof(val());
+        else if (ci(a, "-cab", 4)) o.leaf.Cab = atof(val());
+        else if (ci(a, "-car", 4)) o.leaf.Car = atof(val());
+        else if (ci(a, "-canth", 3)) o.leaf.Anth = atof(val());
+        else if (ci(a, "-cbrown", 3)) o.leaf.Cbrown = atof(val());
+        else if (ci(a, "-cw", 3)) o.leaf.Cw = atof(val());
+        else if (ci(a, "-cm", 3)) o.leaf.Cm = atof(val());
+        else if (ci(a, "-rsl1", 5)) o.leaf.rsl[0] = atof(val());
+        else if (ci(a, "-rsl2", 5)) o.leaf.rsl[1] = atof(val());
+        else if (ci(a, "-rsl3", 5)) o.leaf.rsl[2] = atof(val());
+        else if (ci(a, "-rsl4", 5)) o.leaf.rsl[3] = atof(val());
+        else if (ci(a, "-b", 2)) o.canopy.b = atof(val());
+        else if (ci(a, "-r", 2)) o.canopy.r = atof(val());
+        else if (ci(a, "-u", 2)) { usage(argv[0]); std::exit(EXIT_SUCCESS); }
+        else {
+            std::fprintf(stderr, "%s: unknown option on command line: %s\n", argv[0], a);
+            std::fprintf(stderr, "(use the option -u to see brief usage instructions)\n");
+            std::exit(EXIT_FAILURE);
+        }
+    }
+    if (use_true_p) gort_canopy_newstyle(&o.canopy, hb, br, pcc);
+    if (use_lai) gort_canopy_set_lai(&o.canopy, lai);
+}
+
+bool read_line(FILE *fp, std::string &line)
+{
+    line.clear();
+    int ch;
+    bool any = false;
+    while ((ch = std::fgetc(fp)) != EOF) {
+        any = true;
+        line.push_back((char)ch);
+        if (ch == '\n') break;
+    }
+    return any;
+}
+
+// whitespace-separated tokens, as get_first_string_token hands them out (gortt.c:1237-1283)
+std::vector<std::string> tokens(const std::string &line)
+{
+    std::vector<std::string> t;
+    size_t i = 0;
+    while (i < line.size()) {
+        while (i < line.size() && std::isspace((unsigned char)line[i])) ++i;
+        size_t j = i;
+        while (j < line.size() && !std::isspace((unsigned char)line[j])) ++j;
+        if (j > i) t.emplace_back(line, i, j - i);
+        i = j;
+    }
+    return t;
+}
+
+struct Out {
+    std::string buf;
+    void num(double v)
+    {
+        char tmp[400];
+        int n = std::isnan(v) ? std::snprintf(tmp, sizeof tmp, "-nan ")    // x86 default NaN prints as -nan
+                              : std::snprintf(tmp, sizeof tmp, "%f ", v);
+        buf.append(tmp, (size_t)n);
+    }
+    void raw(double v)
+    {
+        char tmp[400];
+        int n = std::snprintf(tmp, sizeof tmp, "%f ", v);
+        buf.append(tmp, (size_t)n);
+    }
+    void flush()
+    {
+        std::fwrite(buf.data(), 1, buf.size(), stdout);
+        buf.clear();
+    }
+};
+
+void check(int rc)
+{
+    if (rc != GORT_OK) die("%s: %s\n", g_prog, gort_last_error());
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    g_prog = argv[0];
+    Options o;
+    gort_canopy_defaults(&o.canopy);
+    gort_leaf_soil_defaults(&o.leaf);
+    parse_args(argc, argv, o);
+    check(gort_canopy_init(&o.canopy));
+
+    // 1) gap probabilities on the device unless they come from a file (gortt.c:116-120)
+    if (!o.read_lut) check(gort_gap_probabilities(&o.canopy, 1));
+    // 2) -W: write them and stop, before stdin is touched (gortt.c:123-128)
+    if (o.write_lut) {
+        std::vector<char> text(1 << 15);
+        long n = gort_lut_format(&o.canopy, text.data(), text.size());
+        if (n < 0) check((int)n);
+        std::fwrite(text.data(), 1, (size_t)n, stdout);
+        return EXIT_SUCCESS;
+    }
+    // 3) -P file (gortt.c:131-146)
+    if (o.read_lut && gort_lut_read(o.lut_file.c_str(), &o.canopy) != GORT_OK)
+        die("%s: error opening probability file: %s\n", argv[0], o.lut_file.c_str());
+
+    // header: N M W_1 .. W_M (gortt.c:153-184)
+    std::string header;
+    if (!read_line(stdin, header)) die("%s: error reading data on stdin\n", argv[0]);
+    std::vector<std::string> tk = tokens(header);
+    if (tk.empty()) die("%s: error reading number of angles from line 1\n", argv[0]);
+    const int na_check = atoi(tk[0].c_str());
+    if (tk.size() < 2) die("%s: error reading number of wavebands from line 1\n", argv[0]);
+    const int nw_check = atoi(tk[1].c_str());
+    std::vector<double> wl;
+    for (size_t i = 2; i < tk.size(); ++i) wl.push_back(atof(tk[i].c_str()));
+    const int nw = (int)wl.size();
+    if (nw_check != nw) {
+        std::fprintf(stderr, "%s: expected number of wavelengths (%d) does not match with number found (%d)\n",
+                     argv[0], nw_check, nw);
+        return EXIT_FAILURE;
+    }
+
+    std::vector<double> rsoil(nw), rleaf(nw), tleaf(nw);
+    if (gort_spectra(&o.leaf, wl.data(), nw, rsoil.data(), rleaf.data(), tleaf.data()) != GORT_OK)
+        die("%s\n", gort_last_error());
+
+    gort_engine *eng = nullptr;
+    check(gort_engine_create(&eng));
+    check(gort_engine_set_canopy(eng, &o.canopy));
+    if (nw > 0) check(gort_engine_set_spectra(eng, nw, rsoil.data(), rleaf.data(), tleaf.data()));
+
+    std::fputs(header.c_str(), stdout);
+
+    // angle lines, batched to the device (gortt.c:232-329)
+    const long CHUNK = 1L << 16;
+    long na = 0;
+    bool bad_line = false, eof = false;
+    std::vector<double> ang, rsurf, scomp, K, energy;
+    std::string line;
+    Out out;
+    while (!eof && !bad_line) {
+        ang.clear();
+        while ((long)(ang.size() / 4) < CHUNK) {
+            if (!read_line(stdin, line)) { eof = true; break; }
+            double v[4];
+            if (std::sscanf(line.c_str(), "%lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3]) != 4) { bad_line = true; break; }
+            ang.insert(ang.end(), v, v + 4);
+        }
+        const long n = (long)(ang.size() / 4);
+        if (n > 0) {
+            rsurf.resize((size_t)n * nw);
+            if (o.prnspec) scomp.resize((size_t)n * nw * 4);
+            K.resize((size_t)n * 4);
+            if (nw > 0)
+                check(gort_rsurf_stream(eng, ang.data(), n, rsurf.data(), o.prnspec ? scomp.data() : nullptr, K.data()));
+            if (o.energy && nw > 0) {
+                energy.resize((size_t)n * nw * 3);
+                check(gort_energy_stream(eng, ang.data(), n, energy.data()));
+            }
+            for (long a = 0; a < n; ++a) {
+                for (int q = 0; q < 4; ++q) out.raw(ang[4 * a + q]);
+                for (int i = 0; i < nw; ++i) {
+                    out.num(rsurf[(size_t)a * nw + i]);
+                    if (o.prnspec) {
+                        out.buf += "{ ";
+                        for (int q = 0; q < 4; ++q) out.num(scomp[((size_t)a * nw + i) * 4 + q]);
+                        out.buf += "} ";
+                    }
+                }
+                if (o.prnprop) {
+                    out.buf += "[ ";
+                    for (int q = 0; q < 4; ++q) out.num(nw > 0 ? K[4 * a + q] : 0.0);
+                    out.buf += "] ";
+                }
+                if (o.energy)
+                    for (int i = 0; i < 3 * nw; ++i) out.num(energy[(size_t)a * nw * 3 + i]);
+                out.buf += "\n";
+                if (out.buf.size() > (1u << 20)) out.flush();
+            }
+            out.flush();
+            na += n;
+        }
+    }
+    gort_engine_destroy(eng);
+    if (bad_line) {
+        std::fflush(stdout);
+        std::fprintf(stderr, "%s: error on input, line %ld\n", argv[0], na + 1);
+        return EXIT_FAILURE;
+    }
+    if (na_check != na) {
+        std::fflush(stdout);
+        std::fprintf(stderr, "%s: expected number of angles (%d) does not match with number found (%ld)\n", argv[0],
+                     na_check, na);
+        return EXIT_FAILURE;
+    }
+    return EXIT_SUCCESS;
+}

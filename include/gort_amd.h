@@ -1,0 +1,173 @@
+/*
+ * gort_amd.h -- C ABI of libgort_amd.so: MI355X-native GORT BRDF/albedo engine.
+ *
+ * Drop-in boundary for the hot path of tquaife/gort's `gortt` (Ni et al. 1999 GORT
+ * model).  The reference has no library API - its seam is the set of void functions
+ * that main() calls on caller-owned structs (reference include/gortt.h:217-219,
+ * 251-252).  Each entry point below names the reference interface it replaces
+ * (file:line under the reference tree).  Plain pointers and sizes only; no C++ or
+ * torch types.  All floating point data is IEEE double unless stated.
+ *
+ * Conventions
+ *   - functions return 0 on success, a negative GORT_E* code otherwise;
+ *     gort_last_error() gives the message (thread-local).
+ *   - `*_dev` arguments are DEVICE pointers (HIP, current device); everything else
+ *     is host memory.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - angle tuples are the four columns of a gortt stdin line, in DEGREES:
+ *     view zenith, view azimuth, sun zenith, sun azimuth (gortt.c:234).
+ *   - there is NO CPU fallback: device entry points fail with GORT_ENODEVICE when
+ *     no HIP device is usable.
+ */
+#ifndef GORT_AMD_H
+#define GORT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GORT_NLAYERS   15      /* gortt.c:78  */
+#define GORT_NTH       91      /* gortt.c:714 */
+#define GORT_MAXCROWNS 30      /* gortt.c:89  */
+#define GORT_NH_ES     20      /* gortt.c:90  */
+#define GORT_NPOINTS   32      /* gortt.c:93  */
+#define GORT_NBANDS    2101    /* gortt.h:31  */
+#define GORT_COEF_STRIDE 16    /* doubles per angle record, see gort_geometry_dev */
+
+enum {
+    GORT_OK = 0,
+    GORT_EINVAL = -1,      /* bad argument */
+    GORT_ERANGE = -2,      /* wavelength outside 400..2500 nm (gortt.c:1299-1302,1350-1353) */
+    GORT_ENODEVICE = -3,   /* no usable HIP device / HIP error */
+    GORT_EIO = -4,         /* LUT file cannot be opened (gortt.c:132-135) */
+    GORT_ENOMEM = -5
+};
+
+/* ---- canopy: the members of the reference's gortt_parameters (gortt.h:123-212) that
+ * the live path reads.  One POD record; the same bytes are used on host and device. ---- */
+typedef struct gort_canopy {
+    /* inputs: flag values (gortt.c:1026-1131) */
+    double r, b, h1, h2, lambda, favd;
+    double beta;      int32_t use_user_beta;  int32_t use_user_fd;   /* -beta / -diffuse */
+    double fd_user;                                                  /* 1 - (-diffuse arg) */
+    int32_t use_q08;  int32_t reserved0;                             /* -q08_pn_kopen */
+    /* derived by gort_canopy_init (replaces gortt_init_params, gortt.c:632-868) */
+    double ell, rr, rrr, h, k, elai, tau, z1, z2, lv;
+    double favd_p, tau_p, lv_p, z1_p, z2_p, h1_p, h2_p;
+    double dz, ds, dz_p, dth;
+    double height_p[GORT_NLAYERS];
+    double theta[GORT_NTH], theta_p[GORT_NTH];
+    /* gap-probability products: exactly what `gortt -W` writes (gortt.c:123-128) */
+    double p_n0[GORT_NTH];        /* p_n0[0][t]                                   */
+    double epgap[GORT_NTH];       /* epgap[0][t]; [90] is 0 in the reference      */
+    double k_open, k_openep;      /* k_open[0], k_openep[0]                       */
+} gort_canopy;
+
+/* ---- leaf/soil parameters (gortt_spectra, gortt.h:96-114; defaults gortt.c:38-59) ---- */
+typedef struct gort_leaf_soil {
+    double N, Cab, Car, Anth, Cbrown, Cw, Cm;      /* PROSPECT-D */
+    double rsl[4];                                 /* Price soil EOF weights */
+    int32_t use_alb_leaf, use_alb_soil;            /* -alb_leaf / -alb_soil */
+    double alb_leaf, alb_soil;
+} gort_leaf_soil;
+
+const char *gort_last_error(void);
+const char *gort_version(void);
+
+/* ===================== host-side precompute (no GPU needed) ===================== */
+
+/* defaults of main(): gortt.c:67-72 (canopy), gortt.c:38-59 (leaf/soil) */
+void gort_canopy_defaults(gort_canopy *c);
+void gort_leaf_soil_defaults(gort_leaf_soil *s);
+/* -HB/-BR/-PCC "new style" crown geometry, values as C floats: gortt.c:1014,1117-1125 */
+void gort_canopy_newstyle(gort_canopy *c, float hb, float br, float pcc);
+/* -LAI (float), applied after new-style: gortt.c:1127-1131 */
+void gort_canopy_set_lai(gort_canopy *c, float lai);
+/* derived scalars + zenith/height tables: replaces gortt_init_params, gortt.c:632-868 */
+int  gort_canopy_init(gort_canopy *c);
+
+/* Price soil reflectance: replaces gortt_price_soil, gortt.c:1286-1328 */
+int  gort_price_soil(const double *wl_nm, int nw, const double rsl[4], double *rsoil);
+/* PROSPECT-D on the native 400..2500 @1 nm grid: replaces prospect_DB_,
+ * PROSPECT-D/prospect_DB.f90:72-191 (+ tav_abs.f90).  RT[0..2100]=R, RT[2101..4201]=T */
+int  gort_prospect_d(double N, double Cab, double Car, double Anth, double Cbrown,
+                     double Cw, double Cm, double *RT);
+/* all three spectra at arbitrary wavelengths incl. the -alb_* overrides: replaces
+ * gortt_price_soil + gortt_prospect_interface, gortt.c:224-227,1331-1374 */
+int  gort_spectra(const gort_leaf_soil *s, const double *wl_nm, int nw,
+                  double *rsoil, double *rleaf, double *tleaf);
+/* Gauss-Legendre nodes as the reference computes them: replaces gauleg, gortt_albedo.c:141-199 */
+void gort_gauleg(double x1, double x2, double *x, double *w, int n);
+
+/* probability LUT, text format of `gortt -W` / `gortt -P file`: gortt.c:123-146.
+ * gort_lut_format writes into buf (needs <= 16 KiB), returns bytes written or <0. */
+long gort_lut_format(const gort_canopy *c, char *buf, size_t cap);
+int  gort_lut_read(const char *path, gort_canopy *c);
+
+/* ============================== device entry points ============================== */
+
+int  gort_device_count(void);
+
+/* Pn/EPgap/KOpen for a batch of canopies (one workgroup per member).  Fills
+ * p_n0/epgap/k_open/k_openep of every record in place; honours use_q08.
+ * Replaces gortt_gap_probabilities (gortt_pn_kopen.c:7-129) and
+ * gortt_gap_probabilities_Q08 (gortt_pn_kopen.c:1144-1200).
+ * Each canopy must have been through gort_canopy_init. */
+int  gort_gap_probabilities(gort_canopy *members, int n_members);
+int  gort_gap_probabilities_dev(gort_canopy *members_dev, int n_members, void *stream);
+
+/* Opaque engine: owns a HIP stream, the device copy of one canopy, the spectra and
+ * the wavelength-only tables derived from them. */
+typedef struct gort_engine gort_engine;
+int  gort_engine_create(gort_engine **out);
+void gort_engine_destroy(gort_engine *e);
+void *gort_engine_stream(gort_engine *e);           /* hipStream_t */
+int  gort_engine_synchronize(gort_engine *e);
+/* canopy must carry gap tables (gort_gap_probabilities or gort_lut_read) */
+int  gort_engine_set_canopy(gort_engine *e, const gort_canopy *c);
+int  gort_engine_set_spectra(gort_engine *e, int nw, const double *rsoil,
+                             const double *rleaf, const double *tleaf);
+int  gort_engine_nw(const gort_engine *e);
+
+/* BRDF for a stream of angle lines.  Replaces, per line, the angle normalisation of
+ * main() (gortt.c:240-291), gortt_set_zenith_dependant_probabilities (gortt.c:872-915)
+ * and gortt_rsurf (gortt.c:385-578).
+ *   angles[nA][4]   degrees
+ *   rsurf[nA][nw]
+ *   scomp[nA][nw][4]  C,G,T,Z (-prnspec), may be NULL
+ *   K[nA][4]          Kc,Kg,Kt,Kz (-prnprop), may be NULL */
+int  gort_rsurf_stream(gort_engine *e, const double *angles, long nA,
+                       double *rsurf, double *scomp, double *K);
+int  gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA,
+                           double *rsurf_dev, double *scomp_dev, double *K_dev);
+
+/* Regular-grid LUT: every (sun zenith, view zenith, relative azimuth) node in integer
+ * steps, equivalent to streaming the lines "vza phi sza 0" (SURVEY.md 8d, C3):
+ *   sza = sza0 + i*dsza (i<nsza), vza = vza0 + j*dvza (j<nvza), phi = phi0 + l*dphi (l<nphi)
+ *   lut_dev[nsza][nvza][nphi][nw], wavelength fastest.
+ * [row_begin,row_end) selects (i,j) rows in flattened order i*nvza+j, so that ranks of a
+ * multi-GPU job fill disjoint slabs; lut_dev points at the first selected row. */
+typedef struct gort_grid {
+    double sza0, dsza; int32_t nsza;  int32_t pad0;
+    double vza0, dvza; int32_t nvza;  int32_t pad1;
+    double phi0, dphi; int32_t nphi;  int32_t pad2;
+} gort_grid;
+int  gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, long row_end,
+                         double *lut_dev);
+/* kernel-only timing hook for bench.py: average duration (ms) of the LUT expansion
+ * kernel over the launches since the last call, measured with HIP events on the
+ * engine's stream; returns <0 if none. */
+double gort_engine_last_expand_ms(gort_engine *e);
+
+/* Spectral albedo, vegetation and soil absorption per angle line.  Replaces
+ * gortt_energy/gortt_albedo (gortt_albedo.c:7-138): 32x16 Gauss-Legendre nodes over the
+ * viewing hemisphere.  energy[nA][nw][3] = albedo, favegt, fasoil (print order, gortt.c:323-324) */
+int  gort_energy_stream(gort_engine *e, const double *angles, long nA, double *energy);
+int  gort_energy_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *energy_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GORT_AMD_H */

@@ -1,0 +1,141 @@
+"""CPU-side checks of the product library: it loads, exports every symbol that
+include/gort_amd.h declares, and its HOST precompute (canopy derivation, Price soil,
+PROSPECT-D, Gauss-Legendre nodes, LUT text) agrees with the golden vectors dumped from
+the real reference.  No device entry point is called here.
+"""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, relerr
+from gort_amd import api
+
+TOL = 1e-13
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "gort_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gort_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(api.DECLARED_SYMBOLS), declared ^ set(api.DECLARED_SYMBOLS)
+    L = api.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libgort_amd.so does not export %s" % name
+    assert b"gfx950" in L.gort_version()
+
+
+def test_struct_layout_matches_header():
+    # sizes implied by include/gort_amd.h (all members 8-byte aligned, int32 pairs packed)
+    assert C.sizeof(api.Canopy) == 8 * (6 + 1 + 1 + 1 + 1 + 21 + 15 + 91 * 4 + 2)
+    assert C.sizeof(api.LeafSoil) == 8 * (7 + 4 + 1 + 2)
+    assert C.sizeof(api.Grid) == 8 * 9
+
+
+FLAGS = json.load(open(os.path.join(GOLDEN, "canopies_flags.json")))
+
+
+def canopy_from_flags(flags):
+    kw, ns, i, q08 = {}, {}, 0, False
+    while i < len(flags):
+        f = flags[i]
+        if f == "-q08_pn_kopen":
+            q08 = True; i += 1; continue
+        v = float(flags[i + 1]); i += 2
+        key = {"-LAI": "lai", "-favd": "favd", "-h1": "h1", "-h2": "h2", "-lambda": "lam", "-r": "r", "-b": "b"}.get(f)
+        if key: kw[key] = v
+        else: ns[f] = v
+    if ns:
+        kw["newstyle"] = (ns.get("-HB", 2.0), ns.get("-BR", 1.0), ns.get("-PCC", 0.5))
+    return api.make_canopy(q08=q08, **kw)
+
+
+@pytest.mark.parametrize("tag", sorted(FLAGS))
+def test_canopy_init_matches_reference(tag, golden):
+    g = golden("canopies.npz")
+    c = canopy_from_flags(FLAGS[tag])
+    sc = g[tag + "/scalars"]
+    names = ["r", "b", "h1", "h2", "lambda_", "favd", "ell", "h", "elai", "tau", "z1", "z2", "lv", "favd_p",
+             "tau_p", "lv_p", "z1_p", "z2_p", "h1_p", "h2_p", "dz", "ds", "dz_p", "dth"]
+    for i, n in enumerate(names):
+        assert getattr(c, n) == sc[i], (n, getattr(c, n), sc[i])
+    assert c.k == sc[26] and c.rr == sc[27] and c.rrr == sc[28]
+    assert relerr(np.array(c.theta), g[tag + "/theta"]) == 0
+    assert relerr(np.array(c.theta_p), g[tag + "/theta_p"]) == 0
+    assert relerr(np.array(c.height_p), g[tag + "/height_p"]) == 0
+
+
+@pytest.mark.parametrize("tag", ["default", "dry", "dense", "zero_abs", "opaque"])
+def test_prospect_d(tag, golden):
+    s = golden("spectra.npz")
+    RT = api.prospect_d(*s["prospect/%s/params" % tag])
+    assert relerr(RT, s["prospect/%s/RT" % tag]) <= TOL
+
+
+def test_spectra(golden):
+    s = golden("spectra.npz")
+    rs, rl, tl = api.spectra(s["interp/default/wl"])
+    assert relerr(rs, s["interp/default/rsoil"]) <= TOL
+    assert relerr(rl, s["interp/default/rleaf"]) <= TOL
+    assert relerr(tl, s["interp/default/tleaf"]) <= TOL
+    pr = s["interp/alt/prospect"]
+    ls = api.leaf_soil(prospect=dict(N=pr[0], Cab=pr[1], Car=pr[2], Anth=pr[3], Cbrown=pr[4], Cw=pr[5], Cm=pr[6]),
+                       rsl=s["interp/alt/rsl"])
+    rs, rl, tl = api.spectra(s["interp/alt/wl"], ls)
+    assert relerr(rs, s["interp/alt/rsoil"]) <= TOL
+    assert relerr(rl, s["interp/alt/rleaf"]) <= TOL
+    assert relerr(tl, s["interp/alt/tleaf"]) <= TOL
+    rs, rl, tl = api.spectra([500.0, 900.0], api.leaf_soil(alb_leaf=0.9, alb_soil=0.2))
+    assert (rs == 0.2).all() and (rl == 0.45).all() and (tl == 0.45).all()
+
+
+@pytest.mark.parametrize("bad", [[399.0], [2500.5], [500.0, 2600.0]])
+def test_wavelength_range_error(bad):
+    with pytest.raises(api.GortError) as e:
+        api.spectra(bad)
+    assert e.value.code == api.ERANGE
+    # message text of the reference (gortt.c:1299-1302), printed verbatim by the CLI
+    assert "wavlength out of range (400-2500)" in str(e.value)
+
+
+def test_gauleg(golden):
+    s = golden("spectra.npz")
+    x, w = api.gauleg(32)
+    assert relerr(x, s["gauleg32/x"]) <= TOL and relerr(w, s["gauleg32/w"]) <= TOL
+
+
+def test_lut_text_roundtrip(golden, tmp_path):
+    """gort_lut_format writes the byte format of `gortt -W`; gort_lut_read parses a file the
+    REAL reference wrote."""
+    cases = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "cli_cases.json")))}
+    ref_text = cases["lut_default"]["stdout"]
+    c = api.make_canopy(lai=4.0)
+    api.lut_read_text = None
+    p = tmp_path / "lut.dat"
+    p.write_text(ref_text)
+    api.lut_read(str(p), c)
+    g = golden("canopies.npz")
+    # "%0.40f" keeps 40 decimals: an ABSOLUTE resolution of 1e-40 (values below it read back as 0)
+    assert np.abs(np.array(c.p_n0)[:90] - g["default_lai4/p_n0"][0][:90]).max() <= 1e-40
+    assert np.abs(np.array(c.epgap)[:90] - g["default_lai4/epgap0"][:90]).max() <= 1e-40
+    assert c.p_n0[90] == 0.0 and c.epgap[90] == 0.0          # index 90 is never in the file
+    assert relerr(np.array([c.k_open, c.k_openep]), g["default_lai4/kk"]) <= 1e-15
+    # re-emitting the parsed tables reproduces the reference's bytes
+    assert api.lut_text(c) == ref_text
+    with pytest.raises(api.GortError) as e:
+        api.lut_read("/nonexistent/lut.dat", c)
+    assert e.value.code == api.EIO
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.GortError) as e:
+        api.Engine()
+    assert e.value.code == api.ENODEVICE
+    with pytest.raises(api.GortError):
+        api.gap_probabilities(api.make_canopy(lai=4.0))
