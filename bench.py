@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
+    ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-gb", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (GB)")
@@ -117,7 +118,7 @@ def main():
             dist.barrier()
 
     # ---- untimed setup: canopy, gap probabilities (GPU), spectra, engine ----
-    wl = np.arange(400.0, 2501.0, 1.0)
+    wl = np.arange(400.0, 2501.0, 1.0) if args.nw == 2101 else np.linspace(400.0, 2500.0, args.nw)
     nw = wl.size
     canopy = api.gap_probabilities(api.make_canopy(lai=4.0))
     rs, rl, tl = api.spectra(wl)
@@ -183,6 +184,15 @@ def main():
         value = total_samples * args.steps / dt
         per_launch_bytes = my_samples * BYTES_PER_SAMPLE
         achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else None
+        # HBM bytes per launch of the dominant kernel from the PMC counters: a live bench run cannot collect
+        # them (rocprofv3 --pmc needs its own passes), so the number of the last committed PMC run is quoted
+        # when it was taken on this very workload; otherwise null.
+        traffic, traffic_src = (args.traffic_gb * 1e9, "--traffic-gb") if args.traffic_gb else (None, None)
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if traffic is None and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            if pmc.get("workload") == "%dx%dx%dx%d" % (grid.nsza, grid.nvza, grid.nphi, nw) and pmc.get("n_gpus") == world:
+                traffic, traffic_src = pmc["traffic_bytes"], "profiles/pmc_latest.json: " + pmc["note"]
         out = {
             "metric": "BRDF samples/sec ((theta_v,theta_s,dphi,lambda) tuples)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,10 +202,10 @@ def main():
                                    % (grid.nsza, grid.nvza, grid.nphi, nw),
                        "samples_per_step": total_samples, "output_gb_per_step": total_samples * 8 / 1e9,
                        "sharding": "rows of (sun zenith, view zenith) split in %d contiguous slabs" % world},
-            "roofline": {"bound": "hbm", "kernel": "expand_grid_kernel<9>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "expand_flat_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "traffic": (args.traffic_gb * 1e9) if args.traffic_gb else None},
+                         "traffic": traffic, "traffic_source": traffic_src},
             "parity": parity,
         }
         if world == 1 and not args.no_cpu_baseline:

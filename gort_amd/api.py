@@ -61,7 +61,8 @@ DECLARED_SYMBOLS = [
     "gort_last_error", "gort_version", "gort_canopy_defaults", "gort_leaf_soil_defaults",
     "gort_canopy_newstyle", "gort_canopy_set_lai", "gort_canopy_init", "gort_price_soil",
     "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_lut_format", "gort_lut_read",
-    "gort_device_count", "gort_gap_probabilities", "gort_gap_probabilities_dev",
+    "gort_device_count", "gort_dev_malloc", "gort_dev_free", "gort_memcpy_h2d", "gort_memcpy_d2h",
+    "gort_gap_probabilities", "gort_gap_probabilities_dev",
     "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
@@ -77,12 +78,24 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s missing: run `python -m gort_amd.build` (hipcc, gfx950)" % LIB_PATH)
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64.  If torch is going
+        # to be used for device buffers it must be loaded first so that libgort_amd.so binds to the
+        # same runtime (two runtimes in one process leave the second without devices).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.gort_last_error.restype = C.c_char_p
         L.gort_version.restype = C.c_char_p
         L.gort_lut_format.restype = C.c_long
         L.gort_engine_stream.restype = C.c_void_p
         L.gort_engine_last_expand_ms.restype = D
+        L.gort_dev_malloc.restype = C.c_void_p
+        L.gort_dev_malloc.argtypes = [C.c_size_t]
+        L.gort_dev_free.argtypes = [C.c_void_p]
+        L.gort_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.gort_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gort_engine_create.argtypes = [C.POINTER(C.c_void_p)]
         for name in ("gort_engine_destroy", "gort_engine_synchronize", "gort_engine_stream", "gort_engine_nw",
                      "gort_engine_last_expand_ms"):
@@ -120,7 +133,37 @@ def _ptr(a):
         return None
     if hasattr(a, "data_ptr"):
         return C.c_void_p(a.data_ptr())
+    if isinstance(a, DeviceBuffer):
+        return C.c_void_p(a.ptr)
     return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceBuffer:
+    """Raw HBM allocation through the C ABI (gort_dev_malloc) for torch-free callers."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().gort_dev_malloc(self.nbytes)
+        if not self.ptr:
+            raise GortError(ENOMEM, lib().gort_last_error().decode())
+        self.shape = (self.nbytes // 8,)
+
+    def to_numpy(self, count=None, offset=0):
+        count = (self.nbytes // 8 - offset) if count is None else count
+        out = np.empty(count, dtype=np.float64)
+        _check(lib().gort_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + 8 * offset), 8 * count))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().gort_dev_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------ host side

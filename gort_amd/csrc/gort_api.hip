@@ -67,6 +67,33 @@ extern "C" int gort_device_count(void)
     return n;
 }
 
+extern "C" void *gort_dev_malloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        fail(GORT_ENOMEM, "gort_dev_malloc: cannot allocate %zu bytes", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void gort_dev_free(void *p_dev)
+{
+    if (p_dev) (void)hipFree(p_dev);
+}
+
+extern "C" int gort_memcpy_h2d(void *dst_dev, const void *src, size_t bytes)
+{
+    GORT_HIP(hipMemcpy(dst_dev, src, bytes, hipMemcpyHostToDevice));
+    return GORT_OK;
+}
+
+extern "C" int gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes)
+{
+    GORT_HIP(hipMemcpy(dst, src_dev, bytes, hipMemcpyDeviceToHost));
+    return GORT_OK;
+}
+
 // ------------------------------------------------------------ gap probabilities
 
 extern "C" int gort_gap_probabilities_dev(gort_canopy *members_dev, int n_members, void *stream)
@@ -239,13 +266,22 @@ extern "C" int gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_
     if (!lut_dev) return fail(GORT_EINVAL, "gort_rsurf_grid_dev: null output");
     const long rows = row_end - row_begin, nA = rows * g->nphi;
     const int nw = e->nw;
-    if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
     const gort_canopy *c = e->canopy.as<gort_canopy>();
-    if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), e->stream))) return rc;
-    if (nw < 128 || nw > 9 * 256) {
-        // few bands: one thread per sample straight from the angle records
+    const bool few_bands = nw < 128 || nw > 9 * 256;
+    if (few_bands) {
+        // few bands: one thread per sample straight from the full angle records
+        if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
+        if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
         return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, e->stream);
     }
+    // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel)
+    const long tail = expand_grid_tail_pad_records(nw, nA * (long)nw);
+    const size_t coef_bytes = sizeof(double) * 8 * (size_t)(nA + 1 + tail);
+    const bool fresh = coef_bytes > e->coef.cap;
+    if ((rc = e->coef.reserve(coef_bytes))) return rc;
+    if (fresh) GORT_HIP(hipMemsetAsync(e->coef.p, 0, coef_bytes, e->stream));      // pads hold finite values
+    double *coef8 = e->coef.as<double>() + 8;
+    if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, coef8, true, e->stream))) return rc;
     const int is0 = (int)(row_begin / g->nvza), is1 = (int)((row_end - 1) / g->nvza) + 1;
     if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(is1 - is0)))) return rc;
     if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, is0, is1, e->sun.as<double>(), e->stream))) return rc;
@@ -260,8 +296,8 @@ extern "C" int gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_
         }
         GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
-    rc = launch_expand_grid(e->sun.as<double>(), is0, e->coef.as<double>(), nw, g->nvza, g->nphi, row_begin, row_end,
-                            lut_dev, e->stream);
+    rc = launch_expand_grid(e->sun.as<double>(), is0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
+                            e->stream);
     if (timed) {
         GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;

@@ -17,6 +17,10 @@
 // No MFMA: K=5 is not a matrix-core shape and the kernel is store-bound anyway.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
 #include "gort_internal.h"
 
 namespace gort {
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 // grid nodes generated from indices; identical to streaming "vza phi sza 0" 
 __global__ __launch_bounds__(256) void geometry_grid_kernel(const gort_canopy *__restrict__ canopy, gort_grid g,
                                                              long row_begin, long n_angles,
-                                                             double *__restrict__ coef)
+                                                             double *__restrict__ coef, int compact)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_angles) return;
@@ -253,7 +257,18 @@ __global__ __launch_bounds__(256) void geometry_grid_kernel(const gort_canopy *_
     normalise_angles(g.vza0 + ivza * g.dvza, g.phi0 + l * g.dphi, g.sza0 + isza * g.dsza, 0.0, vza, sza, saa, raa);
     GeomOut o;
     geometry_core(*canopy, vza, sza, raa, o);
-    store_coef(coef + i * GORT_COEF_STRIDE, *canopy, o);
+    if (compact) {
+        // LUT path: only the five expansion coefficients, one 64-B record per node
+        double rec[GORT_COEF_STRIDE];
+        store_coef(rec, *canopy, o);
+        double2 *dst = reinterpret_cast<double2 *>(coef + i * 8);
+        dst[0] = make_double2(rec[A_C], rec[A_B]);
+        dst[1] = make_double2(rec[A_Z], rec[A_G]);
+        dst[2] = make_double2(rec[A_T], 0.0);
+        dst[3] = make_double2(0.0, 0.0);
+    } else {
+        store_coef(coef + i * GORT_COEF_STRIDE, *canopy, o);
+    }
 }
 
 // ------------------------------------------------------- wavelength-only table
@@ -391,26 +406,36 @@ __global__ __launch_bounds__(256) void sun_table_kernel(const gort_canopy *__res
     o[4 * nw + i] = b.T;
 }
 
-// The hot kernel.  One workgroup per (sun zenith, view zenith) row of the LUT; thread
-// `tid` owns bands tid, tid+256, ... (NP passes) and keeps their five sun terms in
-// registers for the whole row; the loop over the relative-azimuth nodes reads the five
-// angle coefficients (workgroup-uniform -> scalar loads) and streams 8 B per lane,
-// 512 contiguous bytes per wave-instruction, to lut[row][phi][band].
-constexpr int EXPAND_THREADS = 256;
-template <int NP>
-__global__ __launch_bounds__(EXPAND_THREADS) void expand_grid_kernel(const double *__restrict__ sun, int isza_base,
-                                                                      const double *__restrict__ coef, int nw,
-                                                                      int nvza, int nphi, long row_begin,
-                                                                      double *__restrict__ lut)
+// The hot kernel.  One workgroup per (sun zenith, view zenith) row of the LUT.
+//   * the row's angle coefficients (nphi x 8 doubles, written compactly by
+//     geometry_grid_kernel) are staged once into LDS with 16-B coalesced loads, so the
+//     azimuth loop never waits on HBM latency;
+//   * thread `tid` owns bands tid, tid+THREADS, ... (NP passes) and keeps their five sun
+//     terms in registers for the whole row;
+//   * per azimuth node: 5 workgroup-uniform LDS reads (broadcast), 5 FMAs per band, and
+//     8 B per lane / 512 contiguous bytes per wave-instruction streamed to
+//     lut[row][phi][band] (optionally non-temporal).
+constexpr int GRID_COEF_STRIDE = 8;     // compact record: A_C..A_T + 3 pad = 64 B
+template <int THREADS, int NP, bool NT>
+__global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__restrict__ sun, int isza_base,
+                                                               const double *__restrict__ coef, int nw, int nvza,
+                                                               int nphi, long row_begin, double *__restrict__ lut)
 {
+    extern __shared__ double s_coef[];      // [nphi][GRID_COEF_STRIDE]
     const long row = row_begin + blockIdx.x;
     const int isza = (int)(row / nvza) - isza_base;
     const int tid = threadIdx.x;
+    {
+        const double2 *__restrict__ src =
+            reinterpret_cast<const double2 *>(coef + (long)blockIdx.x * nphi * GRID_COEF_STRIDE);
+        double2 *dst = reinterpret_cast<double2 *>(s_coef);
+        for (int q = tid; q < nphi * (GRID_COEF_STRIDE / 2); q += THREADS) dst[q] = src[q];
+    }
     const double *__restrict__ b = sun + (long)isza * 5 * nw;
     double bC[NP], bB[NP], bZ[NP], bG[NP], bT[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int i = tid + p * EXPAND_THREADS;
+        const int i = tid + p * THREADS;
         const bool ok = i < nw;
         bC[p] = ok ? b[0 * nw + i] : 0.0;
         bB[p] = ok ? b[1 * nw + i] : 0.0;
@@ -418,19 +443,177 @@ __global__ __launch_bounds__(EXPAND_THREADS) void expand_grid_kernel(const doubl
         bG[p] = ok ? b[3 * nw + i] : 0.0;
         bT[p] = ok ? b[4 * nw + i] : 0.0;
     }
-    const double *__restrict__ rec = coef + (long)blockIdx.x * nphi * GORT_COEF_STRIDE;
+    __syncthreads();
     double *__restrict__ out = lut + (long)blockIdx.x * nphi * nw;
-    // launch_expand_grid picks NP = ceil(nw/256): passes 0..NP-2 are full, only the last is ragged
-    const bool last_ok = tid + (NP - 1) * EXPAND_THREADS < nw;
-    for (int l = 0; l < nphi; ++l, rec += GORT_COEF_STRIDE, out += nw) {
-        const double aC = rec[A_C], aB = rec[A_B], aZ = rec[A_Z], aG = rec[A_G], aT = rec[A_T];
+    // launch_expand_grid picks NP = ceil(nw/THREADS): passes 0..NP-2 are full, only the last is ragged
+    const bool last_ok = tid + (NP - 1) * THREADS < nw;
+#pragma unroll 2
+    for (int l = 0; l < nphi; ++l, out += nw) {
+        const double *a = s_coef + l * GRID_COEF_STRIDE;
+        const double aC = a[A_C], aB = a[A_B], aZ = a[A_Z], aG = a[A_G], aT = a[A_T];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int i = tid + p * EXPAND_THREADS;
+            const int i = tid + p * THREADS;
             const double v = aC * bC[p] + aB * bB[p] + aZ * bZ[p] + aG * bG[p] + aT * bT[p];
-            if (p < NP - 1 || last_ok) __builtin_nontemporal_store(v, out + i);
+            if (p < NP - 1 || last_ok) {
+                if (NT) __builtin_nontemporal_store(v, out + i);
+                else out[i] = v;
+            }
         }
     }
+}
+
+// The hot kernel, aligned form.  The LUT slab is one contiguous array of
+// n_total = angles x nw doubles.  HBM3E on this part sustains its write rate only when
+// every wave store covers whole 128-B lines: a plain 8-B-per-lane fill of the 50 GB slab
+// runs at 6.5 TB/s when its wave stores are 512-B aligned and at 3.2 TB/s when they start
+// 8 B off (tools/store_probe.hip) - and with nw = 2101 (odd) any band-major mapping is
+// 8-B aligned at best.  So the slab is cut into 1-KiB chunks (128 doubles) aligned in
+// ABSOLUTE address, one chunk per wave-step (16 B per lane, one global_store_dwordx4),
+// and wave w takes chunks w, w + W, w + 2W, ... where the stride W (in chunks) is a
+// multiple of nw / gcd(nw, 128).  Then 128 W is a multiple of nw, so a lane keeps the
+// SAME two bands for its whole life (their five (sun zenith, band) terms stay in
+// registers, reloaded only when the lane's angle crosses into the next sun zenith) and
+// advances its angle by da = 128 W / nw per step.
+//
+// Everything that moves per step is wave-uniform and lives in SGPRs: the chunk's output
+// address and the address of the angle record, whose five coefficients arrive through
+// the scalar cache (tools/store_probe2.hip: one scalar record per 1-KiB step costs 2 %,
+// per 512-B step 30 %).  In ~6 % of the waves (nw = 2101) the band index wraps inside
+// the chunk, i.e. the chunk spans two angles: those waves fetch both records and each
+// element picks its own.  The coefficient buffer carries one pad record in front and a
+// tail pad so that the record prefetch needs no bounds logic.
+constexpr int EPL = 2;                  // elements (adjacent bands) per lane and step
+constexpr int CHUNK = 64 * EPL;         // doubles per wave-step
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+struct FlatLane {
+    double b[EPL][5];                   // sun terms C0,B,Z,G,T of this lane's bands at their current sun zenith
+    int isza[EPL], rem[EPL], band[EPL], wrapped[EPL], k_begin[EPL], k_end[EPL];
+};
+
+template <int DEPTH, bool NT, bool WRAP>
+__device__ __forceinline__ void flat_loop(FlatLane st, const double *__restrict__ sun, int isza_base, int nw,
+                                          int angles_per_sza, int da, long step, int k_wave,
+                                          const double *__restrict__ rec_w, double *__restrict__ out_w, int lane)
+{
+    const long rec_step = (long)da * GRID_COEF_STRIDE;
+    double rA[DEPTH][5], rB[WRAP ? DEPTH : 1][5];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const double *r = rec_w + (long)d * rec_step;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            rA[d][q] = r[q];
+            if (WRAP) rB[d][q] = r[GRID_COEF_STRIDE + q];
+        }
+    }
+    rec_w += (long)DEPTH * rec_step;
+    // the two elements of a lane are valid together except at the very ends of the slab
+    const int kb_all = st.k_begin[0] > st.k_begin[1] ? st.k_begin[0] : st.k_begin[1];
+    const int ke_all = st.k_end[0] < st.k_end[1] ? st.k_end[0] : st.k_end[1];
+    for (int k = 0; k < k_wave; k += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kk = k + d;
+            double v[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const double vA = rA[d][A_C] * st.b[j][0] + rA[d][A_B] * st.b[j][1] + rA[d][A_Z] * st.b[j][2] +
+                                  rA[d][A_G] * st.b[j][3] + rA[d][A_T] * st.b[j][4];
+                if (WRAP) {
+                    const double vB = rB[d][A_C] * st.b[j][0] + rB[d][A_B] * st.b[j][1] + rB[d][A_Z] * st.b[j][2] +
+                                      rB[d][A_G] * st.b[j][3] + rB[d][A_T] * st.b[j][4];
+                    v[j] = st.wrapped[j] ? vB : vA;
+                } else {
+                    v[j] = vA;
+                }
+            }
+            double *o = out_w + EPL * lane;
+            if (kk >= kb_all && kk < ke_all) {
+                dbl2 vv;
+                vv.x = v[0];
+                vv.y = v[1];
+                if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<dbl2 *>(o));
+                else *reinterpret_cast<dbl2 *>(o) = vv;
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPL; ++j)
+                    if (kk >= st.k_begin[j] && kk < st.k_end[j]) o[j] = v[j];
+            }
+            out_w += step;
+            // refill this slot with the record(s) DEPTH steps ahead (the tail pad makes them always readable)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                rA[d][q] = rec_w[q];
+                if (WRAP) rB[d][q] = rec_w[GRID_COEF_STRIDE + q];
+            }
+            rec_w += rec_step;
+            // next step's sun zenith, per element
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                st.rem[j] += da;
+                if (st.rem[j] >= angles_per_sza) {
+                    do { st.rem[j] -= angles_per_sza; ++st.isza[j]; } while (st.rem[j] >= angles_per_sza);
+                    if (kk + 1 < st.k_end[j]) {
+                        const double *bp = sun + (long)(st.isza[j] - isza_base) * 5 * nw + st.band[j];
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) st.b[j][q] = bp[(long)q * nw];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int DEPTH, bool NT>
+__global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restrict__ sun, int isza_base,
+                                                           const double *__restrict__ coef, int nw,
+                                                           int angles_per_sza, long angle0, long n_total, int shift,
+                                                           long stride_chunks, double *__restrict__ lut)
+{
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long wave = (long)blockIdx.x * 4 + wave_in_block;                   // scalar
+    if (wave >= stride_chunks) return;
+    const int lane = threadIdx.x & 63;
+    const long step = stride_chunks * CHUNK;       // elements per step; a multiple of nw
+    const int da = (int)(step / nw);               // angles per step
+    const long e0 = wave * CHUNK - shift;          // element index of the chunk start at step 0 (< 0 only for wave 0)
+    if (e0 >= n_total) return;
+    // angle and band of the chunk start at step 0; floor division that also works for e0 < 0
+    const long a_w = (e0 + step) / nw - da;        // scalar, >= -1
+    const int band_w = (int)((e0 + step) % nw);
+    const int k_wave = (int)((n_total - 1 - (e0 < 0 ? 0 : e0)) / step) + 1;    // scalar upper bound over lanes
+
+    FlatLane st;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        int band = band_w + EPL * lane + j;
+        st.wrapped[j] = 0;
+        if (band >= nw) { band -= nw; st.wrapped[j] = 1; }                    // nw >= CHUNK on this path: one wrap at most
+        st.band[j] = band;
+        const long n_el = e0 + EPL * lane + j;
+        st.k_begin[j] = n_el < 0 ? 1 : 0;
+        st.k_end[j] = n_el < n_total ? (int)((n_total - 1 - n_el) / step) + 1 : 0;      // first invalid step
+        // sun zenith of this element's angle, tracked incrementally in 32-bit from "as if at step 0"
+        const long ag = angle0 + a_w + st.wrapped[j] + (long)st.k_begin[j] * da;
+        int isza = (int)(ag / angles_per_sza);
+        int rem = (int)(ag - (long)isza * angles_per_sza) - st.k_begin[j] * da;
+        if (rem < 0) { rem += angles_per_sza; --isza; }
+        st.isza[j] = isza;                                                    // isza_base - 1 only for elements invalid at step 0
+        st.rem[j] = rem;
+        const bool live = st.k_end[j] > st.k_begin[j] && isza >= isza_base;   // else the first crossing loads them
+        const double *bp = sun + (long)(isza - isza_base) * 5 * nw + band;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) st.b[j][q] = live ? bp[(long)q * nw] : 0.0;
+    }
+    const double *rec_w = coef + a_w * GRID_COEF_STRIDE;                      // may point at the front pad record
+    double *out_w = lut + e0;
+    // a wave either never or always has its band wrap inside the chunk (bands are fixed per lane)
+    if (band_w + CHUNK - 1 >= nw)
+        flat_loop<DEPTH, NT, true>(st, sun, isza_base, nw, angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
+    else
+        flat_loop<DEPTH, NT, false>(st, sun, isza_base, nw, angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
 }
 
 // ------------------------------------------------------------- albedo / energy
@@ -541,12 +724,12 @@ int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_d
 }
 
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
-                         double *coef_dev, void *stream)
+                         double *coef_dev, bool compact, void *stream)
 {
     const long n = (row_end - row_begin) * g.nphi;
     if (n <= 0) return GORT_OK;
     hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       canopy_dev, g, row_begin, n, coef_dev);
+                       canopy_dev, g, row_begin, n, coef_dev, compact ? 1 : 0);
     return check_launch("geometry_grid_kernel");
 }
 
@@ -575,19 +758,35 @@ int launch_sun_table(const gort_canopy *canopy_dev, const double *L_dev, int nw,
     return check_launch("sun_table_kernel");
 }
 
-int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
-                       long row_begin, long row_end, double *lut_dev, void *stream)
+// Tuning knobs for the LUT expansion (read once):
+//   GORT_EXPAND_VARIANT  flat (default) | row     kernel form, see the two kernels above
+//   GORT_EXPAND_DEPTH    1 | 2 | 4                coefficient records in flight per lane (flat)
+//   GORT_EXPAND_NT       1 | 0                    non-temporal stores
+//   GORT_EXPAND_WAVES    target number of waves   (flat; rounded to a band-preserving stride)
+struct ExpandTuning {
+    bool flat = true, nt = true;
+    int depth = 2;
+    long waves = 16384;     // measured on MI355X: 4202 -> 9.46 ms, 8404 -> 9.24, 16808 -> 8.33, 33616 -> 8.29 (50 GB slab)
+    ExpandTuning()
+    {
+        if (const char *v = getenv("GORT_EXPAND_VARIANT")) flat = strcmp(v, "row") != 0;
+        if (const char *v = getenv("GORT_EXPAND_NT")) nt = atoi(v) != 0;
+        if (const char *v = getenv("GORT_EXPAND_DEPTH")) depth = atoi(v);
+        if (const char *v = getenv("GORT_EXPAND_WAVES")) waves = atol(v);
+        if (depth != 1 && depth != 2 && depth != 4) depth = 2;
+        if (waves < 64) waves = 64;
+    }
+};
+
+template <bool NT>
+static int launch_expand_rows(int np, dim3 grid, size_t lds, hipStream_t s, const double *sun_dev, int isza_base,
+                              const double *coef_dev, int nw, int nvza, int nphi, long row_begin, double *lut_dev)
 {
-    const long rows = row_end - row_begin;
-    if (rows <= 0) return GORT_OK;
-    const int np = (nw + EXPAND_THREADS - 1) / EXPAND_THREADS;
-    const dim3 grid((unsigned)rows), block(EXPAND_THREADS);
-    hipStream_t s = (hipStream_t)stream;
-#define GORT_EXPAND_CASE(N)                                                                                         \
-    case N:                                                                                                         \
-        hipLaunchKernelGGL(expand_grid_kernel<N>, grid, block, 0, s, sun_dev, isza_base, coef_dev, nw, nvza, nphi,  \
-                           row_begin, lut_dev);                                                                     \
-        break;
+#define GORT_EXPAND_CASE(N)                                                                                    \
+    case N:                                                                                                    \
+        hipLaunchKernelGGL((expand_grid_kernel<256, N, NT>), grid, dim3(256), lds, s, sun_dev, isza_base,     \
+                           coef_dev, nw, nvza, nphi, row_begin, lut_dev);                                      \
+        return GORT_OK;
     switch (np) {
         GORT_EXPAND_CASE(1)
         GORT_EXPAND_CASE(2)
@@ -599,10 +798,78 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
         GORT_EXPAND_CASE(8)
         GORT_EXPAND_CASE(9)
     default:
-        return fail(GORT_EINVAL, "expand_grid: nw=%d exceeds %d bands", nw, 9 * EXPAND_THREADS);
+        return fail(GORT_EINVAL, "expand_grid: nw=%d needs %d passes of 256 threads (max 9)", nw, np);
     }
 #undef GORT_EXPAND_CASE
-    return check_launch("expand_grid_kernel");
+}
+
+static long gcd_long(long a, long b)
+{
+    while (b) { const long t = a % b; a = b; b = t; }
+    return a;
+}
+
+static const ExpandTuning &tuning()
+{
+    static const ExpandTuning t;
+    return t;
+}
+
+// chunk stride (in 1-KiB chunks) of the flat kernel: a multiple of nw/gcd(nw,CHUNK) close to the wave target
+static long flat_stride(int nw, long chunks)
+{
+    const long unit = nw / gcd_long(nw, CHUNK);
+    long mult = (tuning().waves + unit / 2) / unit;
+    if (mult < 1) mult = 1;
+    long stride = unit * mult;
+    if (stride > chunks) stride = unit * ((chunks + unit - 1) / unit);       // tiny slab: one step per wave
+    return stride;
+}
+
+// records the LUT kernel may read past the last angle (prefetch depth x angles per step, + wrap, + slack)
+long expand_grid_tail_pad_records(int nw, long n_total)
+{
+    if (!tuning().flat) return 0;
+    const long stride = flat_stride(nw, (n_total + 2 * CHUNK - 2) / CHUNK);
+    const long da = stride * CHUNK / nw;
+    return 8 * da + 9;      // the k loop runs in groups of DEPTH <= 4 and prefetches DEPTH steps ahead (+1: wrap record)
+}
+
+int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
+                       long row_begin, long row_end, double *lut_dev, void *stream)
+{
+    const long rows = row_end - row_begin;
+    if (rows <= 0) return GORT_OK;
+    const ExpandTuning &tune = tuning();
+    hipStream_t s = (hipStream_t)stream;
+    if (!tune.flat) {
+        const int np = (nw + 255) / 256;
+        const size_t lds = sizeof(double) * GRID_COEF_STRIDE * (size_t)nphi;
+        if (lds > 64 * 1024) return fail(GORT_EINVAL, "expand_grid: nphi=%d too large for the LDS staging buffer", nphi);
+        const dim3 grid((unsigned)rows);
+        int rc = tune.nt ? launch_expand_rows<true>(np, grid, lds, s, sun_dev, isza_base, coef_dev, nw, nvza, nphi, row_begin, lut_dev)
+                         : launch_expand_rows<false>(np, grid, lds, s, sun_dev, isza_base, coef_dev, nw, nvza, nphi, row_begin, lut_dev);
+        if (rc) return rc;
+        return check_launch("expand_grid_kernel");
+    }
+    // flat, absolutely aligned form
+    const long n_total = rows * nphi * (long)nw;
+    const int shift = (int)((reinterpret_cast<uintptr_t>(lut_dev) / sizeof(double)) % CHUNK);
+    const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
+    const long stride = flat_stride(nw, chunks);
+    const dim3 grid((unsigned)((stride + 3) / 4));
+    const int angles_per_sza = nvza * nphi;
+    const long angle0 = row_begin * nphi;
+#define GORT_FLAT(D, N)                                                                                           \
+    hipLaunchKernelGGL((expand_flat_kernel<D, N>), grid, dim3(256), 0, s, sun_dev, isza_base, coef_dev, nw,      \
+                       angles_per_sza, angle0, n_total, shift, stride, lut_dev)
+    if (tune.nt) {
+        if (tune.depth == 1) GORT_FLAT(1, true); else if (tune.depth == 2) GORT_FLAT(2, true); else GORT_FLAT(4, true);
+    } else {
+        if (tune.depth == 1) GORT_FLAT(1, false); else if (tune.depth == 2) GORT_FLAT(2, false); else GORT_FLAT(4, false);
+    }
+#undef GORT_FLAT
+    return check_launch("expand_flat_kernel");
 }
 
 int launch_energy(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev, long nA,

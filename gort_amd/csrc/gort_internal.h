@@ -53,12 +53,16 @@ int launch_lambda_table(const gort_canopy *canopy_dev, int nw, const double *rso
                         const double *rleaf_dev, const double *tleaf_dev, double *L_dev, void *stream);
 int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA,
                            double *coef_dev, double *K_dev, void *stream);
+// compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
-                         double *coef_dev, void *stream);
+                         double *coef_dev, bool compact, void *stream);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
                          long nA, double *rsurf_dev, double *scomp_dev, void *stream);
 int launch_sun_table(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g,
                      int isza_begin, int isza_end, double *sun_dev, void *stream);
+// coef_dev for launch_expand_grid: compact records, with ONE readable pad record in front of coef_dev
+// and expand_grid_tail_pad_records() readable records behind the last angle
+long expand_grid_tail_pad_records(int nw, long n_total);
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
                        long row_begin, long row_end, double *lut_dev, void *stream);
 int launch_energy(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev, long nA,

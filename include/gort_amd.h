@@ -110,6 +110,13 @@ int  gort_lut_read(const char *path, gort_canopy *c);
 
 int  gort_device_count(void);
 
+/* Plain device-memory helpers for callers that do not bring their own allocator (the `gortt`
+ * host, C drivers).  New surface, not reference surface.  gort_dev_malloc returns NULL on failure. */
+void *gort_dev_malloc(size_t bytes);
+void  gort_dev_free(void *p_dev);
+int   gort_memcpy_h2d(void *dst_dev, const void *src, size_t bytes);
+int   gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
+
 /* Pn/EPgap/KOpen for a batch of canopies (one workgroup per member).  Fills
  * p_n0/epgap/k_open/k_openep of every record in place; honours use_q08.
  * Replaces gortt_gap_probabilities (gortt_pn_kopen.c:7-129) and

@@ -29,6 +29,12 @@ def err(a, b):
     return relerr(a, b, floor=FLOOR)
 
 
+def err_K(a, b):
+    """Areal proportions Kc,Kg,Kt,Kz sum to 1 and Kt = max(0, 1-Kc-Kz-Kg) cancels to ~1e-16 noise around
+    zero in the reference itself: compare them on the absolute scale of 1."""
+    return relerr(a, b, floor=1.0)
+
+
 @pytest.fixture(scope="module")
 def eng():
     e = api.Engine()
@@ -104,7 +110,7 @@ def test_c2_principal_plane(eng, golden):
     eng.set_spectra(*api.spectra(g["wl"]))
     r, sc, K = eng.rsurf_stream(g["angles"], want_scomp=True)
     assert err(r, g["rsurf"]) <= REGRESSION
-    assert err(K, g["K"]) <= REGRESSION
+    assert err_K(K, g["K"]) <= REGRESSION
     assert err(sc, g["scomp"]) <= REGRESSION
     assert np.isnan(r[[0, 180], 0]).all() and np.isfinite(r[1:180]).all()
 
@@ -115,7 +121,7 @@ def test_c3_subgrid(eng, golden):
     eng.set_spectra(*api.spectra(g["wl"]))
     r, _, K = eng.rsurf_stream(g["angles"])
     assert err(r, g["rsurf"]) <= REGRESSION
-    assert err(K, g["K"]) <= REGRESSION
+    assert err_K(K, g["K"]) <= REGRESSION
 
 
 def test_random_stream_second_canopy(eng, golden):
@@ -124,7 +130,7 @@ def test_random_stream_second_canopy(eng, golden):
     eng.set_spectra(*api.spectra(g["wl"]))
     r, sc, K = eng.rsurf_stream(g["angles"], want_scomp=True)
     assert err(r, g["rsurf"]) <= REGRESSION
-    assert err(K, g["K"]) <= REGRESSION
+    assert err_K(K, g["K"]) <= REGRESSION
     assert err(sc, g["scomp"]) <= REGRESSION
 
 
@@ -141,7 +147,7 @@ def test_stream_edge_cases(eng):
     ang = np.array([[25., 40., 35., 170.], [95., 0., 30., 0.], [10., 0., 120., 0.]])
     r, _, K = eng.rsurf_stream(ang)
     ro, _, Ko = O.rsurf_stream(oracle_like(c), ang, rs, rl, tl)
-    assert err(r, ro) <= REGRESSION and err(K, Ko) <= REGRESSION
+    assert err(r, ro) <= REGRESSION and err_K(K, Ko) <= REGRESSION
     assert np.isnan(r[1:]).all()
 
 
