@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="after the timed steps, all-gather the full LUT on every rank (RCCL) and report allgather_ms")
     ap.add_argument("--traffic-gb", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (GB)")
     args = ap.parse_args()
@@ -127,8 +129,8 @@ def main():
     eng.set_spectra(rs, rl, tl)
     grid = api.hemisphere_grid(nsza=args.nsza)
     rows = grid.nsza * grid.nvza
-    r0 = rows * rank // world
-    r1 = rows * (rank + 1) // world
+    from gort_amd.shard import all_gather_lut, row_slab
+    r0, r1 = row_slab(rank, world, rows)
     my_samples = (r1 - r0) * grid.nphi * nw
     total_samples = rows * grid.nphi * nw
     lut = torch.empty(((r1 - r0) * grid.nphi, nw), dtype=torch.float64, device="cuda")
@@ -158,6 +160,16 @@ def main():
         k = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
+
+    # ---- optional, OUTSIDE the timed step: reassemble the LUT on every rank with one RCCL all-gather ----
+    allgather_ms = None
+    if args.gather and world > 1:
+        torch.cuda.synchronize(); barrier()
+        tg = time.perf_counter()
+        full = all_gather_lut(lut.view(r1 - r0, grid.nphi * nw), rows)
+        torch.cuda.synchronize(); barrier()
+        allgather_ms = (time.perf_counter() - tg) * 1e3
+        del full
 
     # ---- parity spot check (outside the timed region): sampled rows vs the CPU oracle ----
     parity = None
@@ -208,6 +220,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src},
             "parity": parity,
         }
+        if allgather_ms is not None:
+            out["allgather_ms"] = allgather_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
