@@ -254,3 +254,113 @@ def test_cli_text_identical_to_reference(case, tmp_path):
     else:
         assert out == case["stdout"]
     assert errtxt == case["stderr"]
+
+
+# ------------------------------------------------- BASELINE.json full sizes
+def _full_grid():
+    return api.hemisphere_grid()
+
+
+def test_c3_full_hemisphere_one_band(eng, golden):
+    """Config 3 at full size: 91 x 91 x 361 = 2 989 441 tuples x 1 band through the LUT entry point.
+    Checked against every golden node of the C3 sub-grid, against the oracle on a seeded sample, and
+    through size-independent properties (NaN pattern at the horizons, proportions sum to 1)."""
+    import torch
+    c = gpu_canopy(lai=4.0)
+    rs, rl, tl = api.spectra([800.0])
+    eng.set_canopy(c); eng.set_spectra(rs, rl, tl)
+    g = _full_grid()
+    rows = g.nsza * g.nvza
+    lut = torch.empty((rows * g.nphi, 1), dtype=torch.float64, device="cuda")
+    eng.rsurf_grid_dev(g, 0, rows, lut)
+    eng.synchronize()
+    full = lut.cpu().numpy().reshape(g.nsza, g.nvza, g.nphi)
+    # every integer-degree node of the golden sub-grid (stream order: vza phi sza 0)
+    gg = golden("c3_subgrid.npz")
+    a = gg["angles"]
+    on_grid = (a[:, 1] == np.round(a[:, 1])) & (a[:, 1] <= 360)
+    got = full[a[on_grid, 2].astype(int), a[on_grid, 0].astype(int), a[on_grid, 1].astype(int)]
+    assert err(got, gg["rsurf"][on_grid, 0]) <= REGRESSION
+    # NaN exactly where a zenith is 90 deg
+    nanmask = np.isnan(full)
+    want = np.zeros_like(nanmask)
+    want[90, :, :] = True
+    want[:, 90, :] = True
+    assert np.array_equal(nanmask, want)
+    # seeded sample vs the oracle
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, rows * g.nphi, 3000)
+    r, l = idx // g.nphi, idx % g.nphi
+    ang = np.stack([(r % g.nvza).astype(float), l.astype(float), (r // g.nvza).astype(float), np.zeros(idx.size)], 1)
+    ref, _, Kref = O.rsurf_stream(oracle_like(c), ang, rs, rl, tl)
+    assert err(full.reshape(-1)[idx], ref[:, 0]) <= REGRESSION
+    # proportions: Kc+Kg+Kt+Kz = 1 wherever the shaded-crown proportion is not clipped at 0
+    _, _, K = eng.rsurf_stream(ang)
+    live = K[:, 2] > 0
+    assert np.abs(K[live].sum(axis=1) - 1.0).max() < 1e-12
+    assert err_K(K, Kref) <= REGRESSION
+
+
+def test_metric_grid_full_size_properties(eng):
+    """The benchmark workload itself (2 989 441 tuples x 2101 bands, 50 GB): properties that do not need a
+    CPU pass over 6e9 samples.
+      * sharding invariance: the LUT written as 5 uneven row slabs (unaligned slab pointers, ragged first and
+        last chunks) is BITWISE the LUT written in one launch;
+      * sampled rows equal the stream path bitwise and the oracle to REGRESSION;
+      * checksum of checksums: per-row sums of the slabbed LUT equal those of the one-shot LUT."""
+    import torch
+    c = gpu_canopy(lai=4.0)
+    wl = np.arange(400.0, 2501.0)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_canopy(c); eng.set_spectra(rs, rl, tl)
+    g = _full_grid()
+    rows, nw = g.nsza * g.nvza, wl.size
+    one = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
+    eng.rsurf_grid_dev(g, 0, rows, one)
+    cuts = [0, 1, 1000, 4141, 8280, rows]
+    parts = torch.empty_like(one)
+    for a, b in zip(cuts, cuts[1:]):
+        eng.rsurf_grid_dev(g, a, b, parts[a * g.nphi:])
+    eng.synchronize()
+    # bitwise equality incl. NaN payload positions: compare the raw 64-bit patterns
+    assert torch.equal(one.view(torch.int64), parts.view(torch.int64))
+    s1 = torch.nansum(one.view(rows, -1), dim=1)
+    s2 = torch.nansum(parts.view(rows, -1), dim=1)
+    assert torch.equal(s1, s2) and bool(torch.isfinite(s1).all())
+    del parts
+    rng = np.random.default_rng(3)
+    idx = np.sort(rng.choice(rows * g.nphi, size=48, replace=False))
+    got = one[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+    r = idx // g.nphi
+    ang = np.stack([(r % g.nvza).astype(float), (idx % g.nphi).astype(float), (r // g.nvza).astype(float),
+                    np.zeros(idx.size)], 1)
+    via_stream, _, _ = eng.rsurf_stream(ang, want_K=False)
+    assert err(got, via_stream) <= 1e-13
+    ref, _, _ = O.rsurf_stream(oracle_like(c), ang, rs, rl, tl, want_K=False)
+    assert err(got, ref) <= REGRESSION
+    # the LUT is NaN exactly on the two horizon planes, for every band
+    nan_rows = torch.isnan(one).view(g.nsza, g.nvza, g.nphi * nw).all(dim=2).cpu().numpy()
+    want = np.zeros((g.nsza, g.nvza), bool)
+    want[90, :] = True
+    want[:, 90] = True
+    assert np.array_equal(nan_rows, want)
+    assert not bool(torch.isnan(one.view(g.nsza, g.nvza, -1)[:90, :90]).any())
+
+
+def test_c4_full_spectral_albedo_table(eng, golden):
+    """Config 4 at full size: 91 sun zeniths x 2101 bands x (albedo, favegt, fasoil) in ONE call (the
+    reference needs 66 runs of <= 32 bands).  Golden rows where available, oracle elsewhere."""
+    g = golden("c4_albedo.npz")
+    c = gpu_canopy(lai=4.0)
+    wl = np.arange(400.0, 2501.0)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_canopy(c); eng.set_spectra(rs, rl, tl)
+    sza = np.arange(0.0, 91.0)
+    z = np.zeros_like(sza)
+    e = eng.energy_stream(np.stack([z, z, sza, z], 1))
+    assert e.shape == (91, 2101, 3)
+    assert err(e[g["sza_a"].astype(int)], g["energy_a"]) <= REGRESSION            # all bands, 5 sun zeniths
+    assert err(e[:, ::105][:, :21], g["energy_b"]) <= REGRESSION                   # 21 bands, all sun zeniths
+    # energy conservation: albedo + favegt + fasoil = 1 (gortt_albedo.c:51-52)
+    tot = e[:90].sum(axis=2)
+    assert np.abs(tot - 1.0).max() < 1e-12
