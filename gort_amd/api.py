@@ -65,6 +65,8 @@ DECLARED_SYMBOLS = [
     "gort_gap_probabilities", "gort_gap_probabilities_dev",
     "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
+    "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
+    "gort_rsurf_members_grid_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
     "gort_energy_stream", "gort_energy_stream_dev",
 ]
@@ -105,6 +107,13 @@ def lib():
         L.gort_rsurf_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gort_rsurf_stream_dev.argtypes = L.gort_rsurf_stream.argtypes
         L.gort_rsurf_grid_dev.argtypes = [C.c_void_p, C.POINTER(Grid), C.c_long, C.c_long, C.c_void_p]
+        L.gort_rsurf_members_grid_dev.argtypes = [C.c_void_p, C.POINTER(Grid), C.c_int, C.c_int, C.c_void_p]
+        L.gort_engine_n_members.argtypes = [C.c_void_p]
+        L.gort_engine_set_members.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.gort_engine_set_members_leaf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                   C.c_void_p, C.c_int]
+        L.gort_engine_get_member.argtypes = [C.c_void_p, C.c_int, C.POINTER(Canopy), C.c_void_p, C.c_void_p,
+                                             C.c_void_p]
         L.gort_energy_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.gort_energy_stream_dev.argtypes = L.gort_energy_stream.argtypes
         L.gort_gap_probabilities.argtypes = [C.c_void_p, C.c_int]
@@ -279,6 +288,33 @@ class Engine:
         rs, rl, tl = _f64(rsoil), _f64(rleaf), _f64(tleaf)
         _check(lib().gort_engine_set_spectra(self.h, rs.size, _ptr(rs), _ptr(rl), _ptr(tl)))
         self.nw = rs.size
+
+    # ---- ensembles -------------------------------------------------------------------------------
+    def set_members(self, members, spectra, compute_gaps=False):
+        """members: list of Canopy; spectra: [n][3][nw] (rsoil, rleaf, tleaf per member)."""
+        arr = (Canopy * len(members))(*members)
+        sp = _f64(spectra)
+        assert sp.shape[0] == len(members) and sp.shape[1] == 3
+        _check(lib().gort_engine_set_members(self.h, arr, len(members), int(compute_gaps), sp.shape[2], _ptr(sp)))
+        self.nw = sp.shape[2]
+
+    def set_members_leaf(self, members, leaf, wl, compute_gaps=False):
+        """Spectra of every member computed on the device from its LeafSoil parameters."""
+        arr = (Canopy * len(members))(*members)
+        larr = (LeafSoil * len(leaf))(*leaf)
+        assert len(leaf) == len(members)
+        w = _f64(wl)
+        _check(lib().gort_engine_set_members_leaf(self.h, arr, larr, len(members), int(compute_gaps), _ptr(w), w.size))
+        self.nw = w.size
+
+    def get_member(self, m):
+        c = Canopy()
+        rs, rl, tl = np.zeros(self.nw), np.zeros(self.nw), np.zeros(self.nw)
+        _check(lib().gort_engine_get_member(self.h, m, C.byref(c), _ptr(rs), _ptr(rl), _ptr(tl)))
+        return c, rs, rl, tl
+
+    def rsurf_members_grid_dev(self, grid, member_begin, member_end, lut_t):
+        _check(lib().gort_rsurf_members_grid_dev(self.h, C.byref(grid), member_begin, member_end, _ptr(lut_t)))
 
     def synchronize(self):
         _check(lib().gort_engine_synchronize(self.h))

@@ -24,6 +24,7 @@ ARCH = "gfx950"
 UNITS = [
     ("gort_gap.hip", ["-ffp-contract=off"]),
     ("gort_brdf.hip", []),
+    ("gort_spectra.hip", []),
     ("gort_api.hip", []),
     ("gort_host.cpp", ["-ffp-contract=off", '-DGORT_DATA_DIR="%s"' % os.path.join(PKG, "data")]),
 ]

@@ -49,15 +49,17 @@ struct DevBuf {
 
 using namespace gort;
 
+// The engine holds n_members >= 1 canopies with their spectra.  The single-canopy entry points
+// (gort_engine_set_canopy / _set_spectra, stream, energy) work on member 0 of a 1-member engine.
 struct gort_engine {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> ev;          // start/stop pairs around the LUT expansion kernel
     size_t ev_used = 0;
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
-    gort_canopy host_canopy;
-    bool have_canopy = false, have_spectra = false, have_nodes = false;
+    DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
+    int n_members = 1;
+    bool have_canopy = false, have_spectra = false, have_nodes = false, have_tables = false;
     int nw = 0;
-    std::vector<double> h_rsoil, h_rleaf, h_tleaf;
 };
 
 extern "C" int gort_device_count(void)
@@ -143,7 +145,7 @@ extern "C" void gort_engine_destroy(gort_engine *e)
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
-                      &e->out2})
+                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof})
         b->release();
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -152,6 +154,7 @@ extern "C" void gort_engine_destroy(gort_engine *e)
 
 extern "C" void *gort_engine_stream(gort_engine *e) { return e ? (void *)e->stream : nullptr; }
 extern "C" int gort_engine_nw(const gort_engine *e) { return e ? e->nw : 0; }
+extern "C" int gort_engine_n_members(const gort_engine *e) { return e ? e->n_members : 0; }
 
 extern "C" int gort_engine_synchronize(gort_engine *e)
 {
@@ -160,27 +163,34 @@ extern "C" int gort_engine_synchronize(gort_engine *e)
     return GORT_OK;
 }
 
+// band-only tables of every member, L[n][11][nw]
 static int refresh_lambda_table(gort_engine *e)
 {
     if (!e->have_canopy || !e->have_spectra) return GORT_OK;
-    const int nw = e->nw;
-    int rc = e->L.reserve(sizeof(double) * L_NSLOT * (size_t)nw);
+    int rc = e->L.reserve(sizeof(double) * L_NSLOT * (size_t)e->nw * (size_t)e->n_members);
     if (rc) return rc;
-    const double *sp = e->spectra.as<double>();
-    return launch_lambda_table(e->canopy.as<gort_canopy>(), nw, sp, sp + nw, sp + 2 * nw, e->L.as<double>(),
-                               e->stream);
+    return launch_lambda_table(e->canopy.as<gort_canopy>(), e->n_members, e->nw, e->spectra.as<double>(),
+                               e->L.as<double>(), e->stream);
+}
+
+static int upload_canopies(gort_engine *e, const gort_canopy *members, int n, int compute_gaps)
+{
+    int rc = e->canopy.reserve(sizeof(gort_canopy) * (size_t)n);
+    if (rc) return rc;
+    GORT_HIP(hipStreamSynchronize(e->stream));         // the stream may still be reading the previous records
+    GORT_HIP(hipMemcpy(e->canopy.p, members, sizeof(gort_canopy) * (size_t)n, hipMemcpyHostToDevice));
+    if (compute_gaps && (rc = launch_gap_probabilities(e->canopy.as<gort_canopy>(), n, e->stream))) return rc;
+    if (n != e->n_members) e->have_spectra = false;    // spectra are per member
+    e->n_members = n;
+    e->have_canopy = true;
+    return GORT_OK;
 }
 
 extern "C" int gort_engine_set_canopy(gort_engine *e, const gort_canopy *c)
 {
     if (!e || !c) return fail(GORT_EINVAL, "gort_engine_set_canopy: bad argument");
-    int rc = e->canopy.reserve(sizeof(gort_canopy));
+    int rc = upload_canopies(e, c, 1, 0);
     if (rc) return rc;
-    // the stream may still be reading the previous record
-    GORT_HIP(hipStreamSynchronize(e->stream));
-    e->host_canopy = *c;
-    GORT_HIP(hipMemcpyAsync(e->canopy.p, &e->host_canopy, sizeof(gort_canopy), hipMemcpyHostToDevice, e->stream));
-    e->have_canopy = true;
     return refresh_lambda_table(e);
 }
 
@@ -188,20 +198,99 @@ extern "C" int gort_engine_set_spectra(gort_engine *e, int nw, const double *rso
                                        const double *tleaf)
 {
     if (!e || nw <= 0 || !rsoil || !rleaf || !tleaf) return fail(GORT_EINVAL, "gort_engine_set_spectra: bad argument");
+    if (e->n_members != 1)
+        return fail(GORT_EINVAL, "gort_engine_set_spectra: engine holds %d members; use gort_engine_set_members", e->n_members);
     int rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw);
     if (rc) return rc;
     GORT_HIP(hipStreamSynchronize(e->stream));
-    e->h_rsoil.assign(rsoil, rsoil + nw);
-    e->h_rleaf.assign(rleaf, rleaf + nw);
-    e->h_tleaf.assign(tleaf, tleaf + nw);
     double *sp = e->spectra.as<double>();
     const size_t b = sizeof(double) * (size_t)nw;
-    GORT_HIP(hipMemcpyAsync(sp, e->h_rsoil.data(), b, hipMemcpyHostToDevice, e->stream));
-    GORT_HIP(hipMemcpyAsync(sp + nw, e->h_rleaf.data(), b, hipMemcpyHostToDevice, e->stream));
-    GORT_HIP(hipMemcpyAsync(sp + 2 * nw, e->h_tleaf.data(), b, hipMemcpyHostToDevice, e->stream));
+    GORT_HIP(hipMemcpy(sp, rsoil, b, hipMemcpyHostToDevice));
+    GORT_HIP(hipMemcpy(sp + nw, rleaf, b, hipMemcpyHostToDevice));
+    GORT_HIP(hipMemcpy(sp + 2 * nw, tleaf, b, hipMemcpyHostToDevice));
     e->nw = nw;
     e->have_spectra = true;
     return refresh_lambda_table(e);
+}
+
+// ---- ensembles (BASELINE config 5) ----
+
+extern "C" int gort_engine_set_members(gort_engine *e, const gort_canopy *members, int n_members, int compute_gaps,
+                                       int nw, const double *spectra)
+{
+    if (!e || !members || n_members <= 0 || n_members > 65535 || nw <= 0 || !spectra)
+        return fail(GORT_EINVAL, "gort_engine_set_members: bad argument");
+    int rc = upload_canopies(e, members, n_members, compute_gaps);
+    if (rc) return rc;
+    const size_t bytes = sizeof(double) * 3 * (size_t)nw * (size_t)n_members;
+    if ((rc = e->spectra.reserve(bytes))) return rc;
+    GORT_HIP(hipMemcpy(e->spectra.p, spectra, bytes, hipMemcpyHostToDevice));
+    e->nw = nw;
+    e->have_spectra = true;
+    return refresh_lambda_table(e);
+}
+
+static int ensure_spectral_tables(gort_engine *e)
+{
+    if (e->have_tables) return GORT_OK;
+    const double *t12, *talf;
+    interface_transmissivity_tables(&t12, &talf);
+    int rc;
+    if ((rc = e->tab_coef.reserve(sizeof(float) * 7 * GORT_NBANDS))) return rc;
+    if ((rc = e->tab_t12.reserve(sizeof(double) * GORT_NBANDS))) return rc;
+    if ((rc = e->tab_talf.reserve(sizeof(double) * GORT_NBANDS))) return rc;
+    if ((rc = e->tab_eof.reserve(sizeof(double) * 4 * 421))) return rc;
+    GORT_HIP(hipMemcpy(e->tab_coef.p, prospect_coeff_table(), sizeof(float) * 7 * GORT_NBANDS, hipMemcpyHostToDevice));
+    GORT_HIP(hipMemcpy(e->tab_t12.p, t12, sizeof(double) * GORT_NBANDS, hipMemcpyHostToDevice));
+    GORT_HIP(hipMemcpy(e->tab_talf.p, talf, sizeof(double) * GORT_NBANDS, hipMemcpyHostToDevice));
+    GORT_HIP(hipMemcpy(e->tab_eof.p, price_eof_table(), sizeof(double) * 4 * 421, hipMemcpyHostToDevice));
+    e->have_tables = true;
+    return GORT_OK;
+}
+
+extern "C" int gort_engine_set_members_leaf(gort_engine *e, const gort_canopy *members, const gort_leaf_soil *leaf,
+                                            int n_members, int compute_gaps, const double *wl_nm, int nw)
+{
+    if (!e || !members || !leaf || n_members <= 0 || n_members > 65535 || nw <= 0 || !wl_nm)
+        return fail(GORT_EINVAL, "gort_engine_set_members_leaf: bad argument");
+    for (int i = 0; i < nw; ++i)
+        if (!(wl_nm[i] >= 400 && wl_nm[i] <= 2500))
+            return fail(GORT_ERANGE, "gortt_price_soil: wavlength out of range (400-2500)");
+    int rc = upload_canopies(e, members, n_members, compute_gaps);
+    if (rc) return rc;
+    if ((rc = ensure_spectral_tables(e))) return rc;
+    if ((rc = e->leaf.reserve(sizeof(gort_leaf_soil) * (size_t)n_members))) return rc;
+    if ((rc = e->wl.reserve(sizeof(double) * (size_t)nw))) return rc;
+    if ((rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw * (size_t)n_members))) return rc;
+    GORT_HIP(hipMemcpy(e->leaf.p, leaf, sizeof(gort_leaf_soil) * (size_t)n_members, hipMemcpyHostToDevice));
+    GORT_HIP(hipMemcpy(e->wl.p, wl_nm, sizeof(double) * (size_t)nw, hipMemcpyHostToDevice));
+    rc = launch_member_spectra(e->leaf.as<gort_leaf_soil>(), n_members, nw, e->wl.as<double>(),
+                               e->tab_coef.as<float>(), e->tab_t12.as<double>(), e->tab_talf.as<double>(),
+                               e->tab_eof.as<double>(), e->spectra.as<double>(), e->stream);
+    if (rc) return rc;
+    e->nw = nw;
+    e->have_spectra = true;
+    return refresh_lambda_table(e);
+}
+
+extern "C" int gort_engine_get_member(gort_engine *e, int member, gort_canopy *canopy, double *rsoil, double *rleaf,
+                                      double *tleaf)
+{
+    if (!e || member < 0 || member >= e->n_members) return fail(GORT_EINVAL, "gort_engine_get_member: bad member");
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    if (canopy) {
+        if (!e->have_canopy) return fail(GORT_EINVAL, "gort_engine_get_member: no canopy set");
+        GORT_HIP(hipMemcpy(canopy, e->canopy.as<gort_canopy>() + member, sizeof(gort_canopy), hipMemcpyDeviceToHost));
+    }
+    if (rsoil || rleaf || tleaf) {
+        if (!e->have_spectra) return fail(GORT_EINVAL, "gort_engine_get_member: no spectra set");
+        const double *sp = e->spectra.as<double>() + (size_t)member * 3 * e->nw;
+        const size_t b = sizeof(double) * (size_t)e->nw;
+        if (rsoil) GORT_HIP(hipMemcpy(rsoil, sp, b, hipMemcpyDeviceToHost));
+        if (rleaf) GORT_HIP(hipMemcpy(rleaf, sp + e->nw, b, hipMemcpyDeviceToHost));
+        if (tleaf) GORT_HIP(hipMemcpy(tleaf, sp + 2 * e->nw, b, hipMemcpyDeviceToHost));
+    }
+    return GORT_OK;
 }
 
 static int require_ready(const gort_engine *e, const char *who)
@@ -223,7 +312,7 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if (nA == 0) return GORT_OK;
     rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA);
     if (rc) return rc;
-    const gort_canopy *c = e->canopy.as<gort_canopy>();
+    const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
     rc = launch_geometry_stream(c, angles_dev, nA, e->coef.as<double>(), K_dev, e->stream);
     if (rc) return rc;
     return launch_expand_stream(c, e->L.as<double>(), e->nw, e->coef.as<double>(), nA, rsurf_dev, scomp_dev, e->stream);
@@ -254,22 +343,17 @@ extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, 
 
 // ------------------------------------------------------------------ LUT (grid)
 
-extern "C" int gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, long row_end, double *lut_dev)
+// rows are GLOBAL: member * (nsza*nvza) + isza * nvza + ivza
+static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long row_end, double *lut_dev)
 {
-    int rc = require_ready(e, "gort_rsurf_grid_dev");
-    if (rc) return rc;
-    if (!g || g->nsza <= 0 || g->nvza <= 0 || g->nphi <= 0) return fail(GORT_EINVAL, "gort_rsurf_grid_dev: bad grid");
-    const long rows_total = (long)g->nsza * g->nvza;
-    if (row_begin < 0 || row_end > rows_total || row_begin > row_end)
-        return fail(GORT_EINVAL, "gort_rsurf_grid_dev: rows [%ld,%ld) outside [0,%ld)", row_begin, row_end, rows_total);
-    if (row_begin == row_end) return GORT_OK;
-    if (!lut_dev) return fail(GORT_EINVAL, "gort_rsurf_grid_dev: null output");
+    int rc;
     const long rows = row_end - row_begin, nA = rows * g->nphi;
     const int nw = e->nw;
     const gort_canopy *c = e->canopy.as<gort_canopy>();
     const bool few_bands = nw < 128 || nw > 9 * 256;
     if (few_bands) {
-        // few bands: one thread per sample straight from the full angle records
+        // few bands: one thread per sample straight from the full angle records (single canopy only)
+        if (e->n_members != 1) return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: needs 128 <= nw <= 2304 bands");
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
         return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, e->stream);
@@ -282,9 +366,10 @@ extern "C" int gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_
     if (fresh) GORT_HIP(hipMemsetAsync(e->coef.p, 0, coef_bytes, e->stream));      // pads hold finite values
     double *coef8 = e->coef.as<double>() + 8;
     if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, coef8, true, e->stream))) return rc;
-    const int is0 = (int)(row_begin / g->nvza), is1 = (int)((row_end - 1) / g->nvza) + 1;
-    if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(is1 - is0)))) return rc;
-    if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, is0, is1, e->sun.as<double>(), e->stream))) return rc;
+    // sun rows q = member*nsza + isza touched by [row_begin, row_end)
+    const int q0 = (int)(row_begin / g->nvza), q1 = (int)((row_end - 1) / g->nvza) + 1;
+    if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(q1 - q0)))) return rc;
+    if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, e->sun.as<double>(), e->stream))) return rc;
     // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to
     // 512 launches are kept between two gort_engine_last_expand_ms() calls
     const bool timed = e->ev_used + 2 <= 1024;
@@ -296,13 +381,47 @@ extern "C" int gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_
         }
         GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
-    rc = launch_expand_grid(e->sun.as<double>(), is0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
+    rc = launch_expand_grid(e->sun.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
                             e->stream);
     if (timed) {
         GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;
     }
     return rc;
+}
+
+static int check_grid(const gort_grid *g, const char *who)
+{
+    if (!g || g->nsza <= 0 || g->nvza <= 0 || g->nphi <= 0) return fail(GORT_EINVAL, "%s: bad grid", who);
+    return GORT_OK;
+}
+
+extern "C" int gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, long row_end, double *lut_dev)
+{
+    int rc = require_ready(e, "gort_rsurf_grid_dev");
+    if (rc) return rc;
+    if ((rc = check_grid(g, "gort_rsurf_grid_dev"))) return rc;
+    const long rows_total = (long)g->nsza * g->nvza;       // member 0
+    if (row_begin < 0 || row_end > rows_total || row_begin > row_end)
+        return fail(GORT_EINVAL, "gort_rsurf_grid_dev: rows [%ld,%ld) outside [0,%ld)", row_begin, row_end, rows_total);
+    if (row_begin == row_end) return GORT_OK;
+    if (!lut_dev) return fail(GORT_EINVAL, "gort_rsurf_grid_dev: null output");
+    return grid_rows(e, g, row_begin, row_end, lut_dev);
+}
+
+extern "C" int gort_rsurf_members_grid_dev(gort_engine *e, const gort_grid *g, int member_begin, int member_end,
+                                           double *lut_dev)
+{
+    int rc = require_ready(e, "gort_rsurf_members_grid_dev");
+    if (rc) return rc;
+    if ((rc = check_grid(g, "gort_rsurf_members_grid_dev"))) return rc;
+    if (member_begin < 0 || member_end > e->n_members || member_begin > member_end)
+        return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: members [%d,%d) outside [0,%d)", member_begin, member_end,
+                    e->n_members);
+    if (member_begin == member_end) return GORT_OK;
+    if (!lut_dev) return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: null output");
+    const long rpm = (long)g->nsza * g->nvza;
+    return grid_rows(e, g, member_begin * rpm, member_end * rpm, lut_dev);
 }
 
 extern "C" double gort_engine_last_expand_ms(gort_engine *e)

@@ -244,15 +244,20 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 }
 
 // grid nodes generated from indices; identical to streaming "vza phi sza 0" 
-__global__ __launch_bounds__(256) void geometry_grid_kernel(const gort_canopy *__restrict__ canopy, gort_grid g,
+// Ensemble form: rows run over (member, sun zenith, view zenith); member = row / rows_per_member picks the canopy.
+__global__ __launch_bounds__(256) void geometry_grid_kernel(const gort_canopy *__restrict__ canopies, gort_grid g,
                                                              long row_begin, long n_angles,
                                                              double *__restrict__ coef, int compact)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_angles) return;
-    const long row = row_begin + i / g.nphi;
+    const long rows_per_member = (long)g.nsza * g.nvza;
+    const long grow = row_begin + i / g.nphi;
+    const long member = grow / rows_per_member;
+    const long row = grow - member * rows_per_member;
     const int l = (int)(i % g.nphi);
     const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
+    const gort_canopy *canopy = canopies + member;
     double vza, sza, saa, raa;
     normalise_angles(g.vza0 + ivza * g.dvza, g.phi0 + l * g.dphi, g.sza0 + isza * g.dsza, 0.0, vza, sza, saa, raa);
     GeomOut o;
@@ -274,16 +279,18 @@ __global__ __launch_bounds__(256) void geometry_grid_kernel(const gort_canopy *_
 // ------------------------------------------------------- wavelength-only table
 
 // Two-stream closed forms that depend on the band only (gortt_brdf.c:348-634 hoisted)
-__global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__restrict__ canopy, int nw,
-                                                            const double *__restrict__ rsoil,
-                                                            const double *__restrict__ rleaf,
-                                                            const double *__restrict__ tleaf,
-                                                            double *__restrict__ L)
+// blockIdx.y = ensemble member: canopy[m], spectra[m][3][nw] (rsoil, rleaf, tleaf) -> L[m][11][nw]
+__global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__restrict__ canopies, int nw,
+                                                            const double *__restrict__ spectra,
+                                                            double *__restrict__ Lall)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw) return;
-    const gort_canopy &c = *canopy;
-    const double rs = rsoil[i], rl = rleaf[i], tl = tleaf[i];
+    const long m = blockIdx.y;
+    const gort_canopy &c = canopies[m];
+    const double *__restrict__ sp = spectra + m * 3 * nw;
+    double *__restrict__ L = Lall + m * L_NSLOT * nw;
+    const double rs = sp[i], rl = sp[nw + i], tl = sp[2 * nw + i];
     const double omega = rl + tl;
     const double gam = sqrt(1 - omega);
     const double Rff = (1.0 - gam) / (1.0 + gam);
@@ -376,18 +383,21 @@ __global__ __launch_bounds__(256) void expand_stream_kernel(const gort_canopy *_
 
 // ------------------------------------------------------------ LUT (grid) path
 
-// sun[isza][5][nw]
-__global__ __launch_bounds__(256) void sun_table_kernel(const gort_canopy *__restrict__ canopy,
-                                                         const double *__restrict__ L, int nw, gort_grid g,
-                                                         int isza_begin, int n_sza, double *__restrict__ sun)
+// sun[q - q_begin][5][nw] with q = member * nsza + isza: the "sun rows" of an ensemble are (member, sun zenith)
+__global__ __launch_bounds__(256) void sun_table_kernel(const gort_canopy *__restrict__ canopies,
+                                                         const double *__restrict__ Lall, int nw, gort_grid g,
+                                                         int q_begin, int n_q, double *__restrict__ sun)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int js = blockIdx.y;
-    if (i >= nw || js >= n_sza) return;
-    const gort_canopy &c = *canopy;
+    if (i >= nw || js >= n_q) return;
+    const int q = q_begin + js;
+    const int member = q / g.nsza, isza = q - member * g.nsza;
+    const gort_canopy &c = canopies[member];
+    const double *__restrict__ L = Lall + (long)member * L_NSLOT * nw;
     // sun-only scalars exactly as geometry_core derives them for "vza phi sza 0"
     double vza, sza, saa, raa;
-    normalise_angles(0.0, 0.0, g.sza0 + (isza_begin + js) * g.dsza, 0.0, vza, sza, saa, raa);
+    normalise_angles(0.0, 0.0, g.sza0 + isza * g.dsza, 0.0, vza, sza, saa, raa);
     double sin_sz, cos_sz;
     sincos(sza, &sin_sz, &cos_sz);
     const Primed sp = prime(c.b / c.r, sin_sz / cos_sz);
@@ -705,12 +715,12 @@ inline int check_launch(const char *what)
 
 // ------------------------------------------------------------------- launchers
 
-int launch_lambda_table(const gort_canopy *canopy_dev, int nw, const double *rsoil_dev, const double *rleaf_dev,
-                        const double *tleaf_dev, double *L_dev, void *stream)
+int launch_lambda_table(const gort_canopy *canopies_dev, int n_members, int nw, const double *spectra_dev,
+                        double *L_dev, void *stream)
 {
-    if (nw <= 0) return GORT_OK;
-    hipLaunchKernelGGL(lambda_table_kernel, dim3((nw + 255) / 256), dim3(256), 0, (hipStream_t)stream, canopy_dev, nw,
-                       rsoil_dev, rleaf_dev, tleaf_dev, L_dev);
+    if (nw <= 0 || n_members <= 0) return GORT_OK;
+    hipLaunchKernelGGL(lambda_table_kernel, dim3((nw + 255) / 256, n_members), dim3(256), 0, (hipStream_t)stream,
+                       canopies_dev, nw, spectra_dev, L_dev);
     return check_launch("lambda_table_kernel");
 }
 
@@ -748,13 +758,14 @@ int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int
     return check_launch("expand_stream_kernel");
 }
 
-int launch_sun_table(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g, int isza_begin,
-                     int isza_end, double *sun_dev, void *stream)
+int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int nw, const gort_grid &g, int q_begin,
+                     int q_end, double *sun_dev, void *stream)
 {
-    const int n = isza_end - isza_begin;
+    const int n = q_end - q_begin;
     if (n <= 0 || nw <= 0) return GORT_OK;
-    hipLaunchKernelGGL(sun_table_kernel, dim3((nw + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, canopy_dev,
-                       L_dev, nw, g, isza_begin, n, sun_dev);
+    if (n > 65535) return fail(GORT_EINVAL, "sun_table: %d (member, sun zenith) rows in one launch (max 65535)", n);
+    hipLaunchKernelGGL(sun_table_kernel, dim3((nw + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, canopies_dev,
+                       L_dev, nw, g, q_begin, n, sun_dev);
     return check_launch("sun_table_kernel");
 }
 

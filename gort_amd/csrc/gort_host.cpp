@@ -195,6 +195,22 @@ const InterfaceTables &interface_tables()
     return t;
 }
 
+}  // namespace
+
+// table access for the device-side spectra kernel (gort_spectra.hip)
+namespace gort {
+const float *prospect_coeff_table() { return gort_prospect_coeffs; }
+const double *price_eof_table() { return gort_price_eofs; }
+void interface_transmissivity_tables(const double **t12, const double **talf)
+{
+    const InterfaceTables &t = interface_tables();
+    *t12 = t.t12;
+    *talf = t.talf;
+}
+}  // namespace gort
+
+namespace {
+
 // tau(k) = (1-k) e^-k + k^2 E1(k); E1 by the NAG S13AAF Chebyshev fits (prospect_DB.f90:100-141)
 double plate_transmission(double k)
 {

@@ -49,8 +49,16 @@ static_assert(C_PAD1 + 1 == GORT_COEF_STRIDE, "record size");
 // ---- launchers implemented in the .hip files; all asynchronous on `stream` ----
 // (void* stream is a hipStream_t)
 int launch_gap_probabilities(gort_canopy *members_dev, int n_members, void *stream);
-int launch_lambda_table(const gort_canopy *canopy_dev, int nw, const double *rsoil_dev,
-                        const double *rleaf_dev, const double *tleaf_dev, double *L_dev, void *stream);
+// member-batched: canopies[n], spectra[n][3][nw] (rsoil, rleaf, tleaf) -> L[n][L_NSLOT][nw]
+int launch_lambda_table(const gort_canopy *canopies_dev, int n_members, int nw, const double *spectra_dev,
+                        double *L_dev, void *stream);
+// leaf/soil spectra of ensemble members on the device (gort_spectra.hip); tables from gort_host.cpp
+int launch_member_spectra(const gort_leaf_soil *leaf_dev, int n_members, int nw, const double *wl_dev,
+                          const float *coef_dev, const double *t12_dev, const double *talf_dev,
+                          const double *eof_dev, double *spectra_dev, void *stream);
+const float *prospect_coeff_table();      // [7][2101]
+const double *price_eof_table();          // [4][421]
+void interface_transmissivity_tables(const double **t12, const double **talf);   // [2101] each
 int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA,
                            double *coef_dev, double *K_dev, void *stream);
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
@@ -58,8 +66,9 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
                          double *coef_dev, bool compact, void *stream);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
                          long nA, double *rsurf_dev, double *scomp_dev, void *stream);
-int launch_sun_table(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g,
-                     int isza_begin, int isza_end, double *sun_dev, void *stream);
+// sun rows q = member * nsza + isza, q in [q_begin, q_end): sun_dev[q - q_begin][5][nw]
+int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int nw, const gort_grid &g,
+                     int q_begin, int q_end, double *sun_dev, void *stream);
 // coef_dev for launch_expand_grid: compact records, with ONE readable pad record in front of coef_dev
 // and expand_grid_tail_pad_records() readable records behind the last angle
 long expand_grid_tail_pad_records(int nw, long n_total);

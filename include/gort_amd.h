@@ -138,6 +138,24 @@ int  gort_engine_set_spectra(gort_engine *e, int nw, const double *rsoil,
                              const double *rleaf, const double *tleaf);
 int  gort_engine_nw(const gort_engine *e);
 
+/* Ensembles (BASELINE.json config 5: N canopy/leaf parameter members = N independent forward runs of
+ * the reference, README.md:8-9).  The engine then holds n_members canopies with their own spectra; the
+ * single-canopy calls above and the stream/energy entry points address member 0.
+ *   compute_gaps != 0: run the Pn/EPgap/KOpen kernel for all members on the device copy (one workgroup
+ *                      per member) instead of expecting the tables in `members`.
+ *   gort_engine_set_members:      spectra[n_members][3][nw] = rsoil, rleaf, tleaf per member (host)
+ *   gort_engine_set_members_leaf: spectra computed ON THE DEVICE from each member's PROSPECT-D / Price
+ *                                 parameters, one thread per (member, band); replaces n_members runs of
+ *                                 gortt_price_soil + gortt_prospect_interface (gortt.c:224-227)
+ *   gort_engine_get_member:       read a member back (any pointer may be NULL) */
+int  gort_engine_n_members(const gort_engine *e);
+int  gort_engine_set_members(gort_engine *e, const gort_canopy *members, int n_members, int compute_gaps,
+                             int nw, const double *spectra);
+int  gort_engine_set_members_leaf(gort_engine *e, const gort_canopy *members, const gort_leaf_soil *leaf,
+                                  int n_members, int compute_gaps, const double *wl_nm, int nw);
+int  gort_engine_get_member(gort_engine *e, int member, gort_canopy *canopy, double *rsoil, double *rleaf,
+                            double *tleaf);
+
 /* BRDF for a stream of angle lines.  Replaces, per line, the angle normalisation of
  * main() (gortt.c:240-291), gortt_set_zenith_dependant_probabilities (gortt.c:872-915)
  * and gortt_rsurf (gortt.c:385-578).
@@ -163,6 +181,10 @@ typedef struct gort_grid {
 } gort_grid;
 int  gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, long row_end,
                          double *lut_dev);
+/* Same grid for ensemble members [member_begin, member_end): lut_dev[member][nsza][nvza][nphi][nw],
+ * one launch sequence for all of them (needs 128 <= nw <= 2304). */
+int  gort_rsurf_members_grid_dev(gort_engine *e, const gort_grid *g, int member_begin, int member_end,
+                                 double *lut_dev);
 /* kernel-only timing hook for bench.py: average duration (ms) of the LUT expansion
  * kernel over the launches since the last call, measured with HIP events on the
  * engine's stream; returns <0 if none. */

@@ -364,3 +364,84 @@ def test_c4_full_spectral_albedo_table(eng, golden):
     # energy conservation: albedo + favegt + fasoil = 1 (gortt_albedo.c:51-52)
     tot = e[:90].sum(axis=2)
     assert np.abs(tot - 1.0).max() < 1e-12
+
+
+# ------------------------------------------------------------ ensembles (C5)
+def _members(golden, n_extra=24):
+    g = golden("c5_members.npz")
+    params = [tuple(g["m%d/params" % i]) for i in range(8)]
+    rng = np.random.default_rng(2024)
+    for _ in range(n_extra):
+        params.append((float(np.float32(rng.uniform(1, 3))), float(np.float32(rng.uniform(1, 3.5))),
+                       float(np.float32(rng.uniform(0.2, 0.8))), float(np.float32(rng.uniform(0.5, 6))),
+                       rng.uniform(10, 60), rng.uniform(0.005, 0.03), rng.uniform(0.002, 0.015),
+                       rng.uniform(1, 2.5), rng.uniform(0.05, 0.4)))
+    canopies = [api.make_canopy(newstyle=(p[0], p[1], p[2]), lai=p[3]) for p in params]
+    leaf = [api.leaf_soil(prospect=dict(N=p[7], Cab=p[4], Cw=p[5], Cm=p[6]), rsl=(p[8], 0.1, 0.03726, -0.002426))
+            for p in params]
+    return g, canopies, leaf
+
+
+def test_ensemble_members_one_launch(golden):
+    """BASELINE config 5 in miniature: 32 members, gap probabilities + PROSPECT-D/Price + LUT all on the
+    device in one launch sequence, against (a) the reference's goldens for the first 8 members, (b) the
+    same members run one by one through the single-canopy path, (c) host spectra."""
+    import torch
+    g, canopies, leaf = _members(golden)
+    n, wl = len(canopies), g["wl"]
+    grid = _grid((30.0, 1.0, 1), (0.0, 45.0, 3), (0.0, 90.0, 4))        # sza 30; vza 0,45,90; phi 0,90,180,270
+    e = api.Engine()
+    e.set_members_leaf(canopies, leaf, wl, compute_gaps=True)
+    lut = torch.empty((n, 3, 4, wl.size), dtype=torch.float64, device="cuda")
+    e.rsurf_members_grid_dev(grid, 0, n, lut)
+    e.synchronize()
+    got = lut.cpu().numpy()
+    # (a) golden nodes: angles list of the fixture is vza in (0,45,89,90) x phi in (0,90,180,300), sza 30
+    ga = g["angles"]
+    for i in range(8):
+        for a, (vz, ph) in enumerate(ga[:, :2]):
+            if vz in (0.0, 45.0, 90.0) and ph in (0.0, 90.0, 180.0):
+                assert err(got[i, int(vz // 45), int(ph // 90)], g["m%d/rsurf" % i][a]) <= REGRESSION, (i, vz, ph)
+    # (b)/(c) every member against the single-canopy path with host-side spectra
+    single = api.Engine()
+    one = torch.empty((3 * 4, wl.size), dtype=torch.float64, device="cuda")
+    for i in range(n):
+        c_dev, rs_d, rl_d, tl_d = e.get_member(i)
+        c_ref = api.gap_probabilities(canopies[i])
+        assert np.array_equal(np.array(c_dev.p_n0), np.array(c_ref.p_n0))
+        assert np.array_equal(np.array(c_dev.epgap), np.array(c_ref.epgap))
+        assert c_dev.k_open == c_ref.k_open and c_dev.k_openep == c_ref.k_openep
+        rs, rl, tl = api.spectra(wl, leaf[i])
+        assert err(rs_d, rs) <= 1e-13 and err(rl_d, rl) <= REGRESSION and err(tl_d, tl) <= REGRESSION
+        single.set_canopy(c_ref); single.set_spectra(rs, rl, tl)
+        single.rsurf_grid_dev(grid, 0, 3, one); single.synchronize()
+        assert err(got[i].reshape(12, -1), one.cpu().numpy()) <= REGRESSION
+    # host-spectra form of the same ensemble is bitwise the single-canopy result
+    sp = np.stack([np.stack(api.spectra(wl, l)) for l in leaf])
+    e.set_members([api.gap_probabilities(c) for c in canopies], sp)
+    lut2 = torch.empty_like(lut)
+    e.rsurf_members_grid_dev(grid, 0, n, lut2); e.synchronize()
+    for i in (0, 7, n - 1):
+        single.set_canopy(canopies[i]); single.set_spectra(*sp[i])
+        single.rsurf_grid_dev(grid, 0, 3, one); single.synchronize()
+        assert torch.equal(lut2[i].reshape(12, -1).view(torch.int64), one.view(torch.int64))
+    # a member sub-range writes the same values at the sub-range's own base
+    part = torch.empty((5, 3, 4, wl.size), dtype=torch.float64, device="cuda")
+    e.rsurf_members_grid_dev(grid, 11, 16, part); e.synchronize()
+    assert torch.equal(part.view(torch.int64), lut2[11:16].view(torch.int64))
+    e.close(); single.close()
+
+
+def test_ensemble_argument_errors():
+    e = api.Engine()
+    c = gpu_canopy(lai=4.0)
+    with pytest.raises(api.GortError) as ex:
+        e.set_members_leaf([c], [api.leaf_soil()], [399.0, 500.0])
+    assert ex.value.code == api.ERANGE
+    e.set_members_leaf([c, c], [api.leaf_soil(), api.leaf_soil()], np.linspace(400, 2500, 64))
+    import torch
+    with pytest.raises(api.GortError):       # LUT path needs >= 128 bands for ensembles
+        e.rsurf_members_grid_dev(api.hemisphere_grid(2, 2, 2), 0, 2, torch.empty(2 * 8 * 64, dtype=torch.float64, device="cuda"))
+    with pytest.raises(api.GortError):       # single-canopy spectra call on a 2-member engine
+        e.set_spectra(np.ones(4), np.ones(4) * .1, np.ones(4) * .1)
+    e.close()
