@@ -353,6 +353,42 @@ extern "C" void gort_gauleg(double x1, double x2, double *x, double *w, int n)
     }
 }
 
+// ------------------------------------------------------------------ "%f" formatter
+
+// printf("%f") is where the text boundary spends its time (hundreds of MB of digits per
+// second of GPU work).  For |v| < 9e12 the value times 1e6 is formed exactly as a double
+// plus an FMA error term, rounded to an integer with ties to even exactly as glibc rounds
+// the decimal expansion, and the digits are emitted by hand; anything else goes to snprintf.
+extern "C" int gort_format_f6(double v, char *dst)
+{
+    if (v != v) { std::memcpy(dst, "-nan", 4); return 4; }
+    const double av = std::fabs(v);
+    if (!(av < 4.0e9)) return std::snprintf(dst, 352, "%f", v);
+    // exact: av * 1e6 = p + e with p < 2^52, so ulp(p) <= 0.5 and |e| <= ulp(p)/2
+    const double p = av * 1.0e6;
+    const double e = std::fma(av, 1.0e6, -p);
+    double n = std::nearbyint(p);                 // default rounding mode: ties to even
+    // p - n is exact and a multiple of ulp(p): unless it is exactly +-0.5 the error term cannot move
+    // the value across a rounding boundary; at +-0.5 the sign of e decides, e == 0 is a true tie
+    const double a = p - n;
+    if (a == 0.5) { if (e > 0.0) n += 1.0; }
+    else if (a == -0.5) { if (e < 0.0) n -= 1.0; }
+    unsigned long long q = (unsigned long long)n;
+    const unsigned long long ip = q / 1000000ULL;
+    unsigned frac = (unsigned)(q % 1000000ULL);
+    char *o = dst;
+    if (std::signbit(v)) *o++ = '-';
+    char tmp[24];
+    int k = 0;
+    unsigned long long t = ip;
+    do { tmp[k++] = (char)('0' + t % 10); t /= 10; } while (t);
+    while (k) *o++ = tmp[--k];
+    *o++ = '.';
+    for (int i = 5; i >= 0; --i) { o[i] = (char)('0' + frac % 10); frac /= 10; }
+    o += 6;
+    return (int)(o - dst);
+}
+
 // ------------------------------------------------------------- probability LUT text
 
 extern "C" long gort_lut_format(const gort_canopy *c, char *buf, size_t cap)

@@ -182,15 +182,24 @@ void parse_args(int argc, char **argv, Options &o)
 
 bool read_line(FILE *fp, std::string &line)
 {
-    line.clear();
-    int ch;
-    bool any = false;
-    while ((ch = std::fgetc(fp)) != EOF) {
-        any = true;
-        line.push_back((char)ch);
-        if (ch == '\n') break;
+    static char *buf = nullptr;
+    static size_t cap = 0;
+    const ssize_t n = getline(&buf, &cap, fp);
+    if (n <= 0) { line.clear(); return false; }
+    line.assign(buf, (size_t)n);
+    return true;
+}
+
+// "%lf %lf %lf %lf" of the reference's sscanf (gortt.c:234): four numbers, anything after them ignored
+bool parse_angles(const char *s, double v[4])
+{
+    for (int q = 0; q < 4; ++q) {
+        char *end;
+        v[q] = std::strtod(s, &end);
+        if (end == s) return false;
+        s = end;
     }
-    return any;
+    return true;
 }
 
 // whitespace-separated tokens, as get_first_string_token hands them out (gortt.c:1237-1283)
@@ -210,17 +219,18 @@ std::vector<std::string> tokens(const std::string &line)
 
 struct Out {
     std::string buf;
-    void num(double v)
+    void num(double v)                       // computed value: "%f " with NaN as -nan (x86 default NaN)
     {
         char tmp[400];
-        int n = std::isnan(v) ? std::snprintf(tmp, sizeof tmp, "-nan ")    // x86 default NaN prints as -nan
-                              : std::snprintf(tmp, sizeof tmp, "%f ", v);
+        int n = gort_format_f6(v, tmp);
+        tmp[n++] = ' ';
         buf.append(tmp, (size_t)n);
     }
-    void raw(double v)
+    void raw(double v)                       // echoed input: plain "%f "
     {
         char tmp[400];
-        int n = std::snprintf(tmp, sizeof tmp, "%f ", v);
+        int n = std::isnan(v) ? std::snprintf(tmp, sizeof tmp, "%f", v) : gort_format_f6(v, tmp);
+        tmp[n++] = ' ';
         buf.append(tmp, (size_t)n);
     }
     void flush()
@@ -300,7 +310,7 @@ int main(int argc, char **argv)
         while ((long)(ang.size() / 4) < CHUNK) {
             if (!read_line(stdin, line)) { eof = true; break; }
             double v[4];
-            if (std::sscanf(line.c_str(), "%lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3]) != 4) { bad_line = true; break; }
+            if (!parse_angles(line.c_str(), v)) { bad_line = true; break; }
             ang.insert(ang.end(), v, v + 4);
         }
         const long n = (long)(ang.size() / 4);

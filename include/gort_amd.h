@@ -101,6 +101,11 @@ int  gort_spectra(const gort_leaf_soil *s, const double *wl_nm, int nw,
 /* Gauss-Legendre nodes as the reference computes them: replaces gauleg, gortt_albedo.c:141-199 */
 void gort_gauleg(double x1, double x2, double *x, double *w, int n);
 
+/* Fast formatter of the output rows: writes exactly the bytes of printf("%f", v) (correctly rounded,
+ * ties to even, glibc style), except that every NaN is written as "-nan" - which is what the
+ * reference prints for its NaNs on x86 (gortt.c:310-324).  dst needs 352 bytes; returns the length. */
+int  gort_format_f6(double v, char *dst);
+
 /* probability LUT, text format of `gortt -W` / `gortt -P file`: gortt.c:123-146.
  * gort_lut_format writes into buf (needs <= 16 KiB), returns bytes written or <0. */
 long gort_lut_format(const gort_canopy *c, char *buf, size_t cap);

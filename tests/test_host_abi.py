@@ -139,3 +139,30 @@ def test_device_entry_points_fail_loudly_without_gpu():
     assert e.value.code == api.ENODEVICE
     with pytest.raises(api.GortError):
         api.gap_probabilities(api.make_canopy(lai=4.0))
+
+
+def test_format_f6_equals_printf():
+    """gort_format_f6 writes the bytes of printf("%f") (Python's '%f' is the same correctly rounded,
+    ties-to-even conversion as glibc's) for every magnitude the rows contain, plus the edge cases."""
+    import ctypes as C
+    L = api.lib()
+    L.gort_format_f6.argtypes = [C.c_double, C.c_char_p]
+    buf = C.create_string_buffer(400)
+
+    def f6(x):
+        n = L.gort_format_f6(x, buf)
+        return buf.raw[:n].decode()
+
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([
+        rng.uniform(0, 1, 200000), rng.uniform(-90, 360, 50000), 10.0 ** rng.uniform(-12, 9.5, 100000),
+        -(10.0 ** rng.uniform(-12, 9.5, 20000)), rng.integers(0, 2 ** 31, 20000) / 128.0,     # exact ties .5e-6
+        (rng.integers(0, 10 ** 6, 50000) + 0.5) * 1e-6,                                      # decimal near-ties
+        np.array([0.0, -0.0, 1e-7, 5e-7, 4.999999999999999e-7, 5.000000000000001e-7, -1e-9, 0.0078125, 0.0234375,
+                  1.0, 0.9999995, 0.99999949999999, 123456.7890125, 3.9999999e9, 4.0e9, 1e10, 1e300, -1e300,
+                  2.5e-6, 3.5e-6, 1.5e-6, 0.5e-6, np.inf, -np.inf]),
+    ])
+    for x in vals:
+        want = "%f" % x
+        assert f6(float(x)) == want, (repr(float(x)), f6(float(x)), want)
+    assert f6(float("nan")) == "-nan" and f6(-float("nan")) == "-nan"
