@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="multi-rank dry run on ONE GPU: every rank uses cuda:0, process group gloo (not a measurement)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed steps, all-gather the full LUT on every rank (RCCL) and report allgather_ms")
     ap.add_argument("--traffic-gb", type=float, default=None,
@@ -110,10 +112,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local)
+    # --rehearse: all ranks share GPU 0 and talk over gloo (a 1-GPU box cannot run RCCL between two ranks);
+    # exercises sharding, slab sizing and the max-over-ranks timing exactly as the real multi-GPU run does.
+    dev_index = 0 if args.rehearse else local
+    torch.cuda.set_device(dev_index)
+    red_dev = "cpu" if args.rehearse else "cuda"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     def barrier():
         if world > 1:
@@ -154,10 +163,10 @@ def main():
     kernel_ms = eng.last_expand_ms()          # mean duration of the LUT expansion kernel, HIP events on its stream
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+        k = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
 

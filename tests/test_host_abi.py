@@ -114,7 +114,6 @@ def test_lut_text_roundtrip(golden, tmp_path):
     cases = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "cli_cases.json")))}
     ref_text = cases["lut_default"]["stdout"]
     c = api.make_canopy(lai=4.0)
-    api.lut_read_text = None
     p = tmp_path / "lut.dat"
     p.write_text(ref_text)
     api.lut_read(str(p), c)
