@@ -580,10 +580,17 @@ template <int DEPTH, bool NT>
 __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restrict__ sun, int isza_base,
                                                            const double *__restrict__ coef, int nw,
                                                            int angles_per_sza, long angle0, long n_total, int shift,
-                                                           long stride_chunks, double *__restrict__ lut)
+                                                           long stride_chunks, double *__restrict__ lut, int xcd_contig)
 {
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long wave = (long)blockIdx.x * 4 + wave_in_block;                   // scalar
+    long block = blockIdx.x;
+    if (xcd_contig) {
+        // blocks b, b+8, b+16, ... share an XCD (observed dispatch, speed only): give each XCD one contiguous
+        // range of chunks so that an angle's records are fetched into ONE L2 instead of eight
+        const long nb = gridDim.x, x = block & 7, base = nb >> 3, rem = nb & 7;
+        block = x * base + (x < rem ? x : rem) + (block >> 3);
+    }
+    const long wave = block * 4 + wave_in_block;                              // scalar
     if (wave >= stride_chunks) return;
     const int lane = threadIdx.x & 63;
     const long step = stride_chunks * CHUNK;       // elements per step; a multiple of nw
@@ -776,14 +783,17 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 //   GORT_EXPAND_WAVES    target number of waves   (flat; rounded to a band-preserving stride)
 struct ExpandTuning {
     bool flat = true, nt = true;
+    bool xcd_contig = true;   // interleaved A/B on one box: 8.07-8.14 ms with, 9.38-9.48 ms without (profiles/r01/tune_xcd.log)
     int depth = 2;
-    long waves = 16384;     // measured on MI355X: 4202 -> 9.46 ms, 8404 -> 9.24, 16808 -> 8.33, 33616 -> 8.29 (50 GB slab)
+    long waves = 32768;     // 50 GB slab, XCD-contiguous, interleaved A/B (profiles/r01/tune_flat_kernel.log):
+                            // 8404 -> 8.9 ms, 16808 -> 8.5-9.1 (noisy), 25212/33616 -> 7.95-7.97, 67232 -> 9.5
     ExpandTuning()
     {
         if (const char *v = getenv("GORT_EXPAND_VARIANT")) flat = strcmp(v, "row") != 0;
         if (const char *v = getenv("GORT_EXPAND_NT")) nt = atoi(v) != 0;
         if (const char *v = getenv("GORT_EXPAND_DEPTH")) depth = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_WAVES")) waves = atol(v);
+        if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_contig = atoi(v) != 0;
         if (depth != 1 && depth != 2 && depth != 4) depth = 2;
         if (waves < 64) waves = 64;
     }
@@ -873,7 +883,7 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
     const long angle0 = row_begin * nphi;
 #define GORT_FLAT(D, N)                                                                                           \
     hipLaunchKernelGGL((expand_flat_kernel<D, N>), grid, dim3(256), 0, s, sun_dev, isza_base, coef_dev, nw,      \
-                       angles_per_sza, angle0, n_total, shift, stride, lut_dev)
+                       angles_per_sza, angle0, n_total, shift, stride, lut_dev, tune.xcd_contig ? 1 : 0)
     if (tune.nt) {
         if (tune.depth == 1) GORT_FLAT(1, true); else if (tune.depth == 2) GORT_FLAT(2, true); else GORT_FLAT(4, true);
     } else {
