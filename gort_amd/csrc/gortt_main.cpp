@@ -14,6 +14,7 @@
 //     beyond 32);
 //   * -soil_spectra, which in the reference only dumps a table and exits with failure,
 //     is rejected with a message.
+// Extensions (double-dash, unknown options to the reference): --binary-in, --binary-out, --lut-hex.
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -108,6 +109,11 @@ struct Options {
     gort_canopy canopy;
     gort_leaf_soil leaf;
     bool prnspec = false, prnprop = false, energy = false, write_lut = false, read_lut = false;
+    // extensions (double dash: the reference rejects them as unknown options, so no valid reference
+    // command line changes meaning)
+    bool binary_in = false;    // --binary-in : after the text header, angle lines are records of 4 raw doubles
+    bool binary_out = false;   // --binary-out: rows are raw doubles in print order (angles, then per band ..., K, energy)
+    bool lut_hex = false;      // --lut-hex   : -W writes C99 hex floats (exact; -P of either program reads them)
     std::string lut_file;
 };
 
@@ -133,7 +139,10 @@ void parse_args(int argc, char **argv, Options &o)
             }
             return argv[++i];
         };
-        if (ci(a, "-favd", 5)) o.canopy.favd = atof(val());
+        if (!std::strcmp(a, "--binary-in")) o.binary_in = true;
+        else if (!std::strcmp(a, "--binary-out")) o.binary_out = true;
+        else if (!std::strcmp(a, "--lut-hex")) o.lut_hex = true;
+        else if (ci(a, "-favd", 5)) o.canopy.favd = atof(val());
         else if (ci(a, "-h1", 3)) o.canopy.h1 = atof(val());
         else if (ci(a, "-h2", 3)) o.canopy.h2 = atof(val());
         else if (ci(a, "-lambda", 7)) o.canopy.lambda = atof(val());
@@ -260,6 +269,13 @@ int main(int argc, char **argv)
     if (!o.read_lut) check(gort_gap_probabilities(&o.canopy, 1));
     // 2) -W: write them and stop, before stdin is touched (gortt.c:123-128)
     if (o.write_lut) {
+        if (o.lut_hex) {
+            // same rows, exact: "%a" keeps every bit, and fscanf("%lf") of the reference parses it, so the
+            // horizon values that "%0.40f" flushes to zero (p_n0 at 89 deg ~ 4e-65) survive the round trip
+            for (int j = 0; j < 90; ++j) std::printf("%d %a %a\n", j, o.canopy.p_n0[j], o.canopy.epgap[j]);
+            std::printf("-1 %a %a\n", o.canopy.k_open, o.canopy.k_openep);
+            return EXIT_SUCCESS;
+        }
         std::vector<char> text(1 << 15);
         long n = gort_lut_format(&o.canopy, text.data(), text.size());
         if (n < 0) check((int)n);
@@ -307,11 +323,19 @@ int main(int argc, char **argv)
     Out out;
     while (!eof && !bad_line) {
         ang.clear();
-        while ((long)(ang.size() / 4) < CHUNK) {
-            if (!read_line(stdin, line)) { eof = true; break; }
-            double v[4];
-            if (!parse_angles(line.c_str(), v)) { bad_line = true; break; }
-            ang.insert(ang.end(), v, v + 4);
+        if (o.binary_in) {
+            ang.resize((size_t)CHUNK * 4);
+            const size_t got = std::fread(ang.data(), sizeof(double), (size_t)CHUNK * 4, stdin);
+            if (got % 4 != 0) bad_line = true;           // truncated record
+            ang.resize(got - got % 4);
+            if (got < (size_t)CHUNK * 4) eof = true;
+        } else {
+            while ((long)(ang.size() / 4) < CHUNK) {
+                if (!read_line(stdin, line)) { eof = true; break; }
+                double v[4];
+                if (!parse_angles(line.c_str(), v)) { bad_line = true; break; }
+                ang.insert(ang.end(), v, v + 4);
+            }
         }
         const long n = (long)(ang.size() / 4);
         if (n > 0) {
@@ -324,7 +348,21 @@ int main(int argc, char **argv)
                 energy.resize((size_t)n * nw * 3);
                 check(gort_energy_stream(eng, ang.data(), n, energy.data()));
             }
-            for (long a = 0; a < n; ++a) {
+            for (long a = 0; o.binary_out && a < n; ++a) {
+                // same field order as the text row, raw little-endian doubles
+                std::fwrite(&ang[4 * a], sizeof(double), 4, stdout);
+                if (!o.prnspec) {
+                    std::fwrite(&rsurf[(size_t)a * nw], sizeof(double), (size_t)nw, stdout);
+                } else {
+                    for (int i = 0; i < nw; ++i) {
+                        std::fwrite(&rsurf[(size_t)a * nw + i], sizeof(double), 1, stdout);
+                        std::fwrite(&scomp[((size_t)a * nw + i) * 4], sizeof(double), 4, stdout);
+                    }
+                }
+                if (o.prnprop) std::fwrite(&K[4 * a], sizeof(double), 4, stdout);
+                if (o.energy) std::fwrite(&energy[(size_t)a * nw * 3], sizeof(double), (size_t)nw * 3, stdout);
+            }
+            for (long a = 0; !o.binary_out && a < n; ++a) {
                 for (int q = 0; q < 4; ++q) out.raw(ang[4 * a + q]);
                 for (int i = 0; i < nw; ++i) {
                     out.num(rsurf[(size_t)a * nw + i]);

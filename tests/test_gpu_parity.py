@@ -256,6 +256,64 @@ def test_cli_text_identical_to_reference(case, tmp_path):
     assert errtxt == case["stderr"]
 
 
+def _run_gortt(args, stdin_bytes):
+    run = subprocess.run([api.GORTT_BIN] + args, input=stdin_bytes, capture_output=True, timeout=300)
+    assert run.returncode == 0, run.stderr.decode("latin-1")
+    return run.stdout
+
+
+def test_cli_binary_stream_extension():
+    """--binary-in / --binary-out: same rows as the text mode, as raw doubles."""
+    rng = np.random.default_rng(21)
+    n, wl = 300, [450.0, 800.5, 1650.0]
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), rng.uniform(0, 360, n)], 1)
+    head = ("%d %d %s\n" % (n, len(wl), " ".join(repr(w) for w in wl))).encode()
+    text_in = head + "".join("%r %r %r %r\n" % tuple(map(float, r)) for r in ang).encode()
+    flags = ["-LAI", "4.0", "-prnspec", "-prnprop", "-energy"]
+    text_out = _run_gortt(flags, text_in).decode()
+    bin_out = _run_gortt(flags + ["--binary-in", "--binary-out"], head + ang.astype("<f8").tobytes())
+    assert bin_out.startswith(head)
+    rows = np.frombuffer(bin_out[len(head):], dtype="<f8").reshape(n, -1)
+    per_row = 4 + len(wl) * 5 + 4 + len(wl) * 3
+    assert rows.shape[1] == per_row
+    assert np.array_equal(rows[:, :4], ang)
+    # the text rows are the same numbers rounded to 6 decimals
+    for a, ln in enumerate(text_out.strip("\n").split("\n")[1:]):
+        v = [float(t) for t in ln.replace("{", " ").replace("}", " ").replace("[", " ").replace("]", " ").split()]
+        assert len(v) == per_row
+        assert np.allclose(v, rows[a], rtol=0, atol=5.0001e-7, equal_nan=True), a
+    # and they are the oracle's numbers
+    c = O.make_canopy(lai=4.0)
+    rs, rl, tl = O.spectra(wl)
+    ro, sco, Ko = O.rsurf_stream(c, ang, rs, rl, tl, want_scomp=True)
+    eo = O.energy_stream(c, ang, rs, rl, tl)
+    got_r = rows[:, 4:4 + 5 * len(wl)].reshape(n, len(wl), 5)
+    assert err(got_r[:, :, 0], ro) <= REGRESSION
+    assert err(got_r[:, :, 1:].reshape(n, -1), sco) <= REGRESSION
+    assert err_K(rows[:, 4 + 5 * len(wl):8 + 5 * len(wl)], Ko) <= REGRESSION
+    assert err(rows[:, 8 + 5 * len(wl):].reshape(n, len(wl), 3), eo) <= REGRESSION
+
+
+def test_cli_hex_lut_extension_is_exact_and_reference_readable(tmp_path):
+    """--lut-hex: `-W` with C99 hex floats keeps every bit, so the -P path no longer turns
+    zeniths >= 89 deg into NaN (the '%0.40f' file flushes p_n0(89 deg) ~ 4e-65 to 0); the REAL reference's
+    fscanf("%lf") reads the same file."""
+    lut = tmp_path / "lut_hex.dat"
+    lut.write_bytes(_run_gortt(["-LAI", "4.0", "-W", "--lut-hex"], b""))
+    stream = b"3 2 650 865\n89 0 30 0\n30 0 89 180\n45 10 60 200\n"
+    direct = _run_gortt(["-LAI", "4.0", "-prnprop"], stream)
+    via_hex = _run_gortt(["-LAI", "4.0", "-prnprop", "-P", str(lut)], stream)
+    assert via_hex == direct and b"nan" not in direct
+    plain = tmp_path / "lut.dat"
+    plain.write_bytes(_run_gortt(["-LAI", "4.0", "-W"], b""))
+    via_plain = _run_gortt(["-LAI", "4.0", "-prnprop", "-P", str(plain)], stream)
+    assert b"-nan" in via_plain                       # the reference's own limitation, reproduced
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "gortt")
+    if os.path.exists(ref):
+        r = subprocess.run([ref, "-LAI", "4.0", "-prnprop", "-P", str(lut)], input=stream, capture_output=True, timeout=120)
+        assert r.returncode == 0 and r.stdout == direct
+
+
 # ------------------------------------------------- BASELINE.json full sizes
 def _full_grid():
     return api.hemisphere_grid()
