@@ -35,10 +35,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROA
 BYTES_PER_SAMPLE = 8.0     # one fp64 value written per sample (grid mode)
 
 
-def cpu_baseline(wl, budget_s=20.0):
+def cpu_baseline(wl, budget_s=20.0, force_port=False):
     """Reference `gortt` (oracle/_ref, built from /root/reference in the build container) timed on this
     box's host CPU, one thread (the program is single-threaded); falls back to the oracle port."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "gortt")
+    ref = os.path.join(ROOT, "oracle", "_ref", "gortt") if not force_port else "/nonexistent"
     cores = 1
     try:
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -234,6 +234,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if out["cpu_baseline"]["kind"] == "reference":
+                # additionally: our own hoisted scalar-C restatement (no text I/O), the strongest 1-core CPU number we have
+                out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:

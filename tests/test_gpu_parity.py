@@ -176,6 +176,22 @@ def test_stream_edge_cases(eng):
     ro, _, Ko = O.rsurf_stream(oracle_like(c), ang, rs, rl, tl)
     assert err(r, ro) <= REGRESSION and err_K(K, Ko) <= REGRESSION
     assert np.isnan(r[1:]).all()
+    # degenerate spectra: omega = 0 (0/0 in the phase-function asymmetry -> NaN in the reference), omega = 1
+    # (gamma = 0), black and white soil; absurd azimuths (the fmod fold); same values / NaN pattern as the oracle
+    c = gpu_canopy(lai=3.0)
+    eng.set_canopy(c)
+    ang = np.array([[25., 40., 35., 170.], [0., 0., 0., 0.], [60., 1.0e6 + 10., 20., -7.0e5], [88., 0., 88., 180.]])
+    for leaf, soil in ((0.0, 0.2), (1.0, 0.2), (0.5, 0.0), (0.5, 1.0), (1.0, 1.0)):
+        rs, rl, tl = api.spectra([500.0, 1000.0], api.leaf_soil(alb_leaf=leaf, alb_soil=soil))
+        eng.set_spectra(rs, rl, tl)
+        r, sc, K = eng.rsurf_stream(ang, want_scomp=True)
+        ro, sco, Ko = O.rsurf_stream(oracle_like(c), ang, rs, rl, tl, want_scomp=True)
+        # the azimuth fold changes raa by rounding only: 1e-7 is ample for the 1e6-degree line
+        assert relerr(r, ro, floor=FLOOR) <= 1e-7 and relerr(sc.reshape(sco.shape), sco, floor=FLOOR) <= 1e-7, (leaf, soil)
+        assert err(r[[0, 1, 3]], ro[[0, 1, 3]]) <= REGRESSION, (leaf, soil)
+        e = eng.energy_stream(ang[:2])
+        eo = O.energy_stream(oracle_like(c), ang[:2], rs, rl, tl)
+        assert relerr(e, eo, floor=FLOOR) <= REGRESSION, (leaf, soil)
 
 
 # ----------------------------------------------------------------- LUT (grid)
