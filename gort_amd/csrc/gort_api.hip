@@ -393,6 +393,8 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
 static int check_grid(const gort_grid *g, const char *who)
 {
     if (!g || g->nsza <= 0 || g->nvza <= 0 || g->nphi <= 0) return fail(GORT_EINVAL, "%s: bad grid", who);
+    // the kernels track (view zenith, azimuth) nodes per sun row in 32-bit
+    if ((long)g->nvza * g->nphi >= (1L << 30)) return fail(GORT_EINVAL, "%s: nvza*nphi too large", who);
     return GORT_OK;
 }
 

@@ -316,34 +316,49 @@ __global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__
 }
 
 struct SunTerms { double C0, B, Z, G, T; };
+struct BandTerms { double gam, omega, Rff, Tff, tff, pff, rs, mgk, Zf, Tf, B; };
 
-// the five (sun zenith, band) numbers
+__device__ inline BandTerms load_band(const double *__restrict__ L, int nw, int i)
+{
+    BandTerms t;
+    t.gam = L[L_GAMMA * nw + i];  t.omega = L[L_OMEGA * nw + i];
+    t.Rff = L[L_RFF * nw + i];    t.Tff = L[L_TFF * nw + i];
+    t.tff = L[L_tFF * nw + i];    t.pff = L[L_PFF * nw + i];
+    t.rs = L[L_RS * nw + i];      t.mgk = L[L_MGK * nw + i];
+    t.Zf = L[L_ZF * nw + i];      t.Tf = L[L_TF * nw + i];
+    t.B = L[L_B * nw + i];
+    return t;
+}
+
+// the five (sun zenith, band) numbers.  The two quotients of the reference, 1/(1+2 mu gamma) and
+// 1/(1-(2 gamma mu)^2), share ONE fp64 division: 1-(g2)^2 = (1+g2)(1-g2).
+__device__ inline SunTerms sun_terms(const BandTerms &t, const SunScalars &s, double ko, double kep)
+{
+    const double mu = s.mu, fd = s.fd;
+    const double g2 = 2. * t.gam * mu;
+    const double inv = 1.0 / ((1.0 + g2) * (1.0 - g2));
+    const double Rdf = (1.0 - t.gam) * ((1.0 - g2) * inv);                      // (1-gamma)/(1+2 mu gamma), gortt_brdf.c:552
+    const double Tdf = (t.omega / 2.0) * ((1. + 2. * mu) * inv) * (t.Tff - s.t0);   // :467-471
+    const double X = s.t0 * Rdf + Tdf * t.Rff;
+    const double tdf = Tdf - t.pff * X;                                         // :423-424
+    const double pdf = Rdf - t.tff * X;                                         // :628-630
+    const double tpdf = tdf * (1 - s.tp0);                                      // :361
+    SunTerms o;
+    o.B = t.B;
+    o.G = fd * t.rs + (1 - fd) * t.rs;                                          // gortt.c:481-484
+    o.Z = fd * ((tpdf + s.eps) * t.rs) + (1 - fd) * t.Zf;                       // gortt.c:491-494
+    const double Td = (tpdf + s.tp0) * t.mgk;                                   // gortt.c:541-543
+    o.T = fd * Td + (1 - fd) * t.Tf;                                            // gortt.c:550
+    const double kk = kep + ko;
+    const double CfG = (kk * o.G + (1 - kk) * o.Z) * kep;                       // gortt.c:516-517
+    o.C0 = fd * (pdf + Td) + (1 - fd) * (t.pff + CfG + t.Tf);
+    return o;
+}
+
 __device__ inline SunTerms sun_terms(const double *__restrict__ L, int nw, int i, const SunScalars &s,
                                      double ko, double kep)
 {
-    const double gam = L[L_GAMMA * nw + i], omega = L[L_OMEGA * nw + i];
-    const double Rff = L[L_RFF * nw + i], Tff = L[L_TFF * nw + i];
-    const double tff = L[L_tFF * nw + i], pff = L[L_PFF * nw + i];
-    const double rs = L[L_RS * nw + i], mgk = L[L_MGK * nw + i];
-    const double Zf = L[L_ZF * nw + i], Tf = L[L_TF * nw + i];
-    const double mu = s.mu, fd = s.fd;
-    const double Rdf = (1.0 - gam) / (1.0 + 2.0 * mu * gam);                   // gortt_brdf.c:552
-    const double g2 = 2. * gam * mu;
-    const double Tdf = (omega / 2.0) * ((1. + 2. * mu) / (1. - g2 * g2)) * (Tff - s.t0);   // :467-471
-    const double X = s.t0 * Rdf + Tdf * Rff;
-    const double tdf = Tdf - pff * X;                                           // :423-424
-    const double pdf = Rdf - tff * X;                                           // :628-630
-    const double tpdf = tdf * (1 - s.tp0);                                      // :361
-    SunTerms o;
-    o.B = L[L_B * nw + i];
-    o.G = fd * rs + (1 - fd) * rs;                                              // gortt.c:481-484
-    o.Z = fd * ((tpdf + s.eps) * rs) + (1 - fd) * Zf;                           // gortt.c:491-494
-    const double Td = (tpdf + s.tp0) * mgk;                                     // gortt.c:541-543
-    o.T = fd * Td + (1 - fd) * Tf;                                              // gortt.c:550
-    const double kk = kep + ko;
-    const double CfG = (kk * o.G + (1 - kk) * o.Z) * kep;                       // gortt.c:516-517
-    o.C0 = fd * (pdf + Td) + (1 - fd) * (pff + CfG + Tf);
-    return o;
+    return sun_terms(load_band(L, nw, i), s, ko, kep);
 }
 
 __device__ inline SunScalars load_sun(const double *__restrict__ rec)
@@ -378,6 +393,42 @@ __global__ __launch_bounds__(256) void expand_stream_kernel(const gort_canopy *_
         o.z = b.T;
         o.w = b.Z;
         reinterpret_cast<double4 *>(scomp)[idx] = o;
+    }
+}
+
+// Band-major form for wide spectra: thread = band, keeps its 11 band terms in registers and walks
+// STREAM_LINES angle lines; the line's record (5 coefficients + 6 sun scalars) is workgroup-uniform and
+// comes through the scalar cache.  The flat form above re-reads 88 B of band terms per 8 B written.
+constexpr int STREAM_LINES = 32;
+template <bool WITH_SCOMP>
+__global__ __launch_bounds__(256) void expand_stream_bands_kernel(const gort_canopy *__restrict__ canopy,
+                                                                   const double *__restrict__ L, int nw,
+                                                                   const double *__restrict__ coef, long nA,
+                                                                   double *__restrict__ rsurf,
+                                                                   double *__restrict__ scomp)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const long a0 = (long)blockIdx.y * STREAM_LINES;
+    const long a1 = a0 + STREAM_LINES < nA ? a0 + STREAM_LINES : nA;
+    const bool live = i < nw;
+    const BandTerms t = load_band(L, nw, live ? i : 0);
+    const double ko = canopy->k_open, kep = canopy->k_openep;
+    for (long a = a0; a < a1; ++a) {
+        const double *__restrict__ rec = coef + a * GORT_COEF_STRIDE;
+        const SunScalars s = load_sun(rec);
+        const SunTerms b = sun_terms(t, s, ko, kep);
+        const double v = rec[A_C] * b.C0 + rec[A_B] * b.B + rec[A_Z] * b.Z + rec[A_G] * b.G + rec[A_T] * b.T;
+        if (live) {
+            rsurf[a * nw + i] = v;
+            if (WITH_SCOMP) {
+                double4 o;
+                o.x = b.C0 + rec[C_FDA] * b.B + rec[C_KPZ] * b.Z + rec[C_KPG] * b.G;    // C
+                o.y = b.G;
+                o.z = b.T;
+                o.w = b.Z;
+                reinterpret_cast<double4 *>(scomp)[a * nw + i] = o;
+            }
+        }
     }
 }
 
@@ -755,13 +806,25 @@ int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int
 {
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const long groups = (nA + STREAM_LINES - 1) / STREAM_LINES;
+    if (nw >= 64 && groups <= 65535) {
+        const dim3 grid((unsigned)((nw + 255) / 256), (unsigned)groups), block(256);
+        if (scomp_dev)
+            hipLaunchKernelGGL(expand_stream_bands_kernel<true>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev, nA,
+                               rsurf_dev, scomp_dev);
+        else
+            hipLaunchKernelGGL(expand_stream_bands_kernel<false>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev,
+                               nA, rsurf_dev, scomp_dev);
+        return check_launch("expand_stream_bands_kernel");
+    }
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (scomp_dev)
-        hipLaunchKernelGGL(expand_stream_kernel<true>, grid, block, 0, (hipStream_t)stream, canopy_dev, L_dev, nw,
-                           coef_dev, n, rsurf_dev, scomp_dev);
+        hipLaunchKernelGGL(expand_stream_kernel<true>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev, n, rsurf_dev,
+                           scomp_dev);
     else
-        hipLaunchKernelGGL(expand_stream_kernel<false>, grid, block, 0, (hipStream_t)stream, canopy_dev, L_dev, nw,
-                           coef_dev, n, rsurf_dev, scomp_dev);
+        hipLaunchKernelGGL(expand_stream_kernel<false>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev, n, rsurf_dev,
+                           scomp_dev);
     return check_launch("expand_stream_kernel");
 }
 

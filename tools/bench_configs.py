@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Timings of the BASELINE.json configs other than the headline grid (those are parity-test cases, not
+bench lines; this records what bounds each of them).  Device-resident inputs and outputs, HIP-side time
+measured as wall time around stream synchronisation, best of 5."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from gort_amd import api
+
+
+def best(fn, eng, reps=5):
+    fn(); eng.synchronize()
+    t = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); eng.synchronize(); t.append(time.perf_counter() - t0)
+    return min(t)
+
+
+c = api.gap_probabilities(api.make_canopy(lai=4.0))
+eng = api.Engine(); eng.set_canopy(c)
+
+# C2: principal plane, 181 view zeniths x 1 band (stream entry point, device buffers)
+eng.set_spectra(*api.spectra([800.0]))
+ang = torch.tensor([[float(v), 0.0, 30.0, 0.0] for v in range(-90, 91)], dtype=torch.float64, device="cuda")
+out = torch.empty((181, 1), dtype=torch.float64, device="cuda")
+t = best(lambda: eng.rsurf_stream_dev(ang, out), eng)
+print("C2  181 tuples x 1 band          : %8.1f us  %.3e samples/s  (launch latency bound: 2 kernels)" % (t * 1e6, 181 / t))
+
+# C3: full hemisphere x 1 band (LUT entry point, few-band path)
+g = api.hemisphere_grid(); rows = g.nsza * g.nvza
+lut = torch.empty((rows * g.nphi, 1), dtype=torch.float64, device="cuda")
+t = best(lambda: eng.rsurf_grid_dev(g, 0, rows, lut), eng)
+print("C3  2 989 441 tuples x 1 band    : %8.1f us  %.3e samples/s  (fp64 transcendental bound: geometry kernel)" % (t * 1e6, rows * g.nphi / t))
+
+# C4: spectral albedo + fAPAR, 91 sun zeniths x 2101 bands (energy entry point)
+wl = np.arange(400.0, 2501.0)
+eng.set_spectra(*api.spectra(wl))
+sza = torch.tensor([[0.0, 0.0, float(s), 0.0] for s in range(91)], dtype=torch.float64, device="cuda")
+en = torch.empty((91, wl.size, 3), dtype=torch.float64, device="cuda")
+t = best(lambda: eng.energy_stream_dev(sza, en), eng)
+print("C4  91 sun zeniths x 2101 bands  : %8.1f us  = %.3e BRDF evaluations/s equivalent (91 x 512 nodes x 2101 bands); "
+      "the reference needs 512 rsurf calls per (sun zenith, band)" % (t * 1e6, 91 * 512 * wl.size / t))
+
+# stream entry point at full spectrum: 65 536 random lines x 2101 bands (every line its own sun zenith)
+rng = np.random.default_rng(0)
+n = 65536
+a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), np.zeros(n)], 1), device="cuda")
+o2 = torch.empty((n, wl.size), dtype=torch.float64, device="cuda")
+t = best(lambda: eng.rsurf_stream_dev(a, o2), eng)
+print("stream 65 536 random lines x 2101: %8.1f us  %.3e samples/s  %.0f GB/s written" % (t * 1e6, n * wl.size / t, n * wl.size * 8 / t / 1e9))
+# host in / host out (PCIe inclusive), what the CLI pays before formatting
+ah = a.cpu().numpy()
+t0 = time.perf_counter(); eng.rsurf_stream(ah, want_K=True); t = time.perf_counter() - t0
+print("same through host buffers (PCIe) : %8.1f ms  %.3e samples/s" % (t * 1e3, n * wl.size / t))
