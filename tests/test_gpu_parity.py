@@ -357,6 +357,26 @@ def test_cli_hex_lut_extension_is_exact_and_reference_readable(tmp_path):
         assert r.returncode == 0 and r.stdout == direct
 
 
+def test_bench_json_contract():
+    """bench.py prints ONE JSON line with the driver's keys plus roofline/parity (reduced grid, 2 steps)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run(["python3", os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--nsza", "3",
+                          "--no-cpu-baseline"], capture_output=True, timeout=600)
+    assert run.returncode == 0, run.stderr.decode()
+    lines = [l for l in run.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "parity"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["unit"] == "samples/s" and d["value"] > 1e8 and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert d["parity"]["nan_pattern_equal"] and d["parity"]["max_rel_err"] <= 1e-9
+
+
 # ------------------------------------------------- BASELINE.json full sizes
 def _full_grid():
     return api.hemisphere_grid()
