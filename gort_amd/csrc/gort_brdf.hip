@@ -86,8 +86,12 @@ __device__ inline Primed prime(double ell, double tan_za)
 }
 
 // mutual-shadowing overlap O(theta_s', theta_v', phi)  (gortt_brdf.c:23-100)
+// Unfused on purpose: for equal primed zeniths and phi = 0 the reference gets d = t^2 + t^2 - 2 t t = 0
+// EXACTLY; an FMA leaves 1e-16 t^2 of product rounding in d, sqrt turns it into 1e-8 t, and Kc at 89/89 deg
+// moves by 3e-8.  All geometry below keeps plain IEEE multiply/add for the same reason.
 __device__ inline double overlap(double hb, const Primed &s, const Primed &v, double cphi, double sphi)
 {
+#pragma clang fp contract(off)
     const double d = s.t * s.t + v.t * v.t - 2.0 * s.t * v.t * cphi;
     const double D = sqrt(ref_max(0.0, d));
     const double x = s.t * v.t * sphi;
@@ -105,43 +109,48 @@ struct GeomOut {
     SunScalars sun;
 };
 
-// areal proportions + hot spot for one normalised geometry.
-// Restates gortt_kg/gortt_kc/gortt_kc_fFbeta (gortt_brdf.c:7-238), the angle part of
-// gortt_rsurf (gortt.c:424-449) and gortt_kuusk (gortt_brdf.c:638-702).
-__device__ void geometry_core(const gort_canopy &c, double vza, double sza, double raa, GeomOut &o)
-{
-    const double ell = c.b / c.r;
+// Everything of one (view zenith, sun zenith) pair that does not depend on the relative azimuth:
+// about 25 of the ~35 fp64 transcendentals of a tuple.  The LUT path evaluates it once per row
+// (361 azimuths) into LDS; the stream path once per line.
+struct RowTerms {
+    Primed v, s;
     double sin_vz, cos_vz, sin_sz, cos_sz;
-    sincos(vza, &sin_vz, &cos_vz);
-    sincos(sza, &sin_sz, &cos_sz);
-    const Primed v = prime(ell, sin_vz / cos_vz);
-    const Primed s = prime(ell, sin_sz / cos_sz);
-    double sin_r, cos_r;
-    sincos(raa, &sin_r, &cos_r);
+    double cov, hb, t1, es, ev, Gv;
+    double fF0, fFpi, beta;
+    double eps_s, eps_v, ls, lv, h1, kf;
+    SunScalars sun;
+};
 
-    const double cov = c.lambda * PI * c.rr;              // lambda pi r^2
-    const double hb = c.h / c.b;
-    const double t1 = s.sec + v.sec;
+// Restates the azimuth-independent parts of gortt_kg/gortt_kc/gortt_kc_fFbeta (gortt_brdf.c:7-238),
+// gortt_set_zenith_dependant_probabilities (gortt.c:872-915) and gortt_kuusk (gortt_brdf.c:638-702).
+__device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms &r)
+{
+#pragma clang fp contract(off)
+    const double ell = c.b / c.r;
+    sincos(vza, &r.sin_vz, &r.cos_vz);
+    sincos(sza, &r.sin_sz, &r.cos_sz);
+    r.v = prime(ell, r.sin_vz / r.cos_vz);
+    r.s = prime(ell, r.sin_sz / r.cos_sz);
+    const Primed &v = r.v, &s = r.s;
+    r.cov = c.lambda * PI * c.rr;                         // lambda pi r^2
+    r.hb = c.h / c.b;
+    r.t1 = s.sec + v.sec;
+    const double cov = r.cov, t1 = r.t1;
 
-    // three azimuths: the actual one, 0 and pi (Kc is interpolated between the
-    // principal-plane values, gortt_brdf.c:143-159)
-    const double O_r = overlap(hb, s, v, cos_r, sin_r);
-    const double O_0 = overlap(hb, s, v, 1.0, 0.0);
-    const double O_pi = overlap(hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
-    const double Kg = exp(-(cov * (t1 - O_r)));
+    // principal-plane overlaps (Kc is interpolated between phi = 0 and pi, gortt_brdf.c:143-159)
+    const double O_0 = overlap(r.hb, s, v, 1.0, 0.0);
+    const double O_pi = overlap(r.hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
     const double Kg0 = exp(-(cov * (t1 - O_0)));
     const double Kgpi = exp(-(cov * (t1 - O_pi)));
 
     const double xs = cov * s.sec, xv = cov * v.sec;
-    const double es = exp(-xs), ev = exp(-xv);
-    const double Mi = 1.0 - (1.0 - es) / xs;
-    const double Mv = 1.0 - (1.0 - ev) / xv;
+    r.es = exp(-xs);
+    r.ev = exp(-xv);
+    const double Mi = 1.0 - (1.0 - r.es) / xs;
+    const double Mv = 1.0 - (1.0 - r.ev) / xv;
     const double theta_Mi = acos(1.0 - 2.0 * Mi);
-    const double Gv = PI * c.rr * v.sec;
-
-    // F at the actual azimuth
-    const double ph_r = v.c * s.c + v.s * s.s * cos_r;
-    const double F_r = (Gv * 0.5 * (1.0 + ph_r)) / (PI * c.rr * (t1 - O_r));
+    r.Gv = PI * c.rr * v.sec;
+    const double Gv = r.Gv;
 
     // f*F on the principal plane, phi = 0 and phi = pi
     const bool view_steeper = fabs(vza) > fabs(sza);
@@ -162,54 +171,88 @@ __device__ void geometry_core(const gort_canopy &c, double vza, double sza, doub
         const double f = F * (1.0 - Gv * (PvMv + PiMi - Po) / Gc) / (1.0 - M);
         fF[q] = f * F;
     }
+    r.fF0 = fF[0];
+    r.fFpi = fF[1];
 
-    double beta;
     if (c.use_user_beta) {
-        beta = c.beta;
+        r.beta = c.beta;
     } else if (s.ang < 0.000000001) {
-        beta = 0.0;
+        r.beta = 0.0;
     } else {
         const double Dd = c.r * (1.0 / tan(s.ang / 2.0));
         const double dh = (c.h2 - c.h1) / Dd;
         const double lg = c.lambda * Gv;
-        beta = lg / (lg + dh) * (1.0 - exp(-lg - dh)) / (1.0 - exp(-lg));
+        r.beta = lg / (lg + dh) * (1.0 - exp(-lg - dh)) / (1.0 - exp(-lg));
     }
+
+    // zenith-dependent gap probabilities; path lengths of Kuusk's hot spot
+    double pn0_s, pn0_v;
+    gap_lookup(c, sza, pn0_s, r.eps_s);
+    gap_lookup(c, vza, pn0_v, r.eps_v);
+    r.kf = c.k * c.favd;
+    r.ls = -log(r.eps_s) / r.kf;
+    r.lv = -log(r.eps_v) / (0.5 * c.favd);
+    r.h1 = (r.ls * r.lv) > 0.0 ? sqrt(r.ls * r.lv) : 0.0;
+
+    r.sun.fd = c.use_user_fd ? c.fd_user : r.cos_sz / (r.cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291
+    r.sun.mu = s.c;
+    r.sun.t0 = exp(-(c.k * c.elai * s.sec));
+    r.sun.tp0 = pn0_s + r.eps_s;
+    r.sun.eps = r.eps_s;
+    r.sun.pn0 = pn0_s;
+}
+
+// The azimuth-dependent rest: overlap and Kg at the actual azimuth, the interpolated Kc, the other
+// proportions (gortt.c:424-449) and the hot spot.
+__device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa, GeomOut &o)
+{
+#pragma clang fp contract(off)
+    const Primed &v = r.v, &s = r.s;
+    double sin_r, cos_r;
+    sincos(raa, &sin_r, &cos_r);
+    const double O_r = overlap(r.hb, s, v, cos_r, sin_r);
+    const double Kg = exp(-(r.cov * (r.t1 - O_r)));
+    const double ph_r = v.c * s.c + v.s * s.s * cos_r;
+    const double F_r = (r.Gv * 0.5 * (1.0 + ph_r)) / (PI * c.rr * (r.t1 - O_r));
+
     double frac = raa / PI;
     if (frac > 1.0) frac = 2.0 - frac;
-    double f = (1. - frac) * fF[0] + frac * fF[1];
-    f = beta * f + (1.0 - beta) * F_r;
+    double f = (1. - frac) * r.fF0 + frac * r.fFpi;
+    f = r.beta * f + (1.0 - r.beta) * F_r;
     const double Kc = f * (1.0 - Kg);
 
-    const double Kz = ev - Kg;                               // gortt.c:439
+    const double Kz = r.ev - Kg;                             // gortt.c:439
     const double Kt = ref_max(0.0, 1.0 - Kc - Kz - Kg);      // gortt.c:443-444
-    const double Kpg = es - Kg;                              // gortt.c:448
-    const double Kpz = 1.0 - ev - Kpg;                       // gortt.c:449
+    const double Kpg = r.es - Kg;                            // gortt.c:448
+    const double Kpz = 1.0 - r.ev - Kpg;                     // gortt.c:449
 
-    // zenith-dependent gap probabilities and Kuusk's hot spot (unprimed angles in cos xi)
-    double pn0_s, eps_s, pn0_v, eps_v;
-    gap_lookup(c, sza, pn0_s, eps_s);
-    gap_lookup(c, vza, pn0_v, eps_v);
-    const double cos_xi = cos_sz * cos_vz + sin_sz * sin_vz * cos_r;
-    const double kf = c.k * c.favd;
-    const double ls = -log(eps_s) / kf;
-    const double lv = -log(eps_v) / (0.5 * c.favd);
-    const double q2 = ls * ls + lv * lv - 2. * ls * lv * cos_xi;
+    // Kuusk's hot spot (unprimed angles in cos xi).  In the exact hot-spot direction (vza = sza, raa = 0)
+    // q2 is pure rounding noise of cos_xi around 1, and exp(kf*h1*h2) amplifies it (up to ~1e-4 relative at
+    // 89 deg): the reference's value there is decided by the last bit of its own libm.  The operations below
+    // are kept unfused and in the reference's order (gortt_brdf.c:650-666) so that the same noise comes out
+    // whenever the device sin/cos agree with glibc's.
     double h2 = 1.0;
-    if (q2 > 0.0) {
-        const double lsv = sqrt(q2) / c.r;
-        h2 = (1.0 - exp(-lsv)) / lsv;
+    {
+        const double cos_xi = r.cos_sz * r.cos_vz + r.sin_sz * r.sin_vz * cos_r;
+        const double q2 = r.ls * r.ls + r.lv * r.lv - 2. * r.ls * r.lv * cos_xi;
+        if (q2 > 0.0) {
+            const double lsv = sqrt(q2);
+            h2 = (1.0 - exp(-lsv / c.r)) / (lsv / c.r);
+        }
     }
-    const double h1 = (ls * lv) > 0.0 ? sqrt(ls * lv) : 0.0;
-    const double kuusk = eps_s * eps_v * exp(kf * h1 * h2);
+    const double kuusk = r.eps_s * r.eps_v * exp(r.kf * r.h1 * h2);
 
     o.Kc = Kc;  o.Kg = Kg;  o.Kt = Kt;  o.Kz = Kz;  o.Kpg = Kpg;  o.Kpz = Kpz;
     o.A = kuusk / (2.0 * s.c * v.c);
-    o.sun.fd = c.use_user_fd ? c.fd_user : cos_sz / (cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291
-    o.sun.mu = s.c;
-    o.sun.t0 = exp(-(c.k * c.elai * s.sec));
-    o.sun.tp0 = pn0_s + eps_s;
-    o.sun.eps = eps_s;
-    o.sun.pn0 = pn0_s;
+    o.sun = r.sun;
+}
+
+// areal proportions + hot spot for one normalised geometry
+__device__ void geometry_core(const gort_canopy &c, double vza, double sza, double raa, GeomOut &o)
+{
+    RowTerms r;
+    row_terms(c, vza, sza, r);
+    finish_angle(c, r, raa, o);
 }
 
 __device__ inline void store_coef(double *rec, const gort_canopy &c, const GeomOut &g)
@@ -243,36 +286,46 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
     if (K) { K[4 * a] = g.Kc;  K[4 * a + 1] = g.Kg;  K[4 * a + 2] = g.Kt;  K[4 * a + 3] = g.Kz; }
 }
 
-// grid nodes generated from indices; identical to streaming "vza phi sza 0" 
-// Ensemble form: rows run over (member, sun zenith, view zenith); member = row / rows_per_member picks the canopy.
-__global__ __launch_bounds__(256) void geometry_grid_kernel(const gort_canopy *__restrict__ canopies, gort_grid g,
-                                                             long row_begin, long n_angles,
-                                                             double *__restrict__ coef, int compact)
+// grid nodes generated from indices; identical to streaming "vza phi sza 0" (SURVEY 8d, C3).
+// One workgroup per LUT row = (member, sun zenith, view zenith): the azimuth-independent terms are
+// evaluated ONCE per row into LDS (one lane), then the lanes walk the nphi azimuth nodes.  With 361 nodes per
+// row this removes ~70 % of the transcendentals of the per-tuple form.
+constexpr int GEOM_ROW_THREADS = 128;
+__global__ __launch_bounds__(GEOM_ROW_THREADS) void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
+                                                                          gort_grid g, long row_begin,
+                                                                          double *__restrict__ coef, int compact)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_angles) return;
+    __shared__ RowTerms s_row;
     const long rows_per_member = (long)g.nsza * g.nvza;
-    const long grow = row_begin + i / g.nphi;
+    const long grow = row_begin + blockIdx.x;
     const long member = grow / rows_per_member;
     const long row = grow - member * rows_per_member;
-    const int l = (int)(i % g.nphi);
     const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
-    const gort_canopy *canopy = canopies + member;
+    const gort_canopy &c = canopies[member];
+    const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
     double vza, sza, saa, raa;
-    normalise_angles(g.vza0 + ivza * g.dvza, g.phi0 + l * g.dphi, g.sza0 + isza * g.dsza, 0.0, vza, sza, saa, raa);
-    GeomOut o;
-    geometry_core(*canopy, vza, sza, raa, o);
-    if (compact) {
-        // LUT path: only the five expansion coefficients, one 64-B record per node
-        double rec[GORT_COEF_STRIDE];
-        store_coef(rec, *canopy, o);
-        double2 *dst = reinterpret_cast<double2 *>(coef + i * 8);
-        dst[0] = make_double2(rec[A_C], rec[A_B]);
-        dst[1] = make_double2(rec[A_Z], rec[A_G]);
-        dst[2] = make_double2(rec[A_T], 0.0);
-        dst[3] = make_double2(0.0, 0.0);
-    } else {
-        store_coef(coef + i * GORT_COEF_STRIDE, *canopy, o);
+    if (threadIdx.x == 0) {
+        normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
+        row_terms(c, vza, sza, s_row);
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < g.nphi; l += GEOM_ROW_THREADS) {
+        normalise_angles(vza_deg, g.phi0 + l * g.dphi, sza_deg, 0.0, vza, sza, saa, raa);
+        GeomOut o;
+        finish_angle(c, s_row, raa, o);
+        const long i = (long)blockIdx.x * g.nphi + l;
+        if (compact) {
+            // LUT path: only the five expansion coefficients, one 64-B record per node
+            double rec[GORT_COEF_STRIDE];
+            store_coef(rec, c, o);
+            double2 *dst = reinterpret_cast<double2 *>(coef + i * 8);
+            dst[0] = make_double2(rec[A_C], rec[A_B]);
+            dst[1] = make_double2(rec[A_Z], rec[A_G]);
+            dst[2] = make_double2(rec[A_T], 0.0);
+            dst[3] = make_double2(0.0, 0.0);
+        } else {
+            store_coef(coef + i * GORT_COEF_STRIDE, c, o);
+        }
     }
 }
 
@@ -794,10 +847,10 @@ int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_d
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream)
 {
-    const long n = (row_end - row_begin) * g.nphi;
-    if (n <= 0) return GORT_OK;
-    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       canopy_dev, g, row_begin, n, coef_dev, compact ? 1 : 0);
+    const long rows = row_end - row_begin;
+    if (rows <= 0) return GORT_OK;
+    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)rows), dim3(GEOM_ROW_THREADS), 0, (hipStream_t)stream,
+                       canopy_dev, g, row_begin, coef_dev, compact ? 1 : 0);
     return check_launch("geometry_grid_kernel");
 }
 
