@@ -350,10 +350,10 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     const long rows = row_end - row_begin, nA = rows * g->nphi;
     const int nw = e->nw;
     const gort_canopy *c = e->canopy.as<gort_canopy>();
-    const bool few_bands = nw < 128 || nw > 9 * 256;
+    const bool few_bands = nw < 128;     // the aligned LUT kernel needs a chunk (128 doubles) to span at most two angles
     if (few_bands) {
         // few bands: one thread per sample straight from the full angle records (single canopy only)
-        if (e->n_members != 1) return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: needs 128 <= nw <= 2304 bands");
+        if (e->n_members != 1) return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: needs nw >= 128 bands");
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
         return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, e->stream);

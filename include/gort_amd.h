@@ -187,7 +187,7 @@ typedef struct gort_grid {
 int  gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, long row_end,
                          double *lut_dev);
 /* Same grid for ensemble members [member_begin, member_end): lut_dev[member][nsza][nvza][nphi][nw],
- * one launch sequence for all of them (needs 128 <= nw <= 2304). */
+ * one launch sequence for all of them (needs nw >= 128). */
 int  gort_rsurf_members_grid_dev(gort_engine *e, const gort_grid *g, int member_begin, int member_end,
                                  double *lut_dev);
 /* kernel-only timing hook for bench.py: average duration (ms) of the LUT expansion

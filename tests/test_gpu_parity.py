@@ -213,7 +213,7 @@ def _grid_angles(g, r0, r1):
     return a.reshape(-1, 4)
 
 
-@pytest.mark.parametrize("nw", [1, 100, 256, 300, 1000, 2101])
+@pytest.mark.parametrize("nw", [1, 100, 128, 129, 256, 300, 1000, 2101, 3000])
 def test_grid_equals_stream_and_oracle(eng, nw):
     """LUT path (register-resident sun terms) == stream path == oracle, ragged band counts included."""
     import torch
