@@ -57,6 +57,7 @@ struct gort_engine {
     size_t ev_used = 0;
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
+    DevBuf xcd_slots;                    // 9 ints: per-XCD slot counters + arrival counter of expand_flat_kernel
     int n_members = 1;
     bool have_canopy = false, have_spectra = false, have_nodes = false, have_tables = false;
     int nw = 0;
@@ -145,7 +146,7 @@ extern "C" void gort_engine_destroy(gort_engine *e)
     if (!e) return;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
-                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof})
+                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots})
         b->release();
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -370,6 +371,8 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     const int q0 = (int)(row_begin / g->nvza), q1 = (int)((row_end - 1) / g->nvza) + 1;
     if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(q1 - q0)))) return rc;
     if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, e->sun.as<double>(), e->stream))) return rc;
+    if ((rc = e->xcd_slots.reserve(sizeof(int) * 16))) return rc;
+    GORT_HIP(hipMemsetAsync(e->xcd_slots.p, 0, sizeof(int) * 16, e->stream));       // per-XCD slot counters
     // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to
     // 512 launches are kept between two gort_engine_last_expand_ms() calls
     const bool timed = e->ev_used + 2 <= 1024;
@@ -382,7 +385,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
     rc = launch_expand_grid(e->sun.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
-                            e->stream);
+                            e->xcd_slots.as<int>(), e->stream);
     if (timed) {
         GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;

@@ -684,15 +684,40 @@ template <int DEPTH, bool NT>
 __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restrict__ sun, int isza_base,
                                                            const double *__restrict__ coef, int nw,
                                                            int angles_per_sza, long angle0, long n_total, int shift,
-                                                           long stride_chunks, double *__restrict__ lut, int xcd_contig)
+                                                           long stride_chunks, double *__restrict__ lut, int xcd_mode,
+                                                           int *__restrict__ xcd_slots)
 {
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     long block = blockIdx.x;
-    if (xcd_contig) {
-        // blocks b, b+8, b+16, ... share an XCD (observed dispatch, speed only): give each XCD one contiguous
-        // range of chunks so that an angle's records are fetched into ONE L2 instead of eight
-        const long nb = gridDim.x, x = block & 7, base = nb >> 3, rem = nb & 7;
+    // Give each XCD ONE contiguous range of chunks (eight write windows, one per L2, instead of one window
+    // interleaved over all eight): 9.4 -> 8.1 ms.  Any block->range assignment is correct; only speed depends
+    // on it.  Ranges: XCD y owns logical blocks [y*base + min(y,rem), +quota(y)), quota = base (+1 if y < rem).
+    const long nb = gridDim.x, base = nb >> 3, rem = nb & 7;
+    if (xcd_mode == 1) {
+        // static guess: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch as observed unprofiled)
+        const long x = block & 7;
         block = x * base + (x < rem ? x : rem) + (block >> 3);
+    } else if (xcd_mode == 2) {
+        // placement-independent: read the XCD this block really runs on (HW_REG_XCC_ID) and take the next free
+        // slot of that XCD's range; if that range is used up (uneven placement, e.g. under rocprofv3) take one
+        // from the next XCD.  The ranges sum to nb, so every block finds a slot within 8 tries.  The launcher
+        // zeroes the 8 counters on the stream before every launch.
+        __shared__ long s_block;
+        if (threadIdx.x == 0) {
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            long L = -1;
+            for (int t = 0; t < 8 && L < 0; ++t) {
+                const long y = (x + t) & 7;
+                const long quota = base + (y < rem ? 1 : 0);
+                const long s = atomicAdd(&xcd_slots[y], 1);
+                if (s < quota) L = y * base + (y < rem ? y : rem) + s;
+            }
+            s_block = L;
+        }
+        __syncthreads();
+        block = s_block;
+        if (block < 0) return;      // cannot happen (pigeonhole); never index out of the slab
     }
     const long wave = block * 4 + wave_in_block;                              // scalar
     if (wave >= stride_chunks) return;
@@ -899,7 +924,10 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 //   GORT_EXPAND_WAVES    target number of waves   (flat; rounded to a band-preserving stride)
 struct ExpandTuning {
     bool flat = true, nt = true;
-    bool xcd_contig = true;   // interleaved A/B on one box: 8.07-8.14 ms with, 9.38-9.48 ms without (profiles/r01/tune_xcd.log)
+    // GORT_EXPAND_XCD: 0 = chunk ranges interleaved over the XCDs, 1 = contiguous range per XCD assuming
+    // round-robin dispatch, 2 = contiguous range per XCD by the real XCC_ID (default).
+    // Interleaved A/B on one box: 8.07-8.14 ms with mode 1, 9.38-9.48 ms with mode 0 (profiles/r01/tune_xcd.log)
+    int xcd_mode = 2;
     int depth = 2;
     long waves = 32768;     // 50 GB slab, XCD-contiguous, interleaved A/B (profiles/r01/tune_flat_kernel.log):
                             // 8404 -> 8.9 ms, 16808 -> 8.5-9.1 (noisy), 25212/33616 -> 7.95-7.97, 67232 -> 9.5
@@ -909,7 +937,8 @@ struct ExpandTuning {
         if (const char *v = getenv("GORT_EXPAND_NT")) nt = atoi(v) != 0;
         if (const char *v = getenv("GORT_EXPAND_DEPTH")) depth = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_WAVES")) waves = atol(v);
-        if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_contig = atoi(v) != 0;
+        if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_mode = atoi(v);
+        if (xcd_mode < 0 || xcd_mode > 2) xcd_mode = 2;
         if (depth != 1 && depth != 2 && depth != 4) depth = 2;
         if (waves < 64) waves = 64;
     }
@@ -973,7 +1002,7 @@ long expand_grid_tail_pad_records(int nw, long n_total)
 }
 
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
-                       long row_begin, long row_end, double *lut_dev, void *stream)
+                       long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, void *stream)
 {
     const long rows = row_end - row_begin;
     if (rows <= 0) return GORT_OK;
@@ -999,7 +1028,8 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
     const long angle0 = row_begin * nphi;
 #define GORT_FLAT(D, N)                                                                                           \
     hipLaunchKernelGGL((expand_flat_kernel<D, N>), grid, dim3(256), 0, s, sun_dev, isza_base, coef_dev, nw,      \
-                       angles_per_sza, angle0, n_total, shift, stride, lut_dev, tune.xcd_contig ? 1 : 0)
+                       angles_per_sza, angle0, n_total, shift, stride, lut_dev, xcd_slots_dev ? tune.xcd_mode : 1,   \
+                       xcd_slots_dev)
     if (tune.nt) {
         if (tune.depth == 1) GORT_FLAT(1, true); else if (tune.depth == 2) GORT_FLAT(2, true); else GORT_FLAT(4, true);
     } else {

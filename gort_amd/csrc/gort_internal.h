@@ -72,8 +72,10 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 // coef_dev for launch_expand_grid: compact records, with ONE readable pad record in front of coef_dev
 // and expand_grid_tail_pad_records() readable records behind the last angle
 long expand_grid_tail_pad_records(int nw, long n_total);
+// xcd_slots_dev: 8 ints zeroed on `stream` before the call (per-XCD slot counters), or nullptr to fall back
+// to the static XCD guess
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
-                       long row_begin, long row_end, double *lut_dev, void *stream);
+                       long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, void *stream);
 int launch_energy(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev, long nA,
                   const double *nodes_dev, double *energy_dev, void *stream);
 
