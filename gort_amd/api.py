@@ -68,7 +68,7 @@ DECLARED_SYMBOLS = [
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
     "gort_rsurf_members_grid_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
-    "gort_energy_stream", "gort_energy_stream_dev",
+    "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def lib():
                                              C.c_void_p]
         L.gort_energy_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.gort_energy_stream_dev.argtypes = L.gort_energy_stream.argtypes
+        L.gort_energy_members_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
         L.gort_gap_probabilities.argtypes = [C.c_void_p, C.c_int]
         L.gort_gap_probabilities_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gort_canopy_newstyle.argtypes = [C.POINTER(Canopy), C.c_float, C.c_float, C.c_float]
@@ -346,6 +347,11 @@ class Engine:
 
     def energy_stream_dev(self, angles_t, energy_t):
         _check(lib().gort_energy_stream_dev(self.h, _ptr(angles_t), angles_t.shape[0], _ptr(energy_t)))
+
+    def energy_members_dev(self, angles_t, member_begin, member_end, energy_t):
+        """energy_t[member][nA][nw][3] for the ensemble members [member_begin, member_end)."""
+        _check(lib().gort_energy_members_dev(self.h, _ptr(angles_t), angles_t.shape[0], member_begin, member_end,
+                                             _ptr(energy_t)))
 
 
 def hemisphere_grid(nsza=91, nvza=91, nphi=361):

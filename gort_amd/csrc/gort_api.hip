@@ -480,7 +480,24 @@ extern "C" int gort_energy_stream_dev(gort_engine *e, const double *angles_dev, 
     if (nA < 0 || (nA > 0 && (!angles_dev || !energy_dev))) return fail(GORT_EINVAL, "gort_energy_stream_dev: bad argument");
     if (nA == 0) return GORT_OK;
     if ((rc = ensure_nodes(e))) return rc;
-    return launch_energy(e->canopy.as<gort_canopy>(), e->L.as<double>(), e->nw, angles_dev, nA,
+    return launch_energy(e->canopy.as<gort_canopy>(), 1, e->L.as<double>(), e->nw, angles_dev, nA,
+                         e->nodes.as<double>(), energy_dev, e->stream);
+}
+
+extern "C" int gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
+                                       int member_end, double *energy_dev)
+{
+    int rc = require_ready(e, "gort_energy_members_dev");
+    if (rc) return rc;
+    if (member_begin < 0 || member_end > e->n_members || member_begin > member_end)
+        return fail(GORT_EINVAL, "gort_energy_members_dev: members [%d,%d) outside [0,%d)", member_begin, member_end,
+                    e->n_members);
+    if (nA < 0 || (nA > 0 && member_end > member_begin && (!angles_dev || !energy_dev)))
+        return fail(GORT_EINVAL, "gort_energy_members_dev: bad argument");
+    if (nA == 0 || member_begin == member_end) return GORT_OK;
+    if ((rc = ensure_nodes(e))) return rc;
+    return launch_energy(e->canopy.as<gort_canopy>() + member_begin, member_end - member_begin,
+                         e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw, e->nw, angles_dev, nA,
                          e->nodes.as<double>(), energy_dev, e->stream);
 }
 

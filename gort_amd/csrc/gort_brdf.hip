@@ -778,16 +778,21 @@ __device__ inline double wave_sum(double v)
     return v;
 }
 
-__global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopy,
-                                                                 const double *__restrict__ L, int nw,
+// blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by the members;
+// energy[member][nA][nw][3]
+__global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopies,
+                                                                 const double *__restrict__ Lall, int nw,
                                                                  const double *__restrict__ angles,
                                                                  const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
-                                                                 double *__restrict__ energy)
+                                                                 double *__restrict__ energy_all)
 {
     __shared__ double s_part[5][ENERGY_THREADS / 64];
     __shared__ double s_abar[5];
     __shared__ double s_sun[6];
-    const gort_canopy &c = *canopy;
+    const long member = blockIdx.y;
+    const gort_canopy &c = canopies[member];
+    const double *__restrict__ L = Lall + member * L_NSLOT * nw;
+    double *__restrict__ energy = energy_all + member * (long)gridDim.x * nw * 3;
     const long a = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -1039,12 +1044,13 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
     return check_launch("expand_flat_kernel");
 }
 
-int launch_energy(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev, long nA,
-                  const double *nodes_dev, double *energy_dev, void *stream)
+int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
+                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *stream)
 {
-    if (nA <= 0 || nw <= 0) return GORT_OK;
-    hipLaunchKernelGGL(energy_kernel, dim3((unsigned)nA), dim3(ENERGY_THREADS), 0, (hipStream_t)stream, canopy_dev,
-                       L_dev, nw, angles_dev, nodes_dev, energy_dev);
+    if (nA <= 0 || nw <= 0 || n_members <= 0) return GORT_OK;
+    if (n_members > 65535) return fail(GORT_EINVAL, "energy: %d members in one launch (max 65535)", n_members);
+    hipLaunchKernelGGL(energy_kernel, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0,
+                       (hipStream_t)stream, canopies_dev, L_dev, nw, angles_dev, nodes_dev, energy_dev);
     return check_launch("energy_kernel");
 }
 

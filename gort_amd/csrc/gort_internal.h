@@ -76,8 +76,9 @@ long expand_grid_tail_pad_records(int nw, long n_total);
 // to the static XCD guess
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
                        long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, void *stream);
-int launch_energy(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev, long nA,
-                  const double *nodes_dev, double *energy_dev, void *stream);
+// energy_dev[n_members][nA][nw][3]; members are canopies_dev[0..n) with L_dev[m][L_NSLOT][nw]
+int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
+                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *stream);
 
 }  // namespace gort
 #endif

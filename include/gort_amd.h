@@ -200,6 +200,10 @@ double gort_engine_last_expand_ms(gort_engine *e);
  * viewing hemisphere.  energy[nA][nw][3] = albedo, favegt, fasoil (print order, gortt.c:323-324) */
 int  gort_energy_stream(gort_engine *e, const double *angles, long nA, double *energy);
 int  gort_energy_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *energy_dev);
+/* the same nA angle lines for ensemble members [member_begin, member_end): energy_dev[member][nA][nw][3] -
+ * the reduced per-member product (albedo, fAPAR) an ensemble driver exchanges between GPUs */
+int  gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
+                             int member_end, double *energy_dev);
 
 #ifdef __cplusplus
 }

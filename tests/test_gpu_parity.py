@@ -553,6 +553,31 @@ def test_ensemble_members_one_launch(golden):
     e.close(); single.close()
 
 
+def test_ensemble_energy_table(golden):
+    """Per-member albedo/fAPAR for a member range in one launch == the single-canopy energy path == the oracle."""
+    import torch
+    g, canopies, leaf = _members(golden, n_extra=4)
+    wl = g["wl"][::7]
+    e = api.Engine()
+    e.set_members_leaf(canopies, leaf, wl, compute_gaps=True)
+    lines = np.array([[0., 0., 30., 0.], [10., 20., 65., 140.]])
+    ang = torch.tensor(lines, dtype=torch.float64, device="cuda")
+    n = len(canopies)
+    out = torch.empty((n - 3, 2, wl.size, 3), dtype=torch.float64, device="cuda")
+    e.energy_members_dev(ang, 3, n, out)
+    e.synchronize()
+    got = out.cpu().numpy()
+    single = api.Engine()
+    for i in range(3, n):
+        c = api.gap_probabilities(canopies[i])
+        rs, rl, tl = api.spectra(wl, leaf[i])
+        single.set_canopy(c); single.set_spectra(rs, rl, tl)
+        assert err(got[i - 3], single.energy_stream(lines)) <= REGRESSION
+        assert err(got[i - 3], O.energy_stream(oracle_like(c), lines, rs, rl, tl)) <= REGRESSION
+    assert np.abs(got.sum(axis=3) - 1.0).max() < 1e-12          # albedo + favegt + fasoil = 1
+    e.close(); single.close()
+
+
 def test_ensemble_argument_errors():
     e = api.Engine()
     c = gpu_canopy(lai=4.0)
