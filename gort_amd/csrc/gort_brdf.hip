@@ -35,6 +35,14 @@ __device__ inline double ref_min(double x, double y) { return x < y ? x : y; }
 
 struct SunScalars { double fd, mu, t0, tp0, eps, pn0; };
 
+// rsurf = aC*C0 + aB*B + aZ*Z + aG*G + aT*T with ONE fixed association (an explicit FMA chain), so that
+// every kernel form and every template instantiation writes the same bits for the same inputs.
+__device__ __forceinline__ double dot5(double aC, double aB, double aZ, double aG, double aT,
+                                       double C0, double B, double Z, double G, double T)
+{
+    return __builtin_fma(aT, T, __builtin_fma(aG, G, __builtin_fma(aZ, Z, __builtin_fma(aB, B, aC * C0))));
+}
+
 // ------------------------------------------------------------------ geometry
 
 // linear interpolation in the 1-degree gap tables (gortt.c:872-915).  The reference
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(256) void expand_stream_kernel(const gort_canopy *_
     const double *rec = coef + a * GORT_COEF_STRIDE;
     const SunScalars s = load_sun(rec);
     const SunTerms b = sun_terms(L, nw, i, s, canopy->k_open, canopy->k_openep);
-    rsurf[idx] = rec[A_C] * b.C0 + rec[A_B] * b.B + rec[A_Z] * b.Z + rec[A_G] * b.G + rec[A_T] * b.T;
+    rsurf[idx] = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], b.C0, b.B, b.Z, b.G, b.T);
     if (WITH_SCOMP) {
         double4 o;
         o.x = b.C0 + rec[C_FDA] * b.B + rec[C_KPZ] * b.Z + rec[C_KPG] * b.G;    // C
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256) void expand_stream_bands_kernel(const gort_can
         const double *__restrict__ rec = coef + a * GORT_COEF_STRIDE;
         const SunScalars s = load_sun(rec);
         const SunTerms b = sun_terms(t, s, ko, kep);
-        const double v = rec[A_C] * b.C0 + rec[A_B] * b.B + rec[A_Z] * b.Z + rec[A_G] * b.G + rec[A_T] * b.T;
+        const double v = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], b.C0, b.B, b.Z, b.G, b.T);
         if (live) {
             rsurf[a * nw + i] = v;
             if (WITH_SCOMP) {
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int i = tid + p * THREADS;
-            const double v = aC * bC[p] + aB * bB[p] + aZ * bZ[p] + aG * bG[p] + aT * bT[p];
+            const double v = dot5(aC, aB, aZ, aG, aT, bC[p], bB[p], bZ[p], bG[p], bT[p]);
             if (p < NP - 1 || last_ok) {
                 if (NT) __builtin_nontemporal_store(v, out + i);
                 else out[i] = v;
@@ -633,11 +641,11 @@ __device__ __forceinline__ void flat_loop(FlatLane st, const double *__restrict_
             double v[EPL];
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                const double vA = rA[d][A_C] * st.b[j][0] + rA[d][A_B] * st.b[j][1] + rA[d][A_Z] * st.b[j][2] +
-                                  rA[d][A_G] * st.b[j][3] + rA[d][A_T] * st.b[j][4];
+                const double vA = dot5(rA[d][A_C], rA[d][A_B], rA[d][A_Z], rA[d][A_G], rA[d][A_T], st.b[j][0],
+                                       st.b[j][1], st.b[j][2], st.b[j][3], st.b[j][4]);
                 if (WRAP) {
-                    const double vB = rB[d][A_C] * st.b[j][0] + rB[d][A_B] * st.b[j][1] + rB[d][A_Z] * st.b[j][2] +
-                                      rB[d][A_G] * st.b[j][3] + rB[d][A_T] * st.b[j][4];
+                    const double vB = dot5(rB[d][A_C], rB[d][A_B], rB[d][A_Z], rB[d][A_G], rB[d][A_T], st.b[j][0],
+                                           st.b[j][1], st.b[j][2], st.b[j][3], st.b[j][4]);
                     v[j] = st.wrapped[j] ? vB : vA;
                 } else {
                     v[j] = vA;
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
     const double aC = s_abar[0], aB = s_abar[1], aZ = s_abar[2], aG = s_abar[3], aT = s_abar[4];
     for (int i = tid; i < nw; i += ENERGY_THREADS) {
         const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
-        const double albedo = aC * b.C0 + aB * b.B + aZ * b.Z + aG * b.G + aT * b.T;
+        const double albedo = dot5(aC, aB, aZ, aG, aT, b.C0, b.B, b.Z, b.G, b.T);
         const double rs = L[L_RS * nw + i];
         // energy balance, Lambertian background (gortt_albedo.c:39-52)
         const double Fu2 = b.G * s.pn0 + b.Z * (1. - s.pn0);

@@ -357,6 +357,36 @@ def test_cli_hex_lut_extension_is_exact_and_reference_readable(tmp_path):
         assert r.returncode == 0 and r.stdout == direct
 
 
+_VARIANT_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from gort_amd import api
+c = api.gap_probabilities(api.make_canopy(lai=4.0))
+e = api.Engine(); e.set_canopy(c); e.set_spectra(*api.spectra(np.arange(400.0, 2501.0)))
+g = api.hemisphere_grid(7, 9, 361)
+lut = torch.empty((63 * 361 + 3, 2101), dtype=torch.float64, device="cuda")
+e.rsurf_grid_dev(g, 0, 63, lut.view(-1)[5:])          # deliberately misaligned slab pointer (+40 B)
+e.synchronize()
+print(hashlib.sha256(lut.view(-1)[5:5 + 63 * 361 * 2101].cpu().numpy().tobytes()).hexdigest())
+"""
+
+
+def test_lut_kernel_variants_bitwise_identical():
+    """Every tuning variant of the LUT expansion (kernel form, XCD mapping mode, prefetch depth, wave count,
+    store flavour) writes the same bytes: the knobs change speed only."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envs = [{}, {"GORT_EXPAND_XCD": "0"}, {"GORT_EXPAND_XCD": "1"}, {"GORT_EXPAND_VARIANT": "row"},
+            {"GORT_EXPAND_DEPTH": "1", "GORT_EXPAND_WAVES": "500"}, {"GORT_EXPAND_DEPTH": "4", "GORT_EXPAND_NT": "0"}]
+    digests = []
+    for extra in envs:
+        env = dict(os.environ); env.update(extra)
+        run = subprocess.run(["python3", "-c", _VARIANT_SCRIPT % root], capture_output=True, timeout=300, env=env)
+        assert run.returncode == 0, run.stderr.decode()
+        digests.append(run.stdout.decode().strip().split("\n")[-1])
+    assert len(set(digests)) == 1, list(zip(envs, digests))
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the driver's keys plus roofline/parity (reduced grid, 2 steps)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
