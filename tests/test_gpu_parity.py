@@ -161,6 +161,42 @@ def test_random_stream_second_canopy(eng, golden):
     assert err(sc, g["scomp"]) <= REGRESSION
 
 
+def test_brdf_fuzz_random_canopies_angles_bands(eng):
+    """40 random canopies x 300 random angle lines (incl. negative zeniths, wrapped azimuths, near-horizon and
+    exact hot-spot directions) x 25 random wavelengths, every output (rsurf, C/G/T/Z, K, albedo table) against
+    the oracle given the same gap tables."""
+    rng = np.random.default_rng(777)
+    worst = 0.0
+    for it in range(40):
+        kw = dict(newstyle=(float(np.float32(rng.uniform(0.5, 4))), float(np.float32(rng.uniform(0.4, 4))),
+                            float(np.float32(rng.uniform(0.05, 0.95)))), lai=float(np.float32(rng.uniform(0.1, 9))))
+        if it % 5 == 0: kw["beta"] = float(rng.uniform(0, 1))
+        if it % 7 == 0: kw["diffuse"] = float(rng.uniform(0, 1))
+        c = gpu_canopy(**kw)
+        n = 300
+        ang = np.stack([rng.uniform(-89.9, 89.9, n), rng.uniform(-720, 720, n), rng.uniform(-89.9, 89.9, n),
+                        rng.uniform(-720, 720, n)], 1)
+        ang[:20, 0] = ang[:20, 2]; ang[:20, 1] = ang[:20, 3]                 # exact hot spot
+        ang[20:30, [0, 2]] = np.round(ang[20:30, [0, 2]])                    # integer zeniths (table nodes)
+        ang[30:40, 0] = rng.uniform(88.5, 89.99, 10)                        # near the horizon
+        wl = np.sort(rng.uniform(400, 2500, 25))
+        ls = api.leaf_soil(prospect=dict(N=rng.uniform(1, 3), Cab=rng.uniform(0, 80), Cw=rng.uniform(0.001, 0.04),
+                                         Cm=rng.uniform(0.001, 0.02)), rsl=(rng.uniform(0.05, 0.4), 0.1, 0.03726, -0.002426))
+        rs, rl, tl = api.spectra(wl, ls)
+        eng.set_canopy(c); eng.set_spectra(rs, rl, tl)
+        r, sc, K = eng.rsurf_stream(ang, want_scomp=True)
+        o = oracle_like(c)
+        ro, sco, Ko = O.rsurf_stream(o, ang, rs, rl, tl, want_scomp=True)
+        e = max(err(r, ro), err(sc.reshape(sco.shape), sco), err_K(K, Ko))
+        en = eng.energy_stream(ang[:6])
+        e = max(e, err(en, O.energy_stream(o, ang[:6], rs, rl, tl)))
+        # near-horizon hot-spot directions are ill-conditioned in the reference itself (DESIGN.md 5.2): the
+        # bound here is 10x tighter than north_star's 1e-5, the observed worst case is ~1e-7
+        assert e <= 1e-6, (it, kw, e)
+        worst = max(worst, e)
+    print("BRDF fuzz: worst relative error %.2e" % worst)
+
+
 def test_stream_edge_cases(eng):
     eng.set_canopy(gpu_canopy(lai=4.0))
     eng.set_spectra(*api.spectra([800.0]))
