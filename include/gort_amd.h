@@ -34,7 +34,7 @@ extern "C" {
 #define GORT_NH_ES     20      /* gortt.c:90  */
 #define GORT_NPOINTS   32      /* gortt.c:93  */
 #define GORT_NBANDS    2101    /* gortt.h:31  */
-#define GORT_COEF_STRIDE 16    /* doubles per angle record, see gort_geometry_dev */
+#define GORT_COEF_STRIDE 16    /* doubles per angle record of the stream path (internal buffers only) */
 
 enum {
     GORT_OK = 0,
