@@ -35,9 +35,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROA
 BYTES_PER_SAMPLE = 8.0     # one fp64 value written per sample (grid mode)
 
 
-def cpu_baseline(wl, budget_s=20.0, force_port=False):
+def cpu_baseline(wl, budget_s=20.0, force_port=False, procs=1):
     """Reference `gortt` (oracle/_ref, built from /root/reference in the build container) timed on this
-    box's host CPU, one thread (the program is single-threaded); falls back to the oracle port."""
+    box's host CPU.  The program is single-threaded: `procs` > 1 runs that many copies at once, each on its own
+    angle stream (how a user would use all cores).  Falls back to the oracle port (1 thread)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "gortt") if not force_port else "/nonexistent"
     cores = 1
     try:
@@ -63,14 +64,24 @@ def cpu_baseline(wl, budget_s=20.0, force_port=False):
             subprocess.run([ref, "-LAI", "4.0", "-P", lut_path], input=stream(n), stdout=subprocess.DEVNULL, timeout=300)
             dt = time.perf_counter() - t0
             n = int(min(max(n * budget_s / max(dt, 1e-3), n), 400000))
-            data = stream(n)
+            files = []
+            for p in range(procs):
+                path = "/tmp/gort_bench_stream_%d_%d.txt" % (os.getpid(), p)
+                open(path, "wb").write(stream(n))
+                files.append(path)
             t0 = time.perf_counter()
-            subprocess.run([ref, "-LAI", "4.0", "-P", lut_path], input=data, stdout=subprocess.DEVNULL, timeout=600)
+            running = [subprocess.Popen([ref, "-LAI", "4.0", "-P", lut_path], stdin=open(f, "rb"),
+                                        stdout=subprocess.DEVNULL) for f in files]
+            rcs = [p.wait(timeout=900) for p in running]
             dt = time.perf_counter() - t0
-            os.unlink(lut_path)
-            return {"value": n * len(w) / dt, "unit": "samples/s", "cores": cores, "kind": "reference",
+            for f in files + [lut_path]:
+                os.unlink(f)
+            if any(rcs):
+                raise RuntimeError("reference exited with %r" % rcs)
+            return {"value": procs * n * len(w) / dt, "unit": "samples/s", "cores": procs, "kind": "reference",
                     "sample": "reference gortt (-O3 build of /root/reference, gap LUT via -P, text I/O to /dev/null): "
-                              "%d random angle lines x %d bands in %.1f s; cpu: %s" % (n, len(w), dt, model)}
+                              "%d process(es) x %d random angle lines x %d bands in %.1f s; cpu: %s"
+                              % (procs, n, len(w), dt, model)}
         except Exception as ex:                      # fall through to the port
             print("cpu_baseline: reference run failed (%s); using the oracle port" % ex, file=sys.stderr)
     from oracle import oracle as O
@@ -232,9 +243,12 @@ def main():
         if allgather_ms is not None:
             out["allgather_ms"] = allgather_ms
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            # all host cores of the box's share (16 per GPU on this pool), one reference process per core
+            ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
+            out["cpu_baseline"] = cpu_baseline(wl, budget_s=15.0, procs=ncores)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             if out["cpu_baseline"]["kind"] == "reference":
+                out["cpu_baseline_1core"] = cpu_baseline(wl, budget_s=8.0, procs=1)
                 # additionally: our own hoisted scalar-C restatement (no text I/O), the strongest 1-core CPU number we have
                 out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
         print(json.dumps(out), flush=True)
