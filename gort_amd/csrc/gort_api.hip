@@ -311,12 +311,20 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if (rc) return rc;
     if (nA < 0 || (nA > 0 && (!angles_dev || !rsurf_dev))) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
     if (nA == 0) return GORT_OK;
-    rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA);
-    if (rc) return rc;
+    // line records with one pad record in front and a tail pad (the aligned flat expansion prefetches)
+    const long tail = expand_stream_tail_pad_records(e->nw, nA);
+    const size_t coef_bytes = sizeof(double) * GORT_COEF_STRIDE * (size_t)(nA + 1 + tail);
+    const bool fresh = coef_bytes > e->coef.cap;
+    if ((rc = e->coef.reserve(coef_bytes))) return rc;
+    if (fresh) GORT_HIP(hipMemsetAsync(e->coef.p, 0, coef_bytes, e->stream));      // pads hold finite values
+    double *coef = e->coef.as<double>() + GORT_COEF_STRIDE;
+    if ((rc = e->xcd_slots.reserve(sizeof(int) * 16))) return rc;
+    GORT_HIP(hipMemsetAsync(e->xcd_slots.p, 0, sizeof(int) * 16, e->stream));
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
-    rc = launch_geometry_stream(c, angles_dev, nA, e->coef.as<double>(), K_dev, e->stream);
+    rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, e->stream);
     if (rc) return rc;
-    return launch_expand_stream(c, e->L.as<double>(), e->nw, e->coef.as<double>(), nA, rsurf_dev, scomp_dev, e->stream);
+    return launch_expand_stream(c, e->L.as<double>(), e->nw, coef, nA, rsurf_dev, scomp_dev, e->xcd_slots.as<int>(),
+                                e->stream);
 }
 
 extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, double *rsurf, double *scomp,
@@ -357,7 +365,8 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         if (e->n_members != 1) return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: needs nw >= 128 bands");
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
-        return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, e->stream);
+        return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr,
+                                    e->stream);
     }
     // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel)
     const long tail = expand_grid_tail_pad_records(nw, nA * (long)nw);

@@ -770,6 +770,133 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
         flat_loop<DEPTH, NT, false>(st, sun, isza_base, nw, angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
 }
 
+// The aligned flat form for ARBITRARY angle lines (every line has its own sun zenith): same chunking and
+// band-preserving stride as expand_flat_kernel, but a lane keeps the 11 BAND terms of its two bands in
+// registers and forms the five (sun, band) terms per step from the line's sun scalars, which travel in the
+// same 128-B record as the five coefficients (scalar loads).  Per sample ~45 flops + half an fp64 division on
+// top of the store; rows of nw doubles are never 128-B aligned in the band-major kernels above.
+// coef: stream records (GORT_COEF_STRIDE doubles), one pad record in front, tail pad behind.
+template <bool NT, bool WRAP>
+__device__ __forceinline__ void flat_stream_loop(const BandTerms (&t)[EPL], const int (&wrapped)[EPL],
+                                                 const int (&k_begin)[EPL], const int (&k_end)[EPL], double ko,
+                                                 double kep, int da, long step, int k_wave,
+                                                 const double *__restrict__ rec_w, double *__restrict__ out_w,
+                                                 int lane)
+{
+    const long rec_step = (long)da * GORT_COEF_STRIDE;
+    const int kb_all = k_begin[0] > k_begin[1] ? k_begin[0] : k_begin[1];
+    const int ke_all = k_end[0] < k_end[1] ? k_end[0] : k_end[1];
+    // current record(s) in registers, the next one in flight
+    double cur[2][10], nxt[2][10];
+    constexpr int slots[10] = {A_C, A_B, A_Z, A_G, A_T, S_FD, S_MU, S_T0, S_TP0, S_EPS};
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        cur[0][q] = rec_w[slots[q]];
+        cur[1][q] = WRAP ? rec_w[GORT_COEF_STRIDE + slots[q]] : 0.0;
+    }
+    rec_w += rec_step;
+    for (int kk = 0; kk < k_wave; ++kk) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            nxt[0][q] = rec_w[slots[q]];
+            nxt[1][q] = WRAP ? rec_w[GORT_COEF_STRIDE + slots[q]] : 0.0;
+        }
+        rec_w += rec_step;
+        double v[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            double vv[2];
+#pragma unroll
+            for (int w = 0; w < (WRAP ? 2 : 1); ++w) {
+                SunScalars s;
+                s.fd = cur[w][5];  s.mu = cur[w][6];  s.t0 = cur[w][7];  s.tp0 = cur[w][8];  s.eps = cur[w][9];
+                s.pn0 = 0.0;
+                const SunTerms b = sun_terms(t[j], s, ko, kep);
+                vv[w] = dot5(cur[w][0], cur[w][1], cur[w][2], cur[w][3], cur[w][4], b.C0, b.B, b.Z, b.G, b.T);
+            }
+            v[j] = (WRAP && wrapped[j]) ? vv[1] : vv[0];
+        }
+        double *o = out_w + EPL * lane;
+        if (kk >= kb_all && kk < ke_all) {
+            dbl2 x;
+            x.x = v[0];
+            x.y = v[1];
+            if (NT) __builtin_nontemporal_store(x, reinterpret_cast<dbl2 *>(o));
+            else *reinterpret_cast<dbl2 *>(o) = x;
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j)
+                if (kk >= k_begin[j] && kk < k_end[j]) o[j] = v[j];
+        }
+        out_w += step;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { cur[0][q] = nxt[0][q];  cur[1][q] = nxt[1][q]; }
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256) void expand_flat_stream_kernel(const gort_canopy *__restrict__ canopy,
+                                                                  const double *__restrict__ L, int nw,
+                                                                  const double *__restrict__ coef, long n_total,
+                                                                  int shift, long stride_chunks,
+                                                                  double *__restrict__ out, int xcd_mode,
+                                                                  int *__restrict__ xcd_slots)
+{
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    long block = blockIdx.x;
+    const long nb = gridDim.x, base = nb >> 3, rem = nb & 7;
+    if (xcd_mode == 1) {
+        const long x = block & 7;
+        block = x * base + (x < rem ? x : rem) + (block >> 3);
+    } else if (xcd_mode == 2) {               // see expand_flat_kernel
+        __shared__ long s_block;
+        if (threadIdx.x == 0) {
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            long Lb = -1;
+            for (int q = 0; q < 8 && Lb < 0; ++q) {
+                const long y = (x + q) & 7;
+                const long quota = base + (y < rem ? 1 : 0);
+                const long sl = atomicAdd(&xcd_slots[y], 1);
+                if (sl < quota) Lb = y * base + (y < rem ? y : rem) + sl;
+            }
+            s_block = Lb;
+        }
+        __syncthreads();
+        block = s_block;
+        if (block < 0) return;
+    }
+    const long wave = block * 4 + wave_in_block;
+    if (wave >= stride_chunks) return;
+    const int lane = threadIdx.x & 63;
+    const long step = stride_chunks * CHUNK;       // a multiple of nw
+    const int da = (int)(step / nw);               // angle lines per step
+    const long e0 = wave * CHUNK - shift;
+    if (e0 >= n_total) return;
+    const long a_w = (e0 + step) / nw - da;        // >= -1
+    const int band_w = (int)((e0 + step) % nw);
+    const int k_wave = (int)((n_total - 1 - (e0 < 0 ? 0 : e0)) / step) + 1;
+    BandTerms t[EPL];
+    int wrapped[EPL], k_begin[EPL], k_end[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        int band = band_w + EPL * lane + j;
+        wrapped[j] = 0;
+        if (band >= nw) { band -= nw; wrapped[j] = 1; }
+        const long n_el = e0 + EPL * lane + j;
+        k_begin[j] = n_el < 0 ? 1 : 0;
+        k_end[j] = n_el < n_total ? (int)((n_total - 1 - n_el) / step) + 1 : 0;
+        t[j] = load_band(L, nw, band);
+    }
+    const double *rec_w = coef + a_w * GORT_COEF_STRIDE;
+    double *out_w = out + e0;
+    const double ko = canopy->k_open, kep = canopy->k_openep;
+    if (band_w + CHUNK - 1 >= nw)
+        flat_stream_loop<NT, true>(t, wrapped, k_begin, k_end, ko, kep, da, step, k_wave, rec_w, out_w, lane);
+    else
+        flat_stream_loop<NT, false>(t, wrapped, k_begin, k_end, ko, kep, da, step, k_wave, rec_w, out_w, lane);
+}
+
 // ------------------------------------------------------------- albedo / energy
 
 // One 512-thread workgroup per angle line = the 32 x 16 Gauss-Legendre nodes of the
@@ -892,12 +1019,19 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
     return check_launch("geometry_grid_kernel");
 }
 
+static bool stream_uses_flat(int nw, long nA, bool want_scomp);
+static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double *L_dev, int nw,
+                                     const double *coef_dev, long nA, double *rsurf_dev, int *xcd_slots_dev,
+                                     hipStream_t s);
+
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
-                         double *rsurf_dev, double *scomp_dev, void *stream)
+                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream)
 {
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (xcd_slots_dev && stream_uses_flat(nw, nA, scomp_dev != nullptr))
+        return launch_expand_stream_flat(canopy_dev, L_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, s);
     const long groups = (nA + STREAM_LINES - 1) / STREAM_LINES;
     if (nw >= 64 && groups <= 65535) {
         const dim3 grid((unsigned)((nw + 255) / 256), (unsigned)groups), block(256);
@@ -1050,6 +1184,39 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
     }
 #undef GORT_FLAT
     return check_launch("expand_flat_kernel");
+}
+
+// ---- aligned flat form of the stream expansion: large, wide streams without component spectra ----
+static bool stream_uses_flat(int nw, long nA, bool want_scomp)
+{
+    return tuning().flat && !want_scomp && nw >= CHUNK && nA * (long)nw >= (1L << 22);
+}
+
+// readable records the stream expansion may touch behind the last line (the caller also keeps ONE in front)
+long expand_stream_tail_pad_records(int nw, long nA)
+{
+    if (!stream_uses_flat(nw, nA, false)) return 0;
+    const long stride = flat_stride(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK);
+    return stride * CHUNK / nw + 4;       // one step of prefetch (da lines) + wrap record + slack
+}
+
+static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double *L_dev, int nw,
+                                     const double *coef_dev, long nA, double *rsurf_dev, int *xcd_slots_dev,
+                                     hipStream_t s)
+{
+    const ExpandTuning &tune = tuning();
+    const long n_total = nA * (long)nw;
+    const int shift = (int)((reinterpret_cast<uintptr_t>(rsurf_dev) / sizeof(double)) % CHUNK);
+    const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
+    const long stride = flat_stride(nw, chunks);
+    const dim3 grid((unsigned)((stride + 3) / 4));
+    if (tune.nt)
+        hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
+                           n_total, shift, stride, rsurf_dev, tune.xcd_mode, xcd_slots_dev);
+    else
+        hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
+                           n_total, shift, stride, rsurf_dev, tune.xcd_mode, xcd_slots_dev);
+    return check_launch("expand_flat_stream_kernel");
 }
 
 int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,

@@ -64,8 +64,12 @@ int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_d
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream);
+// coef_dev: stream records (GORT_COEF_STRIDE doubles each) with ONE readable pad record in front and
+// expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: 8 ints zeroed on `stream` before the
+// call, or nullptr to keep to the band-major kernels
+long expand_stream_tail_pad_records(int nw, long nA);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
-                         long nA, double *rsurf_dev, double *scomp_dev, void *stream);
+                         long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream);
 // sun rows q = member * nsza + isza, q in [q_begin, q_end): sun_dev[q - q_begin][5][nw]
 int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int nw, const gort_grid &g,
                      int q_begin, int q_end, double *sun_dev, void *stream);

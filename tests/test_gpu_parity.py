@@ -197,6 +197,31 @@ def test_brdf_fuzz_random_canopies_angles_bands(eng):
     print("BRDF fuzz: worst relative error %.2e" % worst)
 
 
+def test_wide_stream_aligned_flat_path(eng):
+    """Streams of >= 4M samples without component spectra go through expand_flat_stream_kernel (aligned 1-KiB
+    chunks, per-line sun terms).  2500 random lines x 2101 bands, every sample against the oracle; and the
+    same lines WITH component spectra (band-major kernel) must give the same rsurf."""
+    rng = np.random.default_rng(5150)
+    n = 2500
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), rng.uniform(0, 360, n)], 1)
+    wl = np.arange(400.0, 2501.0)
+    c = gpu_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_canopy(c); eng.set_spectra(rs, rl, tl)
+    r, _, K = eng.rsurf_stream(ang)
+    ro, _, Ko = O.rsurf_stream(oracle_like(c), ang, rs, rl, tl)
+    assert err(r, ro) <= REGRESSION and err_K(K, Ko) <= REGRESSION
+    r2, sc, _ = eng.rsurf_stream(ang, want_scomp=True)
+    assert np.array_equal(r.view(np.int64), r2.view(np.int64))      # both kernels share dot5/sun_terms
+    # ragged size that does not fill the last chunk, odd band count below the native grid
+    wl3 = np.linspace(400.0, 2500.0, 1999)
+    rs, rl, tl = api.spectra(wl3)
+    eng.set_spectra(rs, rl, tl)
+    r, _, _ = eng.rsurf_stream(ang[:2111], want_K=False)
+    ro, _, _ = O.rsurf_stream(oracle_like(c), ang[:2111], rs, rl, tl, want_K=False)
+    assert err(r, ro) <= REGRESSION
+
+
 def test_stream_edge_cases(eng):
     eng.set_canopy(gpu_canopy(lai=4.0))
     eng.set_spectra(*api.spectra([800.0]))
