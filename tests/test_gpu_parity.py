@@ -448,6 +448,24 @@ def test_lut_kernel_variants_bitwise_identical():
     assert len(set(digests)) == 1, list(zip(envs, digests))
 
 
+def test_bench_two_ranks_rehearsal():
+    """The N>1 code path of bench.py (row slabs, max-over-ranks timing, optional all-gather) with two ranks
+    sharing this GPU over gloo - everything of the multi-GPU run except RCCL itself."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--nsza", "3", "--rehearse", "--gather",
+                          "--no-cpu-baseline"], capture_output=True, timeout=600)
+    assert run.returncode == 0, run.stderr.decode()[-3000:]
+    lines = [l for l in run.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 1e8
+    assert "2 contiguous slabs" in d["config"]["sharding"] and d["allgather_ms"] > 0
+    assert d["parity"]["nan_pattern_equal"] and d["parity"]["max_rel_err"] <= 1e-9
+    assert "cpu_baseline" not in d
+
+
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the driver's keys plus roofline/parity (reduced grid, 2 steps)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
