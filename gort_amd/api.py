@@ -68,6 +68,7 @@ DECLARED_SYMBOLS = [
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
     "gort_rsurf_members_grid_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
+    "gort_engine_xcd_mapping",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
 ]
 
@@ -100,7 +101,7 @@ def lib():
         L.gort_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gort_engine_create.argtypes = [C.POINTER(C.c_void_p)]
         for name in ("gort_engine_destroy", "gort_engine_synchronize", "gort_engine_stream", "gort_engine_nw",
-                     "gort_engine_last_expand_ms"):
+                     "gort_engine_last_expand_ms", "gort_engine_xcd_mapping"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.gort_engine_set_canopy.argtypes = [C.c_void_p, C.POINTER(Canopy)]
         L.gort_engine_set_spectra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -338,6 +339,13 @@ class Engine:
 
     def last_expand_ms(self):
         return lib().gort_engine_last_expand_ms(self.h)
+
+    def xcd_mapping(self):
+        """'static' where workgroup dispatch was probed to be round-robin over the XCDs, else 'slots'."""
+        m = lib().gort_engine_xcd_mapping(self.h)
+        if m < 0:
+            _check(-m)
+        return {1: "static", 2: "slots"}[m]
 
     def energy_stream(self, angles_deg):
         ang = _f64(angles_deg).reshape(-1, 4)

@@ -57,7 +57,8 @@ struct gort_engine {
     size_t ev_used = 0;
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
-    DevBuf xcd_slots;                    // 9 ints: per-XCD slot counters + arrival counter of expand_flat_kernel
+    DevBuf xcd_slots;                    // XCD_SLOT_BYTES: per-XCD slot counters of the flat expansion kernels
+    int xcd_round_robin = -1;            // probe_xcd_dispatch(): -1 not probed yet, 0 no, 1 yes
     int n_members = 1;
     bool have_canopy = false, have_spectra = false, have_nodes = false, have_tables = false;
     int nw = 0;
@@ -151,6 +152,34 @@ extern "C" void gort_engine_destroy(gort_engine *e)
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+}
+
+// Slot counters for one flat expansion launch, zeroed on the stream - or nullptr where workgroup dispatch is
+// round-robin over the XCDs, probed once per engine (the static mapping is then exact and free of atomics).
+static int xcd_slots_for_launch(gort_engine *e, int **slots)
+{
+    *slots = nullptr;
+    if (e->xcd_round_robin < 0) {
+        int rr = 0;
+        const int rc = probe_xcd_dispatch(e->stream, &rr);
+        if (rc) return rc;
+        e->xcd_round_robin = rr;
+    }
+    if (!expand_wants_xcd_slots(e->xcd_round_robin == 1)) return GORT_OK;
+    const int rc = e->xcd_slots.reserve(XCD_SLOT_BYTES);
+    if (rc) return rc;
+    GORT_HIP(hipMemsetAsync(e->xcd_slots.p, 0, XCD_SLOT_BYTES, e->stream));
+    *slots = e->xcd_slots.as<int>();
+    return GORT_OK;
+}
+
+extern "C" int gort_engine_xcd_mapping(gort_engine *e)
+{
+    if (!e) return fail(GORT_EINVAL, "gort_engine_xcd_mapping: null engine");
+    int *slots = nullptr;
+    const int rc = xcd_slots_for_launch(e, &slots);
+    if (rc) return -rc;
+    return slots ? 2 : 1;
 }
 
 extern "C" void *gort_engine_stream(gort_engine *e) { return e ? (void *)e->stream : nullptr; }
@@ -318,13 +347,12 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if ((rc = e->coef.reserve(coef_bytes))) return rc;
     if (fresh) GORT_HIP(hipMemsetAsync(e->coef.p, 0, coef_bytes, e->stream));      // pads hold finite values
     double *coef = e->coef.as<double>() + GORT_COEF_STRIDE;
-    if ((rc = e->xcd_slots.reserve(sizeof(int) * 16))) return rc;
-    GORT_HIP(hipMemsetAsync(e->xcd_slots.p, 0, sizeof(int) * 16, e->stream));
+    int *xcd_slots = nullptr;
+    if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
     rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, e->stream);
     if (rc) return rc;
-    return launch_expand_stream(c, e->L.as<double>(), e->nw, coef, nA, rsurf_dev, scomp_dev, e->xcd_slots.as<int>(),
-                                e->stream);
+    return launch_expand_stream(c, e->L.as<double>(), e->nw, coef, nA, rsurf_dev, scomp_dev, xcd_slots, e->stream);
 }
 
 extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, double *rsurf, double *scomp,
@@ -380,8 +408,8 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     const int q0 = (int)(row_begin / g->nvza), q1 = (int)((row_end - 1) / g->nvza) + 1;
     if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(q1 - q0)))) return rc;
     if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, e->sun.as<double>(), e->stream))) return rc;
-    if ((rc = e->xcd_slots.reserve(sizeof(int) * 16))) return rc;
-    GORT_HIP(hipMemsetAsync(e->xcd_slots.p, 0, sizeof(int) * 16, e->stream));       // per-XCD slot counters
+    int *xcd_slots = nullptr;
+    if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to
     // 512 launches are kept between two gort_engine_last_expand_ms() calls
     const bool timed = e->ev_used + 2 <= 1024;
@@ -394,7 +422,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
     rc = launch_expand_grid(e->sun.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
-                            e->xcd_slots.as<int>(), e->stream);
+                            xcd_slots, e->stream);
     if (timed) {
         GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;

@@ -692,7 +692,8 @@ template <int DEPTH, bool NT>
 __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restrict__ sun, int isza_base,
                                                            const double *__restrict__ coef, int nw,
                                                            int angles_per_sza, long angle0, long n_total, int shift,
-                                                           long stride_chunks, double *__restrict__ lut, int xcd_mode,
+                                                           long stride_chunks, int da, int steps_per_wave,
+                                                           double *__restrict__ lut, int xcd_mode,
                                                            int *__restrict__ xcd_slots)
 {
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -718,7 +719,7 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
             for (int t = 0; t < 8 && L < 0; ++t) {
                 const long y = (x + t) & 7;
                 const long quota = base + (y < rem ? 1 : 0);
-                const long s = atomicAdd(&xcd_slots[y], 1);
+                const long s = atomicAdd(&xcd_slots[y * XCD_SLOT_PITCH], 1);
                 if (s < quota) L = y * base + (y < rem ? y : rem) + s;
             }
             s_block = L;
@@ -727,33 +728,62 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
         block = s_block;
         if (block < 0) return;      // cannot happen (pigeonhole); never index out of the slab
     }
-    const long wave = block * 4 + wave_in_block;                              // scalar
-    if (wave >= stride_chunks) return;
+    // panels of steps_per_wave x stride chunks: wave (panel, w) takes chunks panel*K*stride + w + k*stride, k < K
+    // All of the wave's index arithmetic is wave-uniform and, but for one division, 32-bit: a wave of a short
+    // panel lives for a few dozen stores, so its prologue counts.
+    const unsigned wave = (unsigned)(block * 4 + wave_in_block);              // scalar
+    const unsigned stride = (unsigned)stride_chunks;
+    const unsigned panel = wave / stride;
+    const unsigned w_in_panel = wave - panel * stride;
     const int lane = threadIdx.x & 63;
-    const long step = stride_chunks * CHUNK;       // elements per step; a multiple of nw
-    const int da = (int)(step / nw);               // angles per step
-    const long e0 = wave * CHUNK - shift;          // element index of the chunk start at step 0 (< 0 only for wave 0)
-    if (e0 >= n_total) return;
-    // angle and band of the chunk start at step 0; floor division that also works for e0 < 0
-    const long a_w = (e0 + step) / nw - da;        // scalar, >= -1
-    const int band_w = (int)((e0 + step) % nw);
-    const int k_wave = (int)((n_total - 1 - (e0 < 0 ? 0 : e0)) / step) + 1;    // scalar upper bound over lanes
+    const long step = stride_chunks * CHUNK;       // elements per step = da * nw
+    // chunk index at step 0, counted from the aligned chunk that holds element 0 (the slab starts `shift`
+    // elements into chunk 0), and the chunk / offset of the slab's last element
+    const long c0 = (long)panel * steps_per_wave * stride_chunks + w_in_panel;
+    const long last = n_total - 1 + shift;
+    const long last_chunk = last / CHUNK;
+    const int last_off = (int)(last % CHUNK);
+    if (c0 > last_chunk) return;
+    const long e0 = c0 * CHUNK - shift;            // element index of the chunk start at step 0 (< 0 only for chunk 0)
+    // angle and band of the chunk start at step 0: a panel starts a whole number of angles into the slab,
+    // and the rest, taken one step ahead to stay positive, is below 2 step < 2^31
+    const unsigned local = w_in_panel * CHUNK + (unsigned)step - (unsigned)shift;
+    const unsigned a_loc = local / (unsigned)nw;
+    const int band_w = (int)(local - a_loc * (unsigned)nw);
+    const long a_w = (long)panel * steps_per_wave * da + a_loc - da;          // scalar, >= -1
+    // steps until the wave's chunk passes the end of the slab (only the last panel's waves run out)
+    const long rel = last_chunk - c0;
+    const bool runs_out = rel < (long)steps_per_wave * stride_chunks;
+    unsigned k_last = 0;
+    bool ends_in_last_chunk = false;
+    if (runs_out) {
+        k_last = (unsigned)rel / stride;
+        ends_in_last_chunk = (unsigned)rel == k_last * stride;
+    }
+    const int k_wave = runs_out ? (int)k_last + 1 : steps_per_wave;           // scalar upper bound over lanes
+    // sun zenith of the angle a_w: the one 64-bit division
+    const long A0 = angle0 + a_w;                                             // >= -1
+    int isza_w = -1, rem_w = angles_per_sza - 1;
+    if (A0 >= 0) {
+        const long q = A0 / angles_per_sza;
+        isza_w = (int)q;
+        rem_w = (int)(A0 - q * angles_per_sza);
+    }
 
     FlatLane st;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
-        int band = band_w + EPL * lane + j;
+        const int off = EPL * lane + j;
+        int band = band_w + off;
         st.wrapped[j] = 0;
         if (band >= nw) { band -= nw; st.wrapped[j] = 1; }                    // nw >= CHUNK on this path: one wrap at most
         st.band[j] = band;
-        const long n_el = e0 + EPL * lane + j;
-        st.k_begin[j] = n_el < 0 ? 1 : 0;
-        st.k_end[j] = n_el < n_total ? (int)((n_total - 1 - n_el) / step) + 1 : 0;      // first invalid step
-        // sun zenith of this element's angle, tracked incrementally in 32-bit from "as if at step 0"
-        const long ag = angle0 + a_w + st.wrapped[j] + (long)st.k_begin[j] * da;
-        int isza = (int)(ag / angles_per_sza);
-        int rem = (int)(ag - (long)isza * angles_per_sza) - st.k_begin[j] * da;
-        if (rem < 0) { rem += angles_per_sza; --isza; }
+        st.k_begin[j] = (c0 == 0 && off < shift) ? 1 : 0;                     // in front of the slab at step 0
+        // first invalid step
+        st.k_end[j] = runs_out ? (int)k_last + ((!ends_in_last_chunk || off <= last_off) ? 1 : 0) : steps_per_wave;
+        // sun zenith of this element's angle, tracked incrementally from step 0
+        int isza = isza_w, rem = rem_w + st.wrapped[j];
+        if (rem >= angles_per_sza) { rem -= angles_per_sza; ++isza; }
         st.isza[j] = isza;                                                    // isza_base - 1 only for elements invalid at step 0
         st.rem[j] = rem;
         const bool live = st.k_end[j] > st.k_begin[j] && isza >= isza_base;   // else the first crossing loads them
@@ -857,7 +887,7 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const gort_cano
             for (int q = 0; q < 8 && Lb < 0; ++q) {
                 const long y = (x + q) & 7;
                 const long quota = base + (y < rem ? 1 : 0);
-                const long sl = atomicAdd(&xcd_slots[y], 1);
+                const long sl = atomicAdd(&xcd_slots[y * XCD_SLOT_PITCH], 1);
                 if (sl < quota) Lb = y * base + (y < rem ? y : rem) + sl;
             }
             s_block = Lb;
@@ -1030,7 +1060,7 @@ int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (xcd_slots_dev && stream_uses_flat(nw, nA, scomp_dev != nullptr))
+    if (stream_uses_flat(nw, nA, scomp_dev != nullptr))
         return launch_expand_stream_flat(canopy_dev, L_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, s);
     const long groups = (nA + STREAM_LINES - 1) / STREAM_LINES;
     if (nw >= 64 && groups <= 65535) {
@@ -1068,26 +1098,45 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 //   GORT_EXPAND_VARIANT  flat (default) | row     kernel form, see the two kernels above
 //   GORT_EXPAND_DEPTH    1 | 2 | 4                coefficient records in flight per lane (flat)
 //   GORT_EXPAND_NT       1 | 0                    non-temporal stores
-//   GORT_EXPAND_WAVES    target number of waves   (flat; rounded to a band-preserving stride)
+//   GORT_EXPAND_WAVES    target wave stride of expand_flat_kernel in chunks = waves per panel (rounded to a
+//                        band-preserving multiple of nw/gcd(nw,128))
+//   GORT_EXPAND_STEPS    steps per wave = panel height; 0 = one panel, every wave strides through the whole slab
+//   GORT_EXPAND_XCD      0 | 1 | 2                XCD mapping, see below; default automatic
+//   GORT_STREAM_WAVES    target number of waves of expand_flat_stream_kernel
+// Measured on the 50.25 GB metric slab, four slabs held at once per run (profiles/r01/tune_panels*.log):
+//   whole-slab strides (steps 0, stride 33616)   8.1-8.3 ms, 9.5 ms on some allocations
+//   panels of 6 steps x 2101 waves, XCD mode 1   7.04-7.30 ms (6.9-7.1 TB/s), 7.8 ms on some allocations
+//   the same with 4 steps                        7.8 ms on every allocation (prologue-bound)
+//   the same, XCD mode 0 (interleaved)           8.2 ms
+//   XCD mode 2 with panels                       one returning atomic per workgroup costs ~190 ns on its
+//                                                counter's line: 9.2 ms at 16 steps before the counters were
+//                                                spread over 8 lines, then fine from 8 steps up
+// The spread between allocations of one size is a property of where the slab lies physically (the same slab
+// is slow or fast at any offset and for the whole run); short panels narrow it from 18 % to 10 %.
 struct ExpandTuning {
     bool flat = true, nt = true;
-    // GORT_EXPAND_XCD: 0 = chunk ranges interleaved over the XCDs, 1 = contiguous range per XCD assuming
-    // round-robin dispatch, 2 = contiguous range per XCD by the real XCC_ID (default).
-    // Interleaved A/B on one box: 8.07-8.14 ms with mode 1, 9.38-9.48 ms with mode 0 (profiles/r01/tune_xcd.log)
-    int xcd_mode = 2;
+    // GORT_EXPAND_XCD: 0 = logical blocks interleaved over the XCDs, 1 = one contiguous range per XCD assuming
+    // round-robin dispatch, 2 = the same by the real XCC_ID through per-XCD slot counters;
+    // -1 = automatic: 1 where dispatch is round-robin over the XCDs (probed once per engine), else 2
+    int xcd_mode = -1;
     int depth = 2;
-    long waves = 32768;     // 50 GB slab, XCD-contiguous, interleaved A/B (profiles/r01/tune_flat_kernel.log):
-                            // 8404 -> 8.9 ms, 16808 -> 8.5-9.1 (noisy), 25212/33616 -> 7.95-7.97, 67232 -> 9.5
+    int steps = -1;             // -1 = automatic: 6 with the static mapping, 16 with slot counters (fewer atomics)
+    long waves = 2048;
+    long stream_waves = 32768;
     ExpandTuning()
     {
         if (const char *v = getenv("GORT_EXPAND_VARIANT")) flat = strcmp(v, "row") != 0;
         if (const char *v = getenv("GORT_EXPAND_NT")) nt = atoi(v) != 0;
         if (const char *v = getenv("GORT_EXPAND_DEPTH")) depth = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_WAVES")) waves = atol(v);
+        if (const char *v = getenv("GORT_STREAM_WAVES")) stream_waves = atol(v);
         if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_mode = atoi(v);
-        if (xcd_mode < 0 || xcd_mode > 2) xcd_mode = 2;
+        if (const char *v = getenv("GORT_EXPAND_STEPS")) steps = atoi(v);
+        if (xcd_mode < -1 || xcd_mode > 2) xcd_mode = -1;
         if (depth != 1 && depth != 2 && depth != 4) depth = 2;
+        if (steps > 0) steps = (steps + depth - 1) / depth * depth;        // whole groups of DEPTH
         if (waves < 64) waves = 64;
+        if (stream_waves < 64) stream_waves = 64;
     }
 };
 
@@ -1128,11 +1177,60 @@ static const ExpandTuning &tuning()
     return t;
 }
 
+// XCD mapping of a flat launch: without slot counters only the static forms are possible
+static int resolve_xcd_mode(const int *xcd_slots_dev)
+{
+    const int m = tuning().xcd_mode;
+    if (m < 0) return xcd_slots_dev ? 2 : 1;
+    return (m == 2 && !xcd_slots_dev) ? 1 : m;
+}
+
+bool expand_wants_xcd_slots(bool dispatch_round_robin)
+{
+    const int m = tuning().xcd_mode;
+    return m == 2 || (m < 0 && !dispatch_round_robin);
+}
+
+// Are workgroups b, b+8, b+16, ... of a launch placed on one XCD each (round-robin dispatch, the documented
+// behaviour of the multi-XCD dispatcher)?  Then the static mapping of the flat kernels is exact and needs no
+// atomics.  A profiler or a partition mode may change the pattern, hence the probe rather than an assumption.
+namespace {
+__global__ void xcd_probe_kernel(int *__restrict__ xcc_of_block)
+{
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcc_of_block[blockIdx.x] = (int)(x & 7);
+    }
+}
+}  // namespace
+
+int probe_xcd_dispatch(void *stream, int *round_robin)
+{
+    constexpr int NB = 4096;
+    *round_robin = 0;
+    int *dev = nullptr;
+    if (hipMalloc(&dev, sizeof(int) * NB) != hipSuccess) return fail(GORT_ENOMEM, "xcd probe: hipMalloc failed");
+    int host[NB];
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(NB), dim3(256), 0, s, dev);
+    hipError_t err = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
+    (void)hipFree(dev);
+    if (err != hipSuccess) return fail(GORT_ENODEVICE, "xcd probe: %s", hipGetErrorString(err));
+    unsigned seen = 0;
+    for (int b = 0; b < 8; ++b) seen |= 1u << host[b];
+    bool ok = seen == 0xffu;
+    for (int b = 8; b < NB && ok; ++b) ok = host[b] == host[b & 7];
+    *round_robin = ok ? 1 : 0;
+    return GORT_OK;
+}
+
 // chunk stride (in 1-KiB chunks) of the flat kernel: a multiple of nw/gcd(nw,CHUNK) close to the wave target
-static long flat_stride(int nw, long chunks)
+static long flat_stride(int nw, long chunks, long target)
 {
     const long unit = nw / gcd_long(nw, CHUNK);
-    long mult = (tuning().waves + unit / 2) / unit;
+    long mult = (target + unit / 2) / unit;
     if (mult < 1) mult = 1;
     long stride = unit * mult;
     if (stride > chunks) stride = unit * ((chunks + unit - 1) / unit);       // tiny slab: one step per wave
@@ -1143,9 +1241,9 @@ static long flat_stride(int nw, long chunks)
 long expand_grid_tail_pad_records(int nw, long n_total)
 {
     if (!tuning().flat) return 0;
-    const long stride = flat_stride(nw, (n_total + 2 * CHUNK - 2) / CHUNK);
+    const long stride = flat_stride(nw, (n_total + 2 * CHUNK - 2) / CHUNK, tuning().waves);
     const long da = stride * CHUNK / nw;
-    return 8 * da + 9;      // the k loop runs in groups of DEPTH <= 4 and prefetches DEPTH steps ahead (+1: wrap record)
+    return 12 * da + 9;     // the k loop runs in groups of DEPTH <= 4 and prefetches DEPTH steps ahead (+1: wrap record)
 }
 
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
@@ -1169,14 +1267,25 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
     const long n_total = rows * nphi * (long)nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(lut_dev) / sizeof(double)) % CHUNK);
     const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
-    const long stride = flat_stride(nw, chunks);
-    const dim3 grid((unsigned)((stride + 3) / 4));
+    const long stride = flat_stride(nw, chunks, tune.waves);
+    const int xcd_mode = resolve_xcd_mode(xcd_slots_dev);
+    // panel height: short panels keep the eight write windows compact; with slot counters every workgroup
+    // pays a returning atomic, so there the panels are taller (fewer workgroups)
+    int steps = tune.steps;
+    if (steps < 0) steps = xcd_mode == 2 ? 16 : (6 + tune.depth - 1) / tune.depth * tune.depth;
+    const long panels = steps > 0 ? (chunks + (long)steps * stride - 1) / ((long)steps * stride) : 1;
+    if (steps == 0) steps = 1 << 30;
+    if (panels * stride >= (1L << 31) || chunks >= (1L << 31) || stride * CHUNK >= (1L << 30))
+        return fail(GORT_EINVAL, "expand_grid: slab of %ld chunks in %ld waves is beyond the kernel's 32-bit indices",
+                    chunks, panels * stride);
+    const int da = (int)(stride * CHUNK / nw);          // angles per step (the stride is a multiple of nw/gcd(nw,CHUNK))
+    const dim3 grid((unsigned)((panels * stride + 3) / 4));
     const int angles_per_sza = nvza * nphi;
     const long angle0 = row_begin * nphi;
 #define GORT_FLAT(D, N)                                                                                           \
     hipLaunchKernelGGL((expand_flat_kernel<D, N>), grid, dim3(256), 0, s, sun_dev, isza_base, coef_dev, nw,      \
-                       angles_per_sza, angle0, n_total, shift, stride, lut_dev, xcd_slots_dev ? tune.xcd_mode : 1,   \
-                       xcd_slots_dev)
+                       angles_per_sza, angle0, n_total, shift, stride, da, steps, lut_dev,                       \
+                       xcd_mode, xcd_slots_dev)
     if (tune.nt) {
         if (tune.depth == 1) GORT_FLAT(1, true); else if (tune.depth == 2) GORT_FLAT(2, true); else GORT_FLAT(4, true);
     } else {
@@ -1196,7 +1305,7 @@ static bool stream_uses_flat(int nw, long nA, bool want_scomp)
 long expand_stream_tail_pad_records(int nw, long nA)
 {
     if (!stream_uses_flat(nw, nA, false)) return 0;
-    const long stride = flat_stride(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK);
+    const long stride = flat_stride(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK, tuning().stream_waves);
     return stride * CHUNK / nw + 4;       // one step of prefetch (da lines) + wrap record + slack
 }
 
@@ -1208,14 +1317,14 @@ static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double
     const long n_total = nA * (long)nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(rsurf_dev) / sizeof(double)) % CHUNK);
     const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
-    const long stride = flat_stride(nw, chunks);
+    const long stride = flat_stride(nw, chunks, tune.stream_waves);
     const dim3 grid((unsigned)((stride + 3) / 4));
     if (tune.nt)
         hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, tune.xcd_mode, xcd_slots_dev);
+                           n_total, shift, stride, rsurf_dev, resolve_xcd_mode(xcd_slots_dev), xcd_slots_dev);
     else
         hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, tune.xcd_mode, xcd_slots_dev);
+                           n_total, shift, stride, rsurf_dev, resolve_xcd_mode(xcd_slots_dev), xcd_slots_dev);
     return check_launch("expand_flat_stream_kernel");
 }
 

@@ -64,9 +64,17 @@ int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_d
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream);
+// per-XCD slot counters of the flat expansion kernels: 8 ints, one per 128-B line (XCD_SLOT_PITCH ints apart) so
+// that the eight XCDs' atomics do not serialise on one line; the caller zeroes XCD_SLOT_BYTES on the stream
+constexpr int XCD_SLOT_PITCH = 32;
+constexpr size_t XCD_SLOT_BYTES = sizeof(int) * 8 * XCD_SLOT_PITCH;
+// round_robin = 1 if workgroups b, b+8, ... of a launch share an XCD (then the static XCD mapping is exact);
+// expand_wants_xcd_slots: does the flat expansion need the slot counters (GORT_EXPAND_XCD or the probe says so)
+int probe_xcd_dispatch(void *stream, int *round_robin);
+bool expand_wants_xcd_slots(bool dispatch_round_robin);
 // coef_dev: stream records (GORT_COEF_STRIDE doubles each) with ONE readable pad record in front and
-// expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: 8 ints zeroed on `stream` before the
-// call, or nullptr to keep to the band-major kernels
+// expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the
+// call, or nullptr for the static XCD mapping
 long expand_stream_tail_pad_records(int nw, long nA);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
                          long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream);
@@ -76,8 +84,8 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 // coef_dev for launch_expand_grid: compact records, with ONE readable pad record in front of coef_dev
 // and expand_grid_tail_pad_records() readable records behind the last angle
 long expand_grid_tail_pad_records(int nw, long n_total);
-// xcd_slots_dev: 8 ints zeroed on `stream` before the call (per-XCD slot counters), or nullptr to fall back
-// to the static XCD guess
+// xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the call (per-XCD slot counters), or nullptr for the static
+// XCD mapping
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
                        long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, void *stream);
 // energy_dev[n_members][nA][nw][3]; members are canopies_dev[0..n) with L_dev[m][L_NSLOT][nw]

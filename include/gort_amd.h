@@ -194,6 +194,9 @@ int  gort_rsurf_members_grid_dev(gort_engine *e, const gort_grid *g, int member_
  * kernel over the launches since the last call, measured with HIP events on the
  * engine's stream; returns <0 if none. */
 double gort_engine_last_expand_ms(gort_engine *e);
+/* how the flat expansion kernels map workgroups to XCD-contiguous output ranges on this device: 1 = static
+ * (workgroup dispatch probed to be round-robin over the XCDs), 2 = per-XCD slot counters; <0 = -error */
+int  gort_engine_xcd_mapping(gort_engine *e);
 
 /* Spectral albedo, vegetation and soil absorption per angle line.  Replaces
  * gortt_energy/gortt_albedo (gortt_albedo.c:7-138): 32x16 Gauss-Legendre nodes over the

@@ -437,8 +437,11 @@ def test_lut_kernel_variants_bitwise_identical():
     """Every tuning variant of the LUT expansion (kernel form, XCD mapping mode, prefetch depth, wave count,
     store flavour) writes the same bytes: the knobs change speed only."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    envs = [{}, {"GORT_EXPAND_XCD": "0"}, {"GORT_EXPAND_XCD": "1"}, {"GORT_EXPAND_VARIANT": "row"},
-            {"GORT_EXPAND_DEPTH": "1", "GORT_EXPAND_WAVES": "500"}, {"GORT_EXPAND_DEPTH": "4", "GORT_EXPAND_NT": "0"}]
+    envs = [{}, {"GORT_EXPAND_XCD": "0"}, {"GORT_EXPAND_XCD": "1"}, {"GORT_EXPAND_XCD": "2"},
+            {"GORT_EXPAND_VARIANT": "row"},
+            {"GORT_EXPAND_DEPTH": "1", "GORT_EXPAND_WAVES": "500"}, {"GORT_EXPAND_DEPTH": "4", "GORT_EXPAND_NT": "0"},
+            {"GORT_EXPAND_STEPS": "0", "GORT_EXPAND_WAVES": "33616"}, {"GORT_EXPAND_STEPS": "2"},
+            {"GORT_EXPAND_STEPS": "10", "GORT_EXPAND_DEPTH": "4", "GORT_EXPAND_XCD": "2"}]
     digests = []
     for extra in envs:
         env = dict(os.environ); env.update(extra)
