@@ -592,11 +592,17 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 // 8 B off (tools/store_probe.hip) - and with nw = 2101 (odd) any band-major mapping is
 // 8-B aligned at best.  So the slab is cut into 1-KiB chunks (128 doubles) aligned in
 // ABSOLUTE address, one chunk per wave-step (16 B per lane, one global_store_dwordx4),
-// and wave w takes chunks w, w + W, w + 2W, ... where the stride W (in chunks) is a
+// and a wave takes chunks c, c + W, c + 2W, ... where the stride W (in chunks) is a
 // multiple of nw / gcd(nw, 128).  Then 128 W is a multiple of nw, so a lane keeps the
 // SAME two bands for its whole life (their five (sun zenith, band) terms stay in
 // registers, reloaded only when the lane's angle crosses into the next sun zenith) and
 // advances its angle by da = 128 W / nw per step.
+//
+// The slab is worked through in PANELS of K steps x W waves: wave (panel, w) writes chunks
+// panel K W + w + k W, k < K, so that a panel is K W consecutive chunks and each XCD's write
+// window stays compact (K = 6, W = 2101: 12 MiB) instead of combing through the whole slab
+// (7.1 against 7.9-9.5 ms for the 50 GB slab, and far less dependent on where the slab lies
+// physically - DESIGN.md 5.1).  Waves are short-lived, hence the lean prologue below.
 //
 // Everything that moves per step is wave-uniform and lives in SGPRs: the chunk's output
 // address and the address of the angle record, whose five coefficients arrive through
