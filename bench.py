@@ -237,7 +237,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "expand_flat_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "xcd_mapping": eng.xcd_mapping(),
+                         "xcd_mapping": eng.xcd_mapping(), "xcd_weights_32nds": eng.xcd_weights()[0],
                          "traffic": traffic, "traffic_source": traffic_src},
             "parity": parity,
         }

@@ -59,6 +59,9 @@ struct gort_engine {
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
     DevBuf xcd_slots;                    // XCD_SLOT_BYTES: per-XCD slot counters of the flat expansion kernels
     int xcd_round_robin = -1;            // probe_xcd_dispatch(): -1 not probed yet, 0 no, 1 yes
+    // duty weights of the XCDs (32nds) for the static mapping; calibrated on the first LUT slab big enough
+    int xcd_weights[8] = {32, 32, 32, 32, 32, 32, 32, 32};
+    bool xcd_calibrated = false;
     int n_members = 1;
     bool have_canopy = false, have_spectra = false, have_nodes = false, have_tables = false;
     int nw = 0;
@@ -138,6 +141,14 @@ extern "C" int gort_engine_create(gort_engine **out)
         gort_engine_destroy(e);
         return fail(GORT_ENODEVICE, "gort_engine_create: cannot create stream");
     }
+    if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = atoi(v) == 0;        // 0: equal weights
+    if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
+        int w[8];
+        if (sscanf(v, "%d,%d,%d,%d,%d,%d,%d,%d", w, w + 1, w + 2, w + 3, w + 4, w + 5, w + 6, w + 7) == 8) {
+            for (int x = 0; x < 8; ++x) e->xcd_weights[x] = w[x];
+            e->xcd_calibrated = true;
+        }
+    }
     *out = e;
     return GORT_OK;
 }
@@ -180,6 +191,28 @@ extern "C" int gort_engine_xcd_mapping(gort_engine *e)
     const int rc = xcd_slots_for_launch(e, &slots);
     if (rc) return -rc;
     return slots ? 2 : 1;
+}
+
+extern "C" int gort_engine_xcd_weights(const gort_engine *e, int weights[8])
+{
+    if (!e || !weights) return fail(GORT_EINVAL, "gort_engine_xcd_weights: null argument");
+    for (int x = 0; x < 8; ++x) weights[x] = e->xcd_weights[x];
+    return e->xcd_calibrated ? 1 : 0;
+}
+
+extern "C" int gort_engine_set_xcd_weights(gort_engine *e, const int weights[8])
+{
+    if (!e) return fail(GORT_EINVAL, "gort_engine_set_xcd_weights: null engine");
+    if (!weights) {                          // back to automatic: calibrate on the next big LUT slab
+        for (int x = 0; x < 8; ++x) e->xcd_weights[x] = 32;
+        e->xcd_calibrated = false;
+        return GORT_OK;
+    }
+    for (int x = 0; x < 8; ++x)
+        if (weights[x] < 8 || weights[x] > 32) return fail(GORT_ERANGE, "gort_engine_set_xcd_weights: weight %d outside 8..32", weights[x]);
+    for (int x = 0; x < 8; ++x) e->xcd_weights[x] = weights[x];
+    e->xcd_calibrated = true;
+    return GORT_OK;
 }
 
 extern "C" void *gort_engine_stream(gort_engine *e) { return e ? (void *)e->stream : nullptr; }
@@ -396,7 +429,11 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr,
                                     e->stream);
     }
-    // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel)
+    // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).  ONE buffer, reused
+    // by every call: the 191 MB of records the geometry kernel writes are still in the 256 MB Infinity Cache when
+    // the expansion fetches them.  Double-buffering them to overlap the next call's geometry with this call's
+    // expansion was tried and cost 14 % (8.0 against 7.0 ms): two buffers do not fit, the record and sun-term
+    // fetches in the waves' prologues then come from HBM, and those short-lived waves are latency-bound.
     const long tail = expand_grid_tail_pad_records(nw, nA * (long)nw);
     const size_t coef_bytes = sizeof(double) * 8 * (size_t)(nA + 1 + tail);
     const bool fresh = coef_bytes > e->coef.cap;
@@ -410,6 +447,11 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, e->sun.as<double>(), e->stream))) return rc;
     int *xcd_slots = nullptr;
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
+    if (!xcd_slots && !e->xcd_calibrated && nA * (long)nw >= (1L << 27)) {
+        // first slab of 1 GiB or more: time the XCDs' write rates on it (it is overwritten right after)
+        if ((rc = calibrate_xcd_weights(e->stream, lut_dev, nA * (long)nw, e->xcd_weights))) return rc;
+        e->xcd_calibrated = true;
+    }
     // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to
     // 512 launches are kept between two gort_engine_last_expand_ms() calls
     const bool timed = e->ev_used + 2 <= 1024;
@@ -422,7 +464,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
     rc = launch_expand_grid(e->sun.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
-                            xcd_slots, e->stream);
+                            xcd_slots, e->xcd_weights, e->stream);
     if (timed) {
         GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;

@@ -611,6 +611,57 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 // the chunk, i.e. the chunk spans two angles: those waves fetch both records and each
 // element picks its own.  The coefficient buffer carries one pad record in front and a
 // tail pad so that the record prefetch needs no bounds logic.
+// ---- which logical block (= 4 consecutive waves of the flat kernels) does this workgroup work on ----
+// Any bijection is correct; only speed depends on it.  Each XCD gets ONE contiguous range of logical blocks
+// (eight compact write windows, one per L2, instead of one window interleaved over all eight).
+//   mode 0  identity (interleaved)
+//   mode 1  static: workgroups b, b+8, ... run on one XCD each (round-robin dispatch, probed per engine).
+//           The XCDs do not write equally fast - on the parts measured the odd XCC_IDs sustain ~80 % of the
+//           even ones, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
+//           workgroups (the others return at once) and owns a range of logical blocks in proportion
+//           (calibrate_xcd_weights; tools/xcd_stream_probe.hip: 7.06 -> 6.70 ms for the 50 GB slab).
+//   mode 2  dynamic: read the XCD the workgroup really runs on (HW_REG_XCC_ID) and take the next free slot of
+//           that XCD's range with one returning atomic; if the range is used up take one from the next XCD.
+//           The ranges sum to the grid, so every workgroup finds a slot within 8 tries.  The launcher zeroes
+//           the counters (one per 128-B line) on the stream before every launch.
+// Returns -1 for a workgroup without work.
+__device__ __forceinline__ long xcd_logical_block(int xcd_mode, const XcdDuty &duty, long useful,
+                                                  int *__restrict__ xcd_slots)
+{
+    const long b = blockIdx.x;
+    if (xcd_mode == 1) {
+        const unsigned sh = ((unsigned)b & 7u) * 8u;
+        const unsigned w = (unsigned)(duty.w8 >> sh) & 0xffu;
+        // sum of the weights of the XCDs in front (<= 7 x 32, fits the top byte of the byte-wise product)
+        const unsigned long long below = duty.w8 & ((1ull << sh) - 1ull);
+        const unsigned pw = (unsigned)((below * 0x0101010101010101ull) >> 56);
+        const long i = b >> 3;                               // < 32 q by the size of the grid
+        const long li = (i * w) >> 5;                        // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
+        if ((((i + 1) * w) >> 5) == li) return -1;
+        const long block = duty.q * pw + li;
+        return block < useful ? block : -1;
+    }
+    if (xcd_mode == 2) {
+        const long base = useful >> 3, rem = useful & 7;     // XCD y owns [y*base + min(y,rem), +base (+1 if y < rem))
+        __shared__ long s_block;
+        if (threadIdx.x == 0) {
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            long L = -1;
+            for (int t = 0; t < 8 && L < 0; ++t) {
+                const long y = (x + t) & 7;
+                const long quota = base + (y < rem ? 1 : 0);
+                const long s = atomicAdd(&xcd_slots[y * XCD_SLOT_PITCH], 1);
+                if (s < quota) L = y * base + (y < rem ? y : rem) + s;
+            }
+            s_block = L;
+        }
+        __syncthreads();
+        return s_block;                                       // never -1 (pigeonhole), checked by the caller anyway
+    }
+    return b < useful ? b : -1;
+}
+
 constexpr int EPL = 2;                  // elements (adjacent bands) per lane and step
 constexpr int CHUNK = 64 * EPL;         // doubles per wave-step
 typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -700,40 +751,22 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
                                                            int angles_per_sza, long angle0, long n_total, int shift,
                                                            long stride_chunks, int da, int steps_per_wave,
                                                            double *__restrict__ lut, int xcd_mode,
+                                                           XcdDuty duty, long useful_blocks,
                                                            int *__restrict__ xcd_slots)
 {
+    // A wave of a short panel lives for a few microseconds and the launch is bound by how many such lives fit
+    // on a CU, not by HBM alone: every scalar-memory round trip in the prologue shows in the kernel's time.
+    // Left alone the compiler fetches kernel arguments where they are first used, in five or six round trips;
+    // naming them here makes it one batch of s_loads.
+#define GORT_ARG_NOW(x) asm volatile("" ::"s"(x))
+    GORT_ARG_NOW(nw);  GORT_ARG_NOW(angles_per_sza);  GORT_ARG_NOW(angle0);  GORT_ARG_NOW(n_total);  GORT_ARG_NOW(shift);
+    GORT_ARG_NOW(stride_chunks);  GORT_ARG_NOW(da);  GORT_ARG_NOW(steps_per_wave);  GORT_ARG_NOW(xcd_mode);
+    GORT_ARG_NOW(duty.w8);  GORT_ARG_NOW(duty.q);  GORT_ARG_NOW(useful_blocks);  GORT_ARG_NOW(isza_base);
+    GORT_ARG_NOW(sun);  GORT_ARG_NOW(lut);      // not `coef`: naming it here costs 40 VGPRs (112 instead of 71)
+#undef GORT_ARG_NOW
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    long block = blockIdx.x;
-    // Give each XCD ONE contiguous range of chunks (eight write windows, one per L2, instead of one window
-    // interleaved over all eight): 9.4 -> 8.1 ms.  Any block->range assignment is correct; only speed depends
-    // on it.  Ranges: XCD y owns logical blocks [y*base + min(y,rem), +quota(y)), quota = base (+1 if y < rem).
-    const long nb = gridDim.x, base = nb >> 3, rem = nb & 7;
-    if (xcd_mode == 1) {
-        // static guess: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch as observed unprofiled)
-        const long x = block & 7;
-        block = x * base + (x < rem ? x : rem) + (block >> 3);
-    } else if (xcd_mode == 2) {
-        // placement-independent: read the XCD this block really runs on (HW_REG_XCC_ID) and take the next free
-        // slot of that XCD's range; if that range is used up (uneven placement, e.g. under rocprofv3) take one
-        // from the next XCD.  The ranges sum to nb, so every block finds a slot within 8 tries.  The launcher
-        // zeroes the 8 counters on the stream before every launch.
-        __shared__ long s_block;
-        if (threadIdx.x == 0) {
-            unsigned x;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-            long L = -1;
-            for (int t = 0; t < 8 && L < 0; ++t) {
-                const long y = (x + t) & 7;
-                const long quota = base + (y < rem ? 1 : 0);
-                const long s = atomicAdd(&xcd_slots[y * XCD_SLOT_PITCH], 1);
-                if (s < quota) L = y * base + (y < rem ? y : rem) + s;
-            }
-            s_block = L;
-        }
-        __syncthreads();
-        block = s_block;
-        if (block < 0) return;      // cannot happen (pigeonhole); never index out of the slab
-    }
+    const long block = xcd_logical_block(xcd_mode, duty, useful_blocks, xcd_slots);
+    if (block < 0) return;
     // panels of steps_per_wave x stride chunks: wave (panel, w) takes chunks panel*K*stride + w + k*stride, k < K
     // All of the wave's index arithmetic is wave-uniform and, but for one division, 32-bit: a wave of a short
     // panel lives for a few dozen stores, so its prologue counts.
@@ -876,32 +909,12 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const gort_cano
                                                                   const double *__restrict__ coef, long n_total,
                                                                   int shift, long stride_chunks,
                                                                   double *__restrict__ out, int xcd_mode,
+                                                                  XcdDuty duty, long useful_blocks,
                                                                   int *__restrict__ xcd_slots)
 {
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    long block = blockIdx.x;
-    const long nb = gridDim.x, base = nb >> 3, rem = nb & 7;
-    if (xcd_mode == 1) {
-        const long x = block & 7;
-        block = x * base + (x < rem ? x : rem) + (block >> 3);
-    } else if (xcd_mode == 2) {               // see expand_flat_kernel
-        __shared__ long s_block;
-        if (threadIdx.x == 0) {
-            unsigned x;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-            long Lb = -1;
-            for (int q = 0; q < 8 && Lb < 0; ++q) {
-                const long y = (x + q) & 7;
-                const long quota = base + (y < rem ? 1 : 0);
-                const long sl = atomicAdd(&xcd_slots[y * XCD_SLOT_PITCH], 1);
-                if (sl < quota) Lb = y * base + (y < rem ? y : rem) + sl;
-            }
-            s_block = Lb;
-        }
-        __syncthreads();
-        block = s_block;
-        if (block < 0) return;
-    }
+    const long block = xcd_logical_block(xcd_mode, duty, useful_blocks, xcd_slots);
+    if (block < 0) return;
     const long wave = block * 4 + wave_in_block;
     if (wave >= stride_chunks) return;
     const int lane = threadIdx.x & 63;
@@ -1197,6 +1210,114 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin)
     return m == 2 || (m < 0 && !dispatch_round_robin);
 }
 
+// Grid and ranges of a flat launch over `useful` logical blocks.  Mode 1: XCD x owns q w[x] blocks, q =
+// ceil(useful / sum w), and gets through them in 32 q workgroup slots whatever its weight (the overshoot of at
+// most sum w blocks falls off the end of the last range).
+static long plan_xcd_duty(int xcd_mode, long useful, const int *weights, XcdDuty &duty)
+{
+    long sumw = 0;
+    duty.w8 = 0;
+    for (int x = 0; x < 8; ++x) {
+        int w = weights ? weights[x] : 32;
+        w = w < 8 ? 8 : (w > 32 ? 32 : w);
+        duty.w8 |= (unsigned long long)w << (8 * x);
+        sumw += w;
+    }
+    duty.q = (useful + sumw - 1) / sumw;
+    return xcd_mode == 1 ? 8 * 32 * duty.q : useful;
+}
+
+namespace {
+// the store pattern of expand_flat_kernel (panels of K x W chunks, 16-B non-temporal stores) with the XCD
+// mapping of mode 1; one workgroup in 64 reports when it started and ended
+__global__ __launch_bounds__(256) void xcd_pattern_kernel(double *__restrict__ slab, long chunks, int K, unsigned W,
+                                                          XcdDuty duty, long useful,
+                                                          unsigned long long *__restrict__ t_first,
+                                                          unsigned long long *__restrict__ t_last)
+{
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long block = xcd_logical_block(1, duty, useful, nullptr);
+    if (block < 0) return;
+    const int xd = blockIdx.x & 7;
+    const bool reports = ((blockIdx.x >> 3) & 63) == 0;
+    if (reports && threadIdx.x == 0) atomicMin(&t_first[xd], wall_clock64());
+    const unsigned wave = (unsigned)(block * 4 + wib);
+    const unsigned panel = wave / W, w = wave - panel * W;
+    const long c0 = (long)panel * K * W + w;
+    const int lane = threadIdx.x & 63;
+    dbl2 v;
+    v.x = 0.0;
+    v.y = 0.0;
+    for (int k = 0; k < K; ++k) {
+        const long c = c0 + (long)k * W;
+        if (c < chunks) __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(slab + c * CHUNK + EPL * lane));
+    }
+    __syncthreads();
+    if (reports && threadIdx.x == 0) atomicMax(&t_last[xd], wall_clock64());
+}
+}  // namespace
+
+int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weights[8])
+{
+    for (int x = 0; x < 8; ++x) weights[x] = 32;
+    // whole aligned chunks inside the slab
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(slab);
+    const long skip = (long)(((addr + 1023) & ~(uintptr_t)1023) - addr) / 8;
+    const long chunks = (n_doubles - skip) / CHUNK;
+    constexpr int K = 6;
+    constexpr unsigned W = 2101;
+    if (chunks < 64L * K * W) return GORT_OK;                  // too small to say anything
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *dev = nullptr;
+    if (hipMalloc(&dev, 16 * sizeof(*dev)) != hipSuccess) return fail(GORT_ENOMEM, "xcd calibration: hipMalloc failed");
+    const long panels = (chunks + (long)K * W - 1) / ((long)K * W);
+    const long useful = (panels * W + 3) / 4;
+    int rc = GORT_OK;
+    for (int iter = 0; iter < 4 && rc == GORT_OK; ++iter) {
+        XcdDuty duty;
+        const long grid = plan_xcd_duty(1, useful, weights, duty);
+        unsigned long long host[16];
+        for (int x = 0; x < 8; ++x) { host[x] = ~0ull; host[8 + x] = 0; }
+        hipError_t err = hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, s);
+        if (err == hipSuccess) {
+            hipLaunchKernelGGL(xcd_pattern_kernel, dim3((unsigned)grid), dim3(256), 0, s, slab + skip, chunks, K, W, duty,
+                               useful, dev, dev + 8);
+            err = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
+        }
+        if (err == hipSuccess) err = hipStreamSynchronize(s);
+        if (err != hipSuccess) { rc = fail(GORT_ENODEVICE, "xcd calibration: %s", hipGetErrorString(err)); break; }
+        unsigned long long t0 = ~0ull;
+        for (int x = 0; x < 8; ++x) if (host[x] < t0) t0 = host[x];
+        // blocks per tick of every XCD in this run; the next weights are proportional to it
+        double rate[8], rmax = 0.0;
+        bool ok = true;
+        for (int x = 0; x < 8; ++x) {
+            if (host[8 + x] <= t0) { ok = false; break; }
+            rate[x] = (double)weights[x] / (double)(host[8 + x] - t0);
+            if (rate[x] > rmax) rmax = rate[x];
+        }
+        if (!ok) break;                                        // an XCD reported nothing: leave the weights alone
+        for (int x = 0; x < 8; ++x) {
+            int w = (int)(32.0 * rate[x] / rmax + 0.5);
+            weights[x] = w < 16 ? 16 : (w > 32 ? 32 : w);
+        }
+    }
+    // What is being measured is a trait of the part - the XCDs with odd XCC_ID write ~15 % slower than the even
+    // ones on every MI355X seen so far - under a few % of run-to-run noise, and a weight that is off by one
+    // costs more than it gains (tools/weights_sweep.py).  So the eight results are averaged within each parity.
+    if (rc == GORT_OK) {
+        double mean[2] = {0.0, 0.0};
+        for (int x = 0; x < 8; ++x) mean[x & 1] += 0.25 * weights[x];
+        const double top = mean[0] > mean[1] ? mean[0] : mean[1];
+        for (int x = 0; x < 8; ++x) {
+            int w = (int)(32.0 * mean[x & 1] / top + 0.5);
+            weights[x] = w < 16 ? 16 : (w > 32 ? 32 : w);
+        }
+    }
+    (void)hipFree(dev);
+    return rc;
+}
+
 // Are workgroups b, b+8, b+16, ... of a launch placed on one XCD each (round-robin dispatch, the documented
 // behaviour of the multi-XCD dispatcher)?  Then the static mapping of the flat kernels is exact and needs no
 // atomics.  A profiler or a partition mode may change the pattern, hence the probe rather than an assumption.
@@ -1253,7 +1374,8 @@ long expand_grid_tail_pad_records(int nw, long n_total)
 }
 
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
-                       long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, void *stream)
+                       long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, const int *xcd_weights,
+                       void *stream)
 {
     const long rows = row_end - row_begin;
     if (rows <= 0) return GORT_OK;
@@ -1285,13 +1407,17 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
         return fail(GORT_EINVAL, "expand_grid: slab of %ld chunks in %ld waves is beyond the kernel's 32-bit indices",
                     chunks, panels * stride);
     const int da = (int)(stride * CHUNK / nw);          // angles per step (the stride is a multiple of nw/gcd(nw,CHUNK))
-    const dim3 grid((unsigned)((panels * stride + 3) / 4));
+    const long useful = (panels * stride + 3) / 4;
+    XcdDuty duty;
+    const long nblocks = plan_xcd_duty(xcd_mode, useful, xcd_weights, duty);
+    if (nblocks >= (1L << 31)) return fail(GORT_EINVAL, "expand_grid: %ld workgroups in one launch", nblocks);
+    const dim3 grid((unsigned)nblocks);
     const int angles_per_sza = nvza * nphi;
     const long angle0 = row_begin * nphi;
 #define GORT_FLAT(D, N)                                                                                           \
     hipLaunchKernelGGL((expand_flat_kernel<D, N>), grid, dim3(256), 0, s, sun_dev, isza_base, coef_dev, nw,      \
                        angles_per_sza, angle0, n_total, shift, stride, da, steps, lut_dev,                       \
-                       xcd_mode, xcd_slots_dev)
+                       xcd_mode, duty, useful, xcd_slots_dev)
     if (tune.nt) {
         if (tune.depth == 1) GORT_FLAT(1, true); else if (tune.depth == 2) GORT_FLAT(2, true); else GORT_FLAT(4, true);
     } else {
@@ -1324,13 +1450,17 @@ static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double
     const int shift = (int)((reinterpret_cast<uintptr_t>(rsurf_dev) / sizeof(double)) % CHUNK);
     const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
     const long stride = flat_stride(nw, chunks, tune.stream_waves);
-    const dim3 grid((unsigned)((stride + 3) / 4));
+    // this kernel is bound by its arithmetic, not by the XCDs' write rates: equal duty
+    const int xcd_mode = resolve_xcd_mode(xcd_slots_dev);
+    const long useful = (stride + 3) / 4;
+    XcdDuty duty;
+    const dim3 grid((unsigned)plan_xcd_duty(xcd_mode, useful, nullptr, duty));
     if (tune.nt)
         hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, resolve_xcd_mode(xcd_slots_dev), xcd_slots_dev);
+                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev);
     else
         hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, resolve_xcd_mode(xcd_slots_dev), xcd_slots_dev);
+                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev);
     return check_launch("expand_flat_stream_kernel");
 }
 

@@ -68,6 +68,17 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
 // that the eight XCDs' atomics do not serialise on one line; the caller zeroes XCD_SLOT_BYTES on the stream
 constexpr int XCD_SLOT_PITCH = 32;
 constexpr size_t XCD_SLOT_BYTES = sizeof(int) * 8 * XCD_SLOT_PITCH;
+// static XCD mapping of the flat kernels, 16 bytes that stay in SGPRs (a wave of a short panel cannot afford a
+// table lookup in its prologue): XCD x (dispatch slot blockIdx & 7) works in w[x] of every 32 of its workgroups
+// and owns the q * w[x] logical blocks from q * (w[0] + ... + w[x-1]); w[x] is byte x of w8, 8..32; weights of
+// 32 = all XCDs alike (see xcd_logical_block in gort_brdf.hip)
+struct XcdDuty {
+    unsigned long long w8;
+    long q;
+};
+// Measure how fast each XCD writes (the store pattern of expand_flat_kernel over `slab`, whose contents are
+// destroyed) and derive the duty weights that make all XCDs finish together; synchronises `stream`.
+int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weights[8]);
 // round_robin = 1 if workgroups b, b+8, ... of a launch share an XCD (then the static XCD mapping is exact);
 // expand_wants_xcd_slots: does the flat expansion need the slot counters (GORT_EXPAND_XCD or the probe says so)
 int probe_xcd_dispatch(void *stream, int *round_robin);
@@ -85,9 +96,10 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 // and expand_grid_tail_pad_records() readable records behind the last angle
 long expand_grid_tail_pad_records(int nw, long n_total);
 // xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the call (per-XCD slot counters), or nullptr for the static
-// XCD mapping
+// XCD mapping, for which xcd_weights[8] (32nds, nullptr = all 32) are the XCDs' duty weights
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
-                       long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, void *stream);
+                       long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, const int *xcd_weights,
+                       void *stream);
 // energy_dev[n_members][nA][nw][3]; members are canopies_dev[0..n) with L_dev[m][L_NSLOT][nw]
 int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                   const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *stream);

@@ -197,6 +197,12 @@ double gort_engine_last_expand_ms(gort_engine *e);
 /* how the flat expansion kernels map workgroups to XCD-contiguous output ranges on this device: 1 = static
  * (workgroup dispatch probed to be round-robin over the XCDs), 2 = per-XCD slot counters; <0 = -error */
 int  gort_engine_xcd_mapping(gort_engine *e);
+/* duty weights of the eight XCDs in 32nds (static mapping): the XCDs of a part do not write equally fast, and
+ * the slower ones get a smaller share of the LUT slab.  Calibrated on the first LUT slab of >= 1 GiB
+ * (GORT_XCD_CALIBRATE=0 or GORT_XCD_WEIGHTS="w0,...,w7" override).  Returns 1 once calibrated or set, else 0. */
+int  gort_engine_xcd_weights(const gort_engine *e, int weights[8]);
+/* set the weights (each 8..32) instead of calibrating; NULL = forget them and calibrate on the next big slab */
+int  gort_engine_set_xcd_weights(gort_engine *e, const int weights[8]);
 
 /* Spectral albedo, vegetation and soil absorption per angle line.  Replaces
  * gortt_energy/gortt_albedo (gortt_albedo.c:7-138): 32x16 Gauss-Legendre nodes over the

@@ -38,6 +38,9 @@ def main():
     for i in range(nslab):
         slabs.append(torch.empty((rows * grid.nphi, wl.size), dtype=torch.float64, device="cuda"))
         print("slab %d at 0x%x" % (i, slabs[-1].data_ptr()), flush=True)
+    eng.rsurf_grid_dev(grid, 0, rows, slabs[0])
+    eng.synchronize()
+    print("xcd weights:", eng.xcd_weights(), flush=True)
     for rnd in range(int(os.environ.get("PROBE_ROUNDS", "2"))):
         for i, lut in enumerate(slabs):
             def step():
