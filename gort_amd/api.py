@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libgort_amd.so")
+LIB_PATH = os.environ.get("GORT_AMD_LIB") or os.path.join(PKG, "libgort_amd.so")     # override: A/B builds
 GORTT_BIN = os.path.join(PKG, "bin", "gortt")
 D = C.c_double
 NTH, NLAYERS, NBANDS, COEF_STRIDE = 91, 15, 2101, 16

@@ -666,15 +666,27 @@ constexpr int EPL = 2;                  // elements (adjacent bands) per lane an
 constexpr int CHUNK = 64 * EPL;         // doubles per wave-step
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
-struct FlatLane {
-    double b[EPL][5];                   // sun terms C0,B,Z,G,T of this lane's bands at their current sun zenith
-    int isza[EPL], rem[EPL], band[EPL], wrapped[EPL], k_begin[EPL], k_end[EPL];
-};
+// exact n / d for n < 2^31 and a divisor fixed per launch: (n * mul) >> (31 + sh), mul and sh from the host
+// (make_fast_div); five scalar instructions instead of the ~35 of a 32-bit division with a run-time divisor
+__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d)
+{
+    return (unsigned)(((unsigned long long)n * d.mul) >> (31u + d.sh));
+}
 
+// The steps of one wave.  What a lane carries is its sun terms b (20 VGPRs) and its bands; everything that
+// moves is wave-uniform: the output chunk, the record address and the sun zenith of the chunk's first angle
+// (isza_w, rem_w = angle index within the zenith).  An element is in the chunk's first angle or (`second`,
+// only in WRAP waves) in the next one, so whether its sun zenith changes at a step follows from the scalar
+// tracker: ch0 for first-angle elements, ch1 for second-angle ones - in the 94 % of waves without a wrap the
+// reload of the sun terms is a wave-uniform branch.  Validity is also scalar but for the two edges of the
+// slab: at step 0 of chunk 0 the elements below first_off lie in front of it, at step last_step (the slab's
+// last chunk; -1 if this wave never gets there) those above last_off lie behind it.
 template <int DEPTH, bool NT, bool WRAP>
-__device__ __forceinline__ void flat_loop(FlatLane st, const double *__restrict__ sun, int isza_base, int nw,
-                                          int angles_per_sza, int da, long step, int k_wave,
-                                          const double *__restrict__ rec_w, double *__restrict__ out_w, int lane)
+__device__ __forceinline__ void flat_loop(double (&b)[EPL][5], const int (&band)[EPL], const bool (&second)[EPL],
+                                          int isza_w, int rem_w, int first_off, int last_step, int last_off,
+                                          const double *__restrict__ sun, int isza_base, int nw, int angles_per_sza,
+                                          int da, long step, int k_wave, const double *__restrict__ rec_w,
+                                          double *__restrict__ out_w, int lane)
 {
     const long rec_step = (long)da * GRID_COEF_STRIDE;
     double rA[DEPTH][5], rB[WRAP ? DEPTH : 1][5];
@@ -688,9 +700,6 @@ __device__ __forceinline__ void flat_loop(FlatLane st, const double *__restrict_
         }
     }
     rec_w += (long)DEPTH * rec_step;
-    // the two elements of a lane are valid together except at the very ends of the slab
-    const int kb_all = st.k_begin[0] > st.k_begin[1] ? st.k_begin[0] : st.k_begin[1];
-    const int ke_all = st.k_end[0] < st.k_end[1] ? st.k_end[0] : st.k_end[1];
     for (int k = 0; k < k_wave; k += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -698,27 +707,32 @@ __device__ __forceinline__ void flat_loop(FlatLane st, const double *__restrict_
             double v[EPL];
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                const double vA = dot5(rA[d][A_C], rA[d][A_B], rA[d][A_Z], rA[d][A_G], rA[d][A_T], st.b[j][0],
-                                       st.b[j][1], st.b[j][2], st.b[j][3], st.b[j][4]);
+                const double vA = dot5(rA[d][A_C], rA[d][A_B], rA[d][A_Z], rA[d][A_G], rA[d][A_T], b[j][0], b[j][1],
+                                       b[j][2], b[j][3], b[j][4]);
                 if (WRAP) {
-                    const double vB = dot5(rB[d][A_C], rB[d][A_B], rB[d][A_Z], rB[d][A_G], rB[d][A_T], st.b[j][0],
-                                           st.b[j][1], st.b[j][2], st.b[j][3], st.b[j][4]);
-                    v[j] = st.wrapped[j] ? vB : vA;
+                    const double vB = dot5(rB[d][A_C], rB[d][A_B], rB[d][A_Z], rB[d][A_G], rB[d][A_T], b[j][0], b[j][1],
+                                           b[j][2], b[j][3], b[j][4]);
+                    v[j] = second[j] ? vB : vA;
                 } else {
                     v[j] = vA;
                 }
             }
-            double *o = out_w + EPL * lane;
-            if (kk >= kb_all && kk < ke_all) {
-                dbl2 vv;
-                vv.x = v[0];
-                vv.y = v[1];
-                if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<dbl2 *>(o));
-                else *reinterpret_cast<dbl2 *>(o) = vv;
-            } else {
+            if (kk < k_wave) {
+                double *o = out_w + EPL * lane;
+                const bool front = kk == 0 && first_off > 0, back = kk == last_step;
+                if (!front && !back) {
+                    dbl2 vv;
+                    vv.x = v[0];
+                    vv.y = v[1];
+                    if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<dbl2 *>(o));
+                    else *reinterpret_cast<dbl2 *>(o) = vv;
+                } else {
 #pragma unroll
-                for (int j = 0; j < EPL; ++j)
-                    if (kk >= st.k_begin[j] && kk < st.k_end[j]) o[j] = v[j];
+                    for (int j = 0; j < EPL; ++j) {
+                        const int off = EPL * lane + j;
+                        if (!(front && off < first_off) && !(back && off > last_off)) o[j] = v[j];
+                    }
+                }
             }
             out_w += step;
             // refill this slot with the record(s) DEPTH steps ahead (the tail pad makes them always readable)
@@ -728,16 +742,21 @@ __device__ __forceinline__ void flat_loop(FlatLane st, const double *__restrict_
                 if (WRAP) rB[d][q] = rec_w[GRID_COEF_STRIDE + q];
             }
             rec_w += rec_step;
-            // next step's sun zenith, per element
+            // next step's sun zenith (scalar), and the sun terms of the elements that cross into it
+            const int isza_old = isza_w + ((WRAP && rem_w == angles_per_sza - 1) ? 1 : 0), isza_old0 = isza_w;
+            rem_w += da;
+            while (rem_w >= angles_per_sza) { rem_w -= angles_per_sza; ++isza_w; }
+            const int isza_new = isza_w + ((WRAP && rem_w == angles_per_sza - 1) ? 1 : 0);
+            const bool ch0 = isza_w != isza_old0, ch1 = WRAP && isza_new != isza_old;
+            if (kk + 1 < k_wave && (ch0 || ch1)) {
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                st.rem[j] += da;
-                if (st.rem[j] >= angles_per_sza) {
-                    do { st.rem[j] -= angles_per_sza; ++st.isza[j]; } while (st.rem[j] >= angles_per_sza);
-                    if (kk + 1 < st.k_end[j]) {
-                        const double *bp = sun + (long)(st.isza[j] - isza_base) * 5 * nw + st.band[j];
+                for (int j = 0; j < EPL; ++j) {
+                    const bool sec = WRAP && second[j];
+                    const bool behind = kk + 1 == last_step && EPL * lane + j > last_off;    // never stored again
+                    if ((sec ? ch1 : ch0) && !behind) {
+                        const double *bp = sun + (long)((sec ? isza_new : isza_w) - isza_base) * 5 * nw + band[j];
 #pragma unroll
-                        for (int q = 0; q < 5; ++q) st.b[j][q] = bp[(long)q * nw];
+                        for (int q = 0; q < 5; ++q) b[j][q] = bp[(long)q * nw];
                     }
                 }
             }
@@ -745,11 +764,14 @@ __device__ __forceinline__ void flat_loop(FlatLane st, const double *__restrict_
     }
 }
 
+// 60 VGPRs but 106 SGPRs (the records of DEPTH steps live there): 7 waves/SIMD.  Forcing 8 with
+// amdgpu_waves_per_eu spills 50 SGPRs into VGPR lanes and changes nothing (6.8 ms either way, ab_occ.log).
 template <int DEPTH, bool NT>
 __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restrict__ sun, int isza_base,
                                                            const double *__restrict__ coef, int nw,
                                                            int angles_per_sza, long angle0, long n_total, int shift,
                                                            long stride_chunks, int da, int steps_per_wave,
+                                                           FastDiv div_stride, FastDiv div_nw, FastDiv div_aps,
                                                            double *__restrict__ lut, int xcd_mode,
                                                            XcdDuty duty, long useful_blocks,
                                                            int *__restrict__ xcd_slots)
@@ -762,17 +784,19 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
     GORT_ARG_NOW(nw);  GORT_ARG_NOW(angles_per_sza);  GORT_ARG_NOW(angle0);  GORT_ARG_NOW(n_total);  GORT_ARG_NOW(shift);
     GORT_ARG_NOW(stride_chunks);  GORT_ARG_NOW(da);  GORT_ARG_NOW(steps_per_wave);  GORT_ARG_NOW(xcd_mode);
     GORT_ARG_NOW(duty.w8);  GORT_ARG_NOW(duty.q);  GORT_ARG_NOW(useful_blocks);  GORT_ARG_NOW(isza_base);
-    GORT_ARG_NOW(sun);  GORT_ARG_NOW(lut);      // not `coef`: naming it here costs 40 VGPRs (112 instead of 71)
+    GORT_ARG_NOW(div_stride.mul);  GORT_ARG_NOW(div_stride.sh);  GORT_ARG_NOW(div_nw.mul);  GORT_ARG_NOW(div_nw.sh);
+    GORT_ARG_NOW(div_aps.mul);  GORT_ARG_NOW(div_aps.sh);
+    GORT_ARG_NOW(sun);  GORT_ARG_NOW(lut);      // not `coef`: naming it here costs 40 VGPRs
 #undef GORT_ARG_NOW
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long block = xcd_logical_block(xcd_mode, duty, useful_blocks, xcd_slots);
     if (block < 0) return;
     // panels of steps_per_wave x stride chunks: wave (panel, w) takes chunks panel*K*stride + w + k*stride, k < K
-    // All of the wave's index arithmetic is wave-uniform and, but for one division, 32-bit: a wave of a short
-    // panel lives for a few dozen stores, so its prologue counts.
+    // All of the wave's index arithmetic is wave-uniform, 32-bit and free of run-time divisions (the host
+    // checks that waves, chunks and 2 step stay below 2^31).
     const unsigned wave = (unsigned)(block * 4 + wave_in_block);              // scalar
     const unsigned stride = (unsigned)stride_chunks;
-    const unsigned panel = wave / stride;
+    const unsigned panel = fast_div(wave, div_stride);
     const unsigned w_in_panel = wave - panel * stride;
     const int lane = threadIdx.x & 63;
     const long step = stride_chunks * CHUNK;       // elements per step = da * nw
@@ -785,58 +809,56 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
     if (c0 > last_chunk) return;
     const long e0 = c0 * CHUNK - shift;            // element index of the chunk start at step 0 (< 0 only for chunk 0)
     // angle and band of the chunk start at step 0: a panel starts a whole number of angles into the slab,
-    // and the rest, taken one step ahead to stay positive, is below 2 step < 2^31
+    // and the rest, taken one step ahead to stay positive, is below 2 step
     const unsigned local = w_in_panel * CHUNK + (unsigned)step - (unsigned)shift;
-    const unsigned a_loc = local / (unsigned)nw;
+    const unsigned a_loc = fast_div(local, div_nw);
     const int band_w = (int)(local - a_loc * (unsigned)nw);
     const long a_w = (long)panel * steps_per_wave * da + a_loc - da;          // scalar, >= -1
     // steps until the wave's chunk passes the end of the slab (only the last panel's waves run out)
     const long rel = last_chunk - c0;
     const bool runs_out = rel < (long)steps_per_wave * stride_chunks;
-    unsigned k_last = 0;
-    bool ends_in_last_chunk = false;
+    int k_wave = steps_per_wave, last_step = -1;
     if (runs_out) {
-        k_last = (unsigned)rel / stride;
-        ends_in_last_chunk = (unsigned)rel == k_last * stride;
+        const unsigned k_last = fast_div((unsigned)rel, div_stride);
+        k_wave = (int)k_last + 1;
+        if ((unsigned)rel == k_last * stride) last_step = (int)k_last;        // ends in the slab's last chunk
     }
-    const int k_wave = runs_out ? (int)k_last + 1 : steps_per_wave;           // scalar upper bound over lanes
-    // sun zenith of the angle a_w: the one 64-bit division
+    // sun zenith of the angle a_w
     const long A0 = angle0 + a_w;                                             // >= -1
     int isza_w = -1, rem_w = angles_per_sza - 1;
     if (A0 >= 0) {
-        const long q = A0 / angles_per_sza;
+        const long q = A0 < (1L << 31) ? (long)fast_div((unsigned)A0, div_aps) : A0 / angles_per_sza;
         isza_w = (int)q;
         rem_w = (int)(A0 - q * angles_per_sza);
     }
+    const int first_off = c0 == 0 ? shift : 0;
 
-    FlatLane st;
+    double b[EPL][5];
+    int band[EPL];
+    bool second[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         const int off = EPL * lane + j;
-        int band = band_w + off;
-        st.wrapped[j] = 0;
-        if (band >= nw) { band -= nw; st.wrapped[j] = 1; }                    // nw >= CHUNK on this path: one wrap at most
-        st.band[j] = band;
-        st.k_begin[j] = (c0 == 0 && off < shift) ? 1 : 0;                     // in front of the slab at step 0
-        // first invalid step
-        st.k_end[j] = runs_out ? (int)k_last + ((!ends_in_last_chunk || off <= last_off) ? 1 : 0) : steps_per_wave;
-        // sun zenith of this element's angle, tracked incrementally from step 0
-        int isza = isza_w, rem = rem_w + st.wrapped[j];
-        if (rem >= angles_per_sza) { rem -= angles_per_sza; ++isza; }
-        st.isza[j] = isza;                                                    // isza_base - 1 only for elements invalid at step 0
-        st.rem[j] = rem;
-        const bool live = st.k_end[j] > st.k_begin[j] && isza >= isza_base;   // else the first crossing loads them
-        const double *bp = sun + (long)(isza - isza_base) * 5 * nw + band;
+        band[j] = band_w + off;
+        second[j] = band[j] >= nw;                                            // nw >= CHUNK on this path: one wrap at most
+        if (second[j]) band[j] -= nw;
+        // sun zenith of this element's angle at step 0; rows outside the table belong to elements that are not
+        // stored at step 0 (in front of the slab: the first crossing loads them; behind it: never)
+        const int isza = isza_w + ((second[j] && rem_w == angles_per_sza - 1) ? 1 : 0);
+        const bool live = isza >= isza_base && !(last_step == 0 && off > last_off);
+        const double *bp = sun + (long)(isza - isza_base) * 5 * nw + band[j];
 #pragma unroll
-        for (int q = 0; q < 5; ++q) st.b[j][q] = live ? bp[(long)q * nw] : 0.0;
+        for (int q = 0; q < 5; ++q) b[j][q] = live ? bp[(long)q * nw] : 0.0;
     }
     const double *rec_w = coef + a_w * GRID_COEF_STRIDE;                      // may point at the front pad record
     double *out_w = lut + e0;
     // a wave either never or always has its band wrap inside the chunk (bands are fixed per lane)
     if (band_w + CHUNK - 1 >= nw)
-        flat_loop<DEPTH, NT, true>(st, sun, isza_base, nw, angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
+        flat_loop<DEPTH, NT, true>(b, band, second, isza_w, rem_w, first_off, last_step, last_off, sun, isza_base, nw,
+                                   angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
     else
-        flat_loop<DEPTH, NT, false>(st, sun, isza_base, nw, angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
+        flat_loop<DEPTH, NT, false>(b, band, second, isza_w, rem_w, first_off, last_step, last_off, sun, isza_base, nw,
+                                    angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
 }
 
 // The aligned flat form for ARBITRARY angle lines (every line has its own sun zenith): same chunking and
@@ -1210,6 +1232,15 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin)
     return m == 2 || (m < 0 && !dispatch_round_robin);
 }
 
+static FastDiv make_fast_div(unsigned d)
+{
+    FastDiv f;
+    f.sh = 0;
+    while ((1ull << f.sh) < d) ++f.sh;
+    f.mul = (unsigned)((1ull << (31 + f.sh)) / d + 1);
+    return f;
+}
+
 // Grid and ranges of a flat launch over `useful` logical blocks.  Mode 1: XCD x owns q w[x] blocks, q =
 // ceil(useful / sum w), and gets through them in 32 q workgroup slots whatever its weight (the overshoot of at
 // most sum w blocks falls off the end of the last range).
@@ -1416,7 +1447,8 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
     const long angle0 = row_begin * nphi;
 #define GORT_FLAT(D, N)                                                                                           \
     hipLaunchKernelGGL((expand_flat_kernel<D, N>), grid, dim3(256), 0, s, sun_dev, isza_base, coef_dev, nw,      \
-                       angles_per_sza, angle0, n_total, shift, stride, da, steps, lut_dev,                       \
+                       angles_per_sza, angle0, n_total, shift, stride, da, steps, make_fast_div((unsigned)stride),   \
+                       make_fast_div((unsigned)nw), make_fast_div((unsigned)angles_per_sza), lut_dev,            \
                        xcd_mode, duty, useful, xcd_slots_dev)
     if (tune.nt) {
         if (tune.depth == 1) GORT_FLAT(1, true); else if (tune.depth == 2) GORT_FLAT(2, true); else GORT_FLAT(4, true);

@@ -76,6 +76,10 @@ struct XcdDuty {
     unsigned long long w8;
     long q;
 };
+// exact division of n < 2^31 by a divisor fixed per launch: n / d == (n * mul) >> (31 + sh)
+struct FastDiv {
+    unsigned mul, sh;
+};
 // Measure how fast each XCD writes (the store pattern of expand_flat_kernel over `slab`, whose contents are
 // destroyed) and derive the duty weights that make all XCDs finish together; synchronises `stream`.
 int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weights[8]);

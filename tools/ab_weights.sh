@@ -1,16 +1,13 @@
 #!/bin/bash
-# A/B of XCD duty weights (32nds) on one box, against ab_old/ (a previous build) when present.
+# A/B of builds and settings on one box: label, then env assignments for bench.py
 cd "$(dirname "$0")/.."
-one() { # dir label env...
-  d=$1; label=$2; shift 2
-  (cd $d && env "$@" python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('%-26s %.3f ms/step kernel %.3f ms %.0f GB/s %s' % ('$label', d['ms_per_step'], r['kernel_ms'], r['achieved'], r.get('xcd_weights_32nds', '')))")
+one() { label=$1; shift
+  env "$@" python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('%-28s %.3f ms/step kernel %.3f ms %.0f GB/s %s' % ('$label', d['ms_per_step'], r['kernel_ms'], r['achieved'], r.get('xcd_weights_32nds', '')))"
 }
-for rep in 1 2; do
-  [ -d ab_old ] && one ab_old "OLD"
-  one . "equal" GORT_XCD_CALIBRATE=0
-  one . "calibrated"
-  one . "even32 odd25" GORT_XCD_WEIGHTS=32,25,32,25,32,25,32,25
-  one . "even32 odd27" GORT_XCD_WEIGHTS=32,27,32,27,32,27,32,27
-  one . "even25 odd32" GORT_XCD_WEIGHTS=25,32,25,32,25,32,25,32
+for rep in 1 2 3; do
+  one "occ7 depth2" A=1
+  one "occ8 depth2" GORT_AMD_LIB=$PWD/gort_amd/libgort_amd_occ8.so
+  one "occ8 depth1" GORT_AMD_LIB=$PWD/gort_amd/libgort_amd_occ8.so GORT_EXPAND_DEPTH=1
+  one "occ7 depth1" GORT_EXPAND_DEPTH=1
 done
