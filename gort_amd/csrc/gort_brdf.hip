@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void xcd_pattern_kernel(double *__restrict__ s
     const long block = xcd_logical_block(1, duty, useful, nullptr);
     if (block < 0) return;
     const int xd = blockIdx.x & 7;
-    const bool reports = ((blockIdx.x >> 3) & 63) == 0;
+    const bool reports = t_first && (block & 63) == 0;
     if (reports && threadIdx.x == 0) atomicMin(&t_first[xd], wall_clock64());
     const unsigned wave = (unsigned)(block * 4 + wib);
     const unsigned panel = wave / W, w = wave - panel * W;
@@ -1304,7 +1304,10 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
     const long panels = (chunks + (long)K * W - 1) / ((long)K * W);
     const long useful = (panels * W + 3) / 4;
     int rc = GORT_OK;
-    for (int iter = 0; iter < 4 && rc == GORT_OK; ++iter) {
+    // ONE pass with equal weights: the rates of the XCDs while all of them run.  Iterating on the result drives
+    // the slow XCDs' weights further down (to 25/32), which suits this bare store pattern but not the LUT kernel
+    // (tools/weights_sweep.py: 27-28 is its optimum, 25 already loses half the gain).
+    for (int iter = 0; iter < 1 && rc == GORT_OK; ++iter) {
         XcdDuty duty;
         const long grid = plan_xcd_duty(1, useful, weights, duty);
         unsigned long long host[16];

@@ -703,3 +703,4 @@ def test_ensemble_argument_errors():
     with pytest.raises(api.GortError):       # single-canopy spectra call on a 2-member engine
         e.set_spectra(np.ones(4), np.ones(4) * .1, np.ones(4) * .1)
     e.close()
+
