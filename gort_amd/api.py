@@ -66,7 +66,7 @@ DECLARED_SYMBOLS = [
     "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
-    "gort_rsurf_members_grid_dev",
+    "gort_rsurf_members_grid_dev", "gort_rsurf_members_stream", "gort_rsurf_members_stream_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
@@ -111,6 +111,8 @@ def lib():
         L.gort_rsurf_stream_dev.argtypes = L.gort_rsurf_stream.argtypes
         L.gort_rsurf_grid_dev.argtypes = [C.c_void_p, C.POINTER(Grid), C.c_long, C.c_long, C.c_void_p]
         L.gort_rsurf_members_grid_dev.argtypes = [C.c_void_p, C.POINTER(Grid), C.c_int, C.c_int, C.c_void_p]
+        L.gort_rsurf_members_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
+        L.gort_rsurf_members_stream_dev.argtypes = L.gort_rsurf_members_stream.argtypes
         L.gort_engine_n_members.argtypes = [C.c_void_p]
         L.gort_engine_set_members.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.gort_engine_set_members_leaf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -319,6 +321,15 @@ class Engine:
 
     def rsurf_members_grid_dev(self, grid, member_begin, member_end, lut_t):
         _check(lib().gort_rsurf_members_grid_dev(self.h, C.byref(grid), member_begin, member_end, _ptr(lut_t)))
+
+    def rsurf_members_stream(self, angles_deg, member_begin=0, member_end=None):
+        """The same angle lines for ensemble members [member_begin, member_end): rsurf[member][line][band]."""
+        ang = _f64(angles_deg).reshape(-1, 4)
+        if member_end is None:
+            member_end = lib().gort_engine_n_members(self.h)
+        out = np.empty((member_end - member_begin, ang.shape[0], self.nw))
+        _check(lib().gort_rsurf_members_stream(self.h, _ptr(ang), ang.shape[0], member_begin, member_end, _ptr(out)))
+        return out
 
     def synchronize(self):
         _check(lib().gort_engine_synchronize(self.h))

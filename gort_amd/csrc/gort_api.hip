@@ -411,6 +411,45 @@ extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, 
     return GORT_OK;
 }
 
+// The same angle lines for ensemble members [member_begin, member_end): what an ensemble filter compares with
+// its observations (a few sun/view geometries x a few bands per member, every member in one launch pair).
+extern "C" int gort_rsurf_members_stream_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
+                                             int member_end, double *rsurf_dev)
+{
+    int rc = require_ready(e, "gort_rsurf_members_stream_dev");
+    if (rc) return rc;
+    if (member_begin < 0 || member_end > e->n_members || member_begin > member_end)
+        return fail(GORT_EINVAL, "gort_rsurf_members_stream_dev: members [%d,%d) outside [0,%d)", member_begin,
+                    member_end, e->n_members);
+    if (nA < 0 || (nA > 0 && member_end > member_begin && (!angles_dev || !rsurf_dev)))
+        return fail(GORT_EINVAL, "gort_rsurf_members_stream_dev: bad argument");
+    const int nm = member_end - member_begin;
+    if (nA == 0 || nm == 0) return GORT_OK;
+    if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA * (size_t)nm))) return rc;
+    return launch_members_stream(e->canopy.as<gort_canopy>() + member_begin, nm,
+                                 e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw, e->nw, angles_dev, nA,
+                                 e->coef.as<double>(), rsurf_dev, e->stream);
+}
+
+extern "C" int gort_rsurf_members_stream(gort_engine *e, const double *angles, long nA, int member_begin,
+                                         int member_end, double *rsurf)
+{
+    int rc = require_ready(e, "gort_rsurf_members_stream");
+    if (rc) return rc;
+    if (nA < 0 || member_begin < 0 || member_begin > member_end || (nA > 0 && member_end > member_begin && (!angles || !rsurf)))
+        return fail(GORT_EINVAL, "gort_rsurf_members_stream: bad argument");
+    if (nA == 0 || member_begin == member_end) return GORT_OK;
+    const size_t n = (size_t)nA, total = n * (size_t)e->nw * (size_t)(member_end - member_begin);
+    if ((rc = e->angles.reserve(sizeof(double) * 4 * n))) return rc;
+    if ((rc = e->out.reserve(sizeof(double) * total))) return rc;
+    GORT_HIP(hipMemcpyAsync(e->angles.p, angles, sizeof(double) * 4 * n, hipMemcpyHostToDevice, e->stream));
+    if ((rc = gort_rsurf_members_stream_dev(e, e->angles.as<double>(), nA, member_begin, member_end, e->out.as<double>())))
+        return rc;
+    GORT_HIP(hipMemcpyAsync(rsurf, e->out.p, sizeof(double) * total, hipMemcpyDeviceToHost, e->stream));
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    return GORT_OK;
+}
+
 // ------------------------------------------------------------------ LUT (grid)
 
 // rows are GLOBAL: member * (nsza*nvza) + isza * nvza + ivza

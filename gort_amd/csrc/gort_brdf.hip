@@ -285,13 +285,18 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 {
     const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nA) return;
-    const gort_canopy &c = *canopy;
+    // blockIdx.z = ensemble member: its canopy, its nA records (the angle lines are shared)
+    const long member = blockIdx.z;
+    const gort_canopy &c = canopy[member];
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
     GeomOut g;
     geometry_core(c, vza, sza, raa, g);
-    store_coef(coef + a * GORT_COEF_STRIDE, c, g);
-    if (K) { K[4 * a] = g.Kc;  K[4 * a + 1] = g.Kg;  K[4 * a + 2] = g.Kt;  K[4 * a + 3] = g.Kz; }
+    store_coef(coef + (member * nA + a) * GORT_COEF_STRIDE, c, g);
+    if (K) {
+        double *k = K + 4 * (member * nA + a);
+        k[0] = g.Kc;  k[1] = g.Kg;  k[2] = g.Kt;  k[3] = g.Kz;
+    }
 }
 
 // grid nodes generated from indices; identical to streaming "vza phi sza 0" (SURVEY 8d, C3).
@@ -439,11 +444,19 @@ __global__ __launch_bounds__(256) void expand_stream_kernel(const gort_canopy *_
                                                              const double *__restrict__ coef, long n_samples,
                                                              double *__restrict__ rsurf, double *__restrict__ scomp)
 {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_samples) return;
     const long a = idx / nw;
     const int i = (int)(idx - a * nw);
+    // blockIdx.z = ensemble member: canopy, band table, records and output of that member (n_samples each)
+    const long member = blockIdx.z;
+    canopy += member;
+    L += member * L_NSLOT * nw;
     const double *rec = coef + a * GORT_COEF_STRIDE;
+    if (member) {                                   // uniform branch; single-canopy launches skip the division
+        rec += member * (n_samples / nw) * GORT_COEF_STRIDE;
+        idx += member * n_samples;
+    }
     const SunScalars s = load_sun(rec);
     const SunTerms b = sun_terms(L, nw, i, s, canopy->k_open, canopy->k_openep);
     rsurf[idx] = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], b.C0, b.B, b.Z, b.G, b.T);
@@ -1088,6 +1101,23 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
     hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)rows), dim3(GEOM_ROW_THREADS), 0, (hipStream_t)stream,
                        canopy_dev, g, row_begin, coef_dev, compact ? 1 : 0);
     return check_launch("geometry_grid_kernel");
+}
+
+// nA angle lines for each of n_members members (member-major records and outputs); one thread per sample
+int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
+                          const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream)
+{
+    const long n = nA * nw;
+    if (n <= 0 || n_members <= 0) return GORT_OK;
+    if (n_members > 65535) return fail(GORT_EINVAL, "members stream: %d members in one launch (max 65535)", n_members);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(geometry_stream_kernel, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0, s,
+                       canopies_dev, angles_dev, nA, coef_dev, (double *)nullptr);
+    int rc = check_launch("geometry_stream_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(expand_stream_kernel<false>, dim3((unsigned)((n + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
+                       s, canopies_dev, L_dev, nw, coef_dev, n, rsurf_dev, (double *)nullptr);
+    return check_launch("expand_stream_kernel");
 }
 
 static bool stream_uses_flat(int nw, long nA, bool want_scomp);

@@ -93,6 +93,9 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin);
 long expand_stream_tail_pad_records(int nw, long nA);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
                          long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream);
+// the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
+int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
+                          const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);
 // sun rows q = member * nsza + isza, q in [q_begin, q_end): sun_dev[q - q_begin][5][nw]
 int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int nw, const gort_grid &g,
                      int q_begin, int q_end, double *sun_dev, void *stream);

@@ -190,6 +190,14 @@ int  gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, lon
  * one launch sequence for all of them (needs nw >= 128). */
 int  gort_rsurf_members_grid_dev(gort_engine *e, const gort_grid *g, int member_begin, int member_end,
                                  double *lut_dev);
+/* The same nA angle lines for ensemble members [member_begin, member_end): rsurf[member][nA][nw] - the
+ * observation vector of every member of an ensemble filter in one launch pair (the
+ * reference has no such code, each member equals a forward run of gortt with that member's flags). */
+int  gort_rsurf_members_stream(gort_engine *e, const double *angles, long nA, int member_begin, int member_end,
+                               double *rsurf);
+int  gort_rsurf_members_stream_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
+                                   int member_end, double *rsurf_dev);
+
 /* kernel-only timing hook for bench.py: average duration (ms) of the LUT expansion
  * kernel over the launches since the last call, measured with HIP events on the
  * engine's stream; returns <0 if none. */

@@ -704,3 +704,72 @@ def test_ensemble_argument_errors():
         e.set_spectra(np.ones(4), np.ones(4) * .1, np.ones(4) * .1)
     e.close()
 
+
+# ------------------------------------------------------- ensemble-facing layer
+def _oracle_forward(state, wl, angles):
+    """One forward run of the reference's algorithm for a member, the way gortt would be called for it."""
+    from gort_amd.ensemble import f32
+    oc = O.make_canopy(newstyle=(f32(state["HB"]), f32(state["BR"]), f32(state["PCC"])), lai=f32(state["LAI"]))
+    rs, rl, tl = O.spectra(wl, rsl=(state["rsl1"], 0.1, 0.03726, -0.002426),
+                           prospect=dict(N=state["N"], Cab=state["Cab"], Car=state["Car"], Cw=state["Cw"], Cm=state["Cm"]))
+    r, _, _ = O.rsurf_stream(oc, angles, rs, rl, tl, want_K=False)
+    return r
+
+
+def test_members_stream_equals_forward_runs():
+    """gort_rsurf_members_stream: every member's observation vector equals (a) the oracle's forward run with
+    that member's parameters and (b), bitwise, a single-canopy engine given the same canopy and spectra."""
+    from gort_amd.ensemble import DEFAULT, Ensemble
+    rng = np.random.default_rng(2024)
+    wl = np.array([450.0, 555.0, 645.0, 858.5, 1240.0, 1640.0, 2130.0])         # MODIS land bands
+    angles = np.stack([rng.uniform(-70, 70, 24), rng.uniform(0, 360, 24), rng.uniform(0, 75, 24), rng.uniform(0, 360, 24)], 1)
+    states = []
+    for _ in range(37):
+        s = dict(DEFAULT)
+        s.update(HB=rng.uniform(1, 3), BR=rng.uniform(1, 3.5), PCC=rng.uniform(0.2, 0.8), LAI=rng.uniform(0.5, 6),
+                 N=rng.uniform(1, 2.5), Cab=rng.uniform(10, 60), Car=rng.uniform(2, 15), Cw=rng.uniform(0.005, 0.03),
+                 Cm=rng.uniform(0.002, 0.015), rsl1=rng.uniform(0.05, 0.4))
+        states.append(s)
+    ens = Ensemble(wl).set_states(states)
+    r = ens.observe(angles)
+    assert r.shape == (37, 24, 7) and np.isfinite(r).all()
+    part = ens.observe(angles, 5, 9)
+    assert np.array_equal(part, r[5:9])
+    single = api.Engine()
+    for m in (0, 11, 36):
+        assert err(r[m], _oracle_forward(states[m], wl, angles)) <= REGRESSION
+        c, rs, rl, tl = ens.eng.get_member(m)
+        single.set_canopy(c)
+        single.set_spectra(rs, rl, tl)
+        one, _, _ = single.rsurf_stream(angles, want_K=False)
+        assert np.array_equal(one, r[m])
+    # albedo / fAPAR table of the members against the single-canopy path
+    e3 = ens.albedo(angles[:3], 10, 13)
+    c, rs, rl, tl = ens.eng.get_member(11)
+    single.set_canopy(c)
+    single.set_spectra(rs, rl, tl)
+    assert np.array_equal(e3[1], single.energy_stream(angles[:3]))
+    single.close()
+    ens.close()
+    with pytest.raises(api.GortError):
+        Ensemble(wl).set_states(states[:2]).eng.rsurf_members_stream(angles, 1, 5)
+
+
+def test_finite_difference_jacobian_is_the_forward_model():
+    """The Jacobian is nothing but forward runs: each column equals the central difference of two oracle runs
+    at the same (float32-rounded) parameters, and the ensemble of 2P+1 members ran in one launch pair."""
+    from gort_amd.ensemble import DEFAULT, STATE, f32, jacobian
+    wl = np.array([555.0, 645.0, 858.5, 1640.0])
+    angles = np.array([[0.0, 0.0, 30.0, 0.0], [35.0, 180.0, 30.0, 0.0], [-50.0, 90.0, 45.0, 0.0]])
+    state = dict(DEFAULT, HB=1.7, BR=2.4, PCC=0.55, LAI=3.1, Cab=42.0)
+    r0, J, steps = jacobian(wl, state, angles, rel_step=2e-3)
+    assert J.shape == (len(STATE), 3, 4)
+    assert err(r0, _oracle_forward(state, wl, angles)) <= REGRESSION
+    for k, p in enumerate(STATE):
+        h = abs(state[p]) * 2e-3
+        lo, hi = dict(state), dict(state)
+        lo[p], hi[p] = state[p] - h, state[p] + h
+        ref = (_oracle_forward(hi, wl, angles) - _oracle_forward(lo, wl, angles)) / (2.0 * steps[k])
+        assert np.max(np.abs(J[k] - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref))), p
+    # sanity of the physics a filter relies on: more leaf chlorophyll darkens the green band in every direction
+    assert (J[STATE.index("Cab"), :, 0] < 0).all()
