@@ -73,7 +73,7 @@ def build(force=False, verbose_resources=False):
     main = os.path.join(SRC, "gortt_main.cpp")
     if os.path.exists(main) and (force or _newer(BIN, [main, LIB] + headers)):
         _run([cc, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), main, "-o", BIN,
-              "-L" + PKG, "-lgort_amd", "-Wl,-rpath,$ORIGIN/.."])
+              "-L" + PKG, "-lgort_amd", "-pthread", "-Wl,-rpath,$ORIGIN/.."])
     return LIB
 
 

@@ -20,8 +20,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <sched.h>
 #include <string>
 #include <strings.h>
+#include <thread>
 #include <vector>
 
 #include "gort_amd.h"
@@ -249,6 +252,22 @@ struct Out {
     }
 };
 
+// worker threads for formatting `values` numbers: one per ~16k values, at most the cores we may run on
+unsigned format_threads(size_t values)
+{
+    if (const char *v = std::getenv("GORTT_THREADS")) {
+        const int t = atoi(v);
+        if (t > 0) return (unsigned)t;
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = (unsigned)CPU_COUNT(&set);
+    if (hw == 0) hw = 1;
+    if (hw > 32) hw = 32;
+    const size_t want = values / 16384;
+    return want < 2 ? 1u : (want < hw ? (unsigned)want : hw);
+}
+
 void check(int rc)
 {
     if (rc != GORT_OK) die("%s: %s\n", g_prog, gort_last_error());
@@ -362,25 +381,45 @@ int main(int argc, char **argv)
                 if (o.prnprop) std::fwrite(&K[4 * a], sizeof(double), 4, stdout);
                 if (o.energy) std::fwrite(&energy[(size_t)a * nw * 3], sizeof(double), (size_t)nw * 3, stdout);
             }
-            for (long a = 0; !o.binary_out && a < n; ++a) {
-                for (int q = 0; q < 4; ++q) out.raw(ang[4 * a + q]);
-                for (int i = 0; i < nw; ++i) {
-                    out.num(rsurf[(size_t)a * nw + i]);
-                    if (o.prnspec) {
-                        out.buf += "{ ";
-                        for (int q = 0; q < 4; ++q) out.num(scomp[((size_t)a * nw + i) * 4 + q]);
-                        out.buf += "} ";
+            // text rows: the formatting (exact "%f", gort_format_f6) is the slowest stage of the whole program, so
+            // the lines of a chunk are formatted by several threads into their own buffers and written in order
+            auto format_lines = [&](long a0, long a1, Out &dst) {
+                for (long a = a0; a < a1; ++a) {
+                    for (int q = 0; q < 4; ++q) dst.raw(ang[4 * a + q]);
+                    for (int i = 0; i < nw; ++i) {
+                        dst.num(rsurf[(size_t)a * nw + i]);
+                        if (o.prnspec) {
+                            dst.buf += "{ ";
+                            for (int q = 0; q < 4; ++q) dst.num(scomp[((size_t)a * nw + i) * 4 + q]);
+                            dst.buf += "} ";
+                        }
                     }
+                    if (o.prnprop) {
+                        dst.buf += "[ ";
+                        for (int q = 0; q < 4; ++q) dst.num(nw > 0 ? K[4 * a + q] : 0.0);
+                        dst.buf += "] ";
+                    }
+                    if (o.energy)
+                        for (int i = 0; i < 3 * nw; ++i) dst.num(energy[(size_t)a * nw * 3 + i]);
+                    dst.buf += "\n";
                 }
-                if (o.prnprop) {
-                    out.buf += "[ ";
-                    for (int q = 0; q < 4; ++q) out.num(nw > 0 ? K[4 * a + q] : 0.0);
-                    out.buf += "] ";
+            };
+            if (!o.binary_out) {
+                const size_t per_line = 4 + (size_t)nw * (o.prnspec ? 5 : 1) + (o.prnprop ? 4 : 0) + (o.energy ? 3 * (size_t)nw : 0);
+                unsigned workers = format_threads((size_t)n * per_line);
+                if (workers <= 1) {
+                    for (long a0 = 0; a0 < n; a0 += 4096) {
+                        format_lines(a0, a0 + 4096 < n ? a0 + 4096 : n, out);
+                        out.flush();
+                    }
+                } else {
+                    std::vector<Out> parts(workers);
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 0; t < workers; ++t)
+                        pool.emplace_back(format_lines, n * (long)t / workers, n * (long)(t + 1) / workers, std::ref(parts[t]));
+                    for (auto &th : pool) th.join();
+                    for (auto &part : parts) part.flush();
                 }
-                if (o.energy)
-                    for (int i = 0; i < 3 * nw; ++i) out.num(energy[(size_t)a * nw * 3 + i]);
-                out.buf += "\n";
-                if (out.buf.size() > (1u << 20)) out.flush();
             }
             out.flush();
             na += n;
