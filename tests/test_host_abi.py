@@ -165,3 +165,22 @@ def test_format_f6_equals_printf():
         want = "%f" % x
         assert f6(float(x)) == want, (repr(float(x)), f6(float(x)), want)
     assert f6(float("nan")) == "-nan" and f6(-float("nan")) == "-nan"
+
+
+def test_ensemble_state_vector_to_gortt_inputs():
+    """gort_amd.ensemble.member_inputs: a state vector becomes what `gortt -HB .. -BR .. -PCC .. -LAI ..` with
+    PROSPECT-D / Price parameters would build (float32 flag parse included); host-only, no GPU."""
+    from gort_amd import api
+    from gort_amd.ensemble import DEFAULT, STATE, f32, member_inputs
+    assert STATE[:4] == ("HB", "BR", "PCC", "LAI") and set(STATE) == set(DEFAULT)
+    state = dict(DEFAULT, HB=1.7, BR=2.4, PCC=0.55, LAI=3.1, Cab=42.0, rsl1=0.31)
+    c, leaf = member_inputs(state)
+    ref = api.make_canopy(newstyle=(f32(1.7), f32(2.4), f32(0.55)), lai=f32(3.1))
+    for name in ("favd", "r", "b", "h1", "h2", "lambda_"):
+        assert getattr(c, name) == getattr(ref, name), name
+    assert leaf.Cab == 42.0 and leaf.N == DEFAULT["N"] and leaf.rsl[0] == 0.31 and leaf.rsl[1] == 0.1
+    c2, _ = member_inputs([state[k] for k in STATE])            # sequence form, STATE order
+    assert c2.favd == c.favd and c2.h2 == c.h2
+    # gort_canopy_newstyle takes the flags as float, like the reference's parser: rounding them beforehand is idempotent
+    c3 = api.make_canopy(newstyle=(1.7, 2.4, 0.55), lai=3.1)
+    assert c3.favd == c.favd and c3.r == c.r
