@@ -62,6 +62,16 @@ struct gort_engine {
     // duty weights of the XCDs (32nds) for the static mapping; calibrated on the first LUT slab big enough
     int xcd_weights[8] = {32, 32, 32, 32, 32, 32, 32, 32};
     bool xcd_calibrated = false;
+    // Small LUT slabs (the per-rank slabs of a multi-GPU run) are pipelined over two streams: geometry and sun
+    // table of call i+1 run on `aux` into the other half of a double buffer while the expansion of call i is
+    // still writing.  Only while both halves stay in the 256 MB Infinity Cache (PIPELINE_MAX_BYTES per half):
+    // for the 191 MB of records of the full grid it costs 14 % instead (see grid_rows).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_tables = nullptr, ev_geom[2] = {nullptr, nullptr}, ev_expand[2] = {nullptr, nullptr};
+    bool tables_recorded = false, expand_recorded[2] = {false, false};
+    DevBuf gcoef[2], gsun[2];
+    unsigned long grid_calls = 0;
+    bool pipeline = true;                // GORT_GRID_PIPELINE=0: everything on `stream`
     int n_members = 1;
     bool have_canopy = false, have_spectra = false, have_nodes = false, have_tables = false;
     int nw = 0;
@@ -137,10 +147,17 @@ extern "C" int gort_engine_create(gort_engine **out)
     if (gort_device_count() <= 0) return fail(GORT_ENODEVICE, "gort_engine_create: no HIP device");
     gort_engine *e = new (std::nothrow) gort_engine();
     if (!e) return fail(GORT_ENOMEM, "gort_engine_create: out of memory");
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+    bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&e->ev_tables, hipEventDisableTiming) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b)
+        ok = hipEventCreateWithFlags(&e->ev_geom[b], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&e->ev_expand[b], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         gort_engine_destroy(e);
-        return fail(GORT_ENODEVICE, "gort_engine_create: cannot create stream");
+        return fail(GORT_ENODEVICE, "gort_engine_create: cannot create streams/events");
     }
+    if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = atoi(v) == 0;        // 0: equal weights
     if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
         int w[8];
@@ -156,7 +173,12 @@ extern "C" int gort_engine_create(gort_engine **out)
 extern "C" void gort_engine_destroy(gort_engine *e)
 {
     if (!e) return;
+    if (e->aux) (void)hipStreamSynchronize(e->aux);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (DevBuf *b : {&e->gcoef[0], &e->gcoef[1], &e->gsun[0], &e->gsun[1]}) b->release();
+    for (hipEvent_t ev : {e->ev_tables, e->ev_geom[0], e->ev_geom[1], e->ev_expand[0], e->ev_expand[1]})
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
                       &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots})
         b->release();
@@ -222,18 +244,25 @@ extern "C" int gort_engine_n_members(const gort_engine *e) { return e ? e->n_mem
 extern "C" int gort_engine_synchronize(gort_engine *e)
 {
     if (!e) return fail(GORT_EINVAL, "gort_engine_synchronize: null engine");
+    GORT_HIP(hipStreamSynchronize(e->aux));
     GORT_HIP(hipStreamSynchronize(e->stream));
     return GORT_OK;
 }
 
-// band-only tables of every member, L[n][11][nw]
+// band-only tables of every member, L[n][11][nw]; every setter ends here, so this is also where the aux
+// stream learns that canopies / spectra / tables changed
 static int refresh_lambda_table(gort_engine *e)
 {
-    if (!e->have_canopy || !e->have_spectra) return GORT_OK;
-    int rc = e->L.reserve(sizeof(double) * L_NSLOT * (size_t)e->nw * (size_t)e->n_members);
-    if (rc) return rc;
-    return launch_lambda_table(e->canopy.as<gort_canopy>(), e->n_members, e->nw, e->spectra.as<double>(),
-                               e->L.as<double>(), e->stream);
+    int rc = GORT_OK;
+    if (e->have_canopy && e->have_spectra) {
+        rc = e->L.reserve(sizeof(double) * L_NSLOT * (size_t)e->nw * (size_t)e->n_members);
+        if (rc) return rc;
+        rc = launch_lambda_table(e->canopy.as<gort_canopy>(), e->n_members, e->nw, e->spectra.as<double>(),
+                                 e->L.as<double>(), e->stream);
+    }
+    GORT_HIP(hipEventRecord(e->ev_tables, e->stream));
+    e->tables_recorded = true;
+    return rc;
 }
 
 static int upload_canopies(gort_engine *e, const gort_canopy *members, int n, int compute_gaps)
@@ -468,22 +497,37 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr,
                                     e->stream);
     }
-    // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).  ONE buffer, reused
-    // by every call: the 191 MB of records the geometry kernel writes are still in the 256 MB Infinity Cache when
-    // the expansion fetches them.  Double-buffering them to overlap the next call's geometry with this call's
-    // expansion was tried and cost 14 % (8.0 against 7.0 ms): two buffers do not fit, the record and sun-term
-    // fetches in the waves' prologues then come from HBM, and those short-lived waves are latency-bound.
+    // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).
+    // Full-size slabs: ONE buffer, reused by every call - the 191 MB of records the geometry kernel writes are
+    // still in the 256 MB Infinity Cache when the expansion fetches them.  Double-buffering them to overlap the
+    // next call's geometry with this call's expansion cost 14 % there (8.0 against 7.0 ms): two buffers do not
+    // fit, the record and sun-term fetches in the waves' prologues then come from HBM, and those short-lived
+    // waves are latency-bound.  Small slabs (the per-rank slabs of a multi-GPU run): both halves fit, and the
+    // pipeline hides the 0.04-0.06 ms of geometry, sun table and launch gaps per call (4 % at N = 8).
     const long tail = expand_grid_tail_pad_records(nw, nA * (long)nw);
     const size_t coef_bytes = sizeof(double) * 8 * (size_t)(nA + 1 + tail);
-    const bool fresh = coef_bytes > e->coef.cap;
-    if ((rc = e->coef.reserve(coef_bytes))) return rc;
-    if (fresh) GORT_HIP(hipMemsetAsync(e->coef.p, 0, coef_bytes, e->stream));      // pads hold finite values
-    double *coef8 = e->coef.as<double>() + 8;
-    if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, coef8, true, e->stream))) return rc;
-    // sun rows q = member*nsza + isza touched by [row_begin, row_end)
-    const int q0 = (int)(row_begin / g->nvza), q1 = (int)((row_end - 1) / g->nvza) + 1;
-    if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(q1 - q0)))) return rc;
-    if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, e->sun.as<double>(), e->stream))) return rc;
+    const int q0 = (int)(row_begin / g->nvza), q1 = (int)((row_end - 1) / g->nvza) + 1;   // sun rows q = member*nsza + isza
+    const size_t sun_bytes = sizeof(double) * 5 * (size_t)nw * (size_t)(q1 - q0);
+    constexpr size_t PIPELINE_MAX_BYTES = 64u << 20;
+    const bool piped = e->pipeline && coef_bytes + sun_bytes <= PIPELINE_MAX_BYTES;
+    const int half = piped ? (int)(e->grid_calls++ & 1) : 0;
+    DevBuf &coef_buf = piped ? e->gcoef[half] : e->coef, &sun_buf = piped ? e->gsun[half] : e->sun;
+    hipStream_t gs = piped ? e->aux : e->stream;
+    if (piped) {
+        if (e->tables_recorded) GORT_HIP(hipStreamWaitEvent(gs, e->ev_tables, 0));
+        if (e->expand_recorded[half]) GORT_HIP(hipStreamWaitEvent(gs, e->ev_expand[half], 0));   // last reader of this half
+    }
+    const bool fresh = coef_bytes > coef_buf.cap;
+    if ((rc = coef_buf.reserve(coef_bytes))) return rc;
+    if (fresh) GORT_HIP(hipMemsetAsync(coef_buf.p, 0, coef_bytes, gs));      // pads hold finite values
+    double *coef8 = coef_buf.as<double>() + 8;
+    if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, coef8, true, gs))) return rc;
+    if ((rc = sun_buf.reserve(sun_bytes))) return rc;
+    if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, sun_buf.as<double>(), gs))) return rc;
+    if (piped) {
+        GORT_HIP(hipEventRecord(e->ev_geom[half], gs));
+        GORT_HIP(hipStreamWaitEvent(e->stream, e->ev_geom[half], 0));
+    }
     int *xcd_slots = nullptr;
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     if (!xcd_slots && !e->xcd_calibrated && nA * (long)nw >= (1L << 27)) {
@@ -502,11 +546,15 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         }
         GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
-    rc = launch_expand_grid(e->sun.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
+    rc = launch_expand_grid(sun_buf.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
                             xcd_slots, e->xcd_weights, e->stream);
     if (timed) {
         GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;
+    }
+    if (piped) {
+        GORT_HIP(hipEventRecord(e->ev_expand[half], e->stream));
+        e->expand_recorded[half] = true;
     }
     return rc;
 }
