@@ -773,3 +773,53 @@ def test_finite_difference_jacobian_is_the_forward_model():
         assert np.max(np.abs(J[k] - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref))), p
     # sanity of the physics a filter relies on: more leaf chlorophyll darkens the green band in every direction
     assert (J[STATE.index("Cab"), :, 0] < 0).all()
+
+
+def test_grid_pipeline_equals_single_stream():
+    """LUT calls whose records fit the double buffer are pipelined over two streams (geometry of call i+1 under
+    the expansion of call i); larger ones and engines with GORT_GRID_PIPELINE=0 use one stream.  A sequence that
+    mixes slab sizes, row ranges and canopy/spectra updates between calls must give the same bytes either way."""
+    import torch
+    wl = np.linspace(400.0, 2500.0, 131)
+    small = api.hemisphere_grid(9, 11, 361)                     # 35 739 angles: piped
+    big = api.hemisphere_grid(40, 91, 361)                      # 1.3e6 angles, 84 MB of records: single stream
+    canopies = [gpu_canopy(lai=l) for l in (1.5, 4.0, 6.5)]
+    spectra = [api.spectra(wl, api.leaf_soil(prospect=dict(Cab=c))) for c in (20.0, 45.0)]
+
+    def run(pipeline):
+        os.environ["GORT_GRID_PIPELINE"] = "1" if pipeline else "0"
+        try:
+            e = api.Engine()
+        finally:
+            del os.environ["GORT_GRID_PIPELINE"]
+        outs = []
+        lut_s = [torch.empty((small.nsza * small.nvza * small.nphi, wl.size), dtype=torch.float64, device="cuda") for _ in range(3)]
+        lut_b = torch.empty((big.nsza * big.nvza * big.nphi, wl.size), dtype=torch.float64, device="cuda")
+        e.set_canopy(canopies[0]); e.set_spectra(*spectra[0])
+        rows_s = small.nsza * small.nvza
+        e.rsurf_grid_dev(small, 0, rows_s, lut_s[0])
+        e.rsurf_grid_dev(small, 7, rows_s - 5, lut_s[1][7 * small.nphi:])          # back to back, other half
+        e.set_canopy(canopies[1])                                                   # update between piped calls
+        e.rsurf_grid_dev(small, 0, rows_s, lut_s[2])
+        e.rsurf_grid_dev(big, 0, big.nsza * big.nvza, lut_b)                        # single-stream call in between
+        e.synchronize()
+        outs += [lut_s[0].clone(), lut_s[1][7 * small.nphi:(rows_s - 5) * small.nphi].clone(), lut_s[2].clone(),
+                 lut_b[::977].clone()]
+        e.set_spectra(*spectra[1]); e.set_canopy(canopies[2])
+        for k in range(3):                                                          # three more piped calls in a row
+            e.rsurf_grid_dev(small, k, rows_s - k, lut_s[k][k * small.nphi:])
+        e.synchronize()
+        outs += [lut_s[k][k * small.nphi:(rows_s - k) * small.nphi].clone() for k in range(3)]
+        e.close()
+        return outs
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) == 7
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.int64), y.view(torch.int64))
+    # and the values are the model's: spot-check the last state against the oracle
+    oc = oracle_like(canopies[2])
+    ang = np.array([[5.0, 17.0, 3.0, 0.0], [9.0, 200.0, 8.0, 0.0]])
+    ref, _, _ = O.rsurf_stream(oc, ang, *spectra[1], want_K=False)
+    got = a[4].view(small.nsza * small.nvza, small.nphi, wl.size).cpu().numpy()
+    assert err(np.stack([got[3 * small.nvza + 5, 17], got[8 * small.nvza + 9, 200]]), ref) <= REGRESSION
