@@ -71,19 +71,20 @@ int main(int argc, char **argv)
     hipMemAccessDesc acc = {};
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         void *va = nullptr;
         CK(hipMemAddressReserve(&va, slab, 0, nullptr, 0));
         for (long j = 0; j < ns; ++j) {
             long src = j;                                   // mode 0: creation order
             if (mode == 1) src = (j * stride) % nh;         // mode 1: strided through the pool
             if (mode == 2) src = (j % 8) * (nh / 8) + j / 8; // mode 2: round-robin over eight eighths of the pool
+            if (mode == 3) { const long w = j * 8 / ns; src = w * (nh / 8) + (j - (w * ns + 7) / 8); }   // mode 3: window x of the slab = one contiguous run in eighth x of the pool
             CK(hipMemMap((char *)va + j * gran, gran, 0, h[src], 0));
         }
         CK(hipMemSetAccess(va, slab, &acc, 1));
         const float ms = run((double *)va, (long)slab);
         printf("mode %d (%s): %.3f ms  %.0f GB/s\n", mode,
-               mode == 0 ? "creation order" : (mode == 1 ? "strided" : "round-robin over eighths"), ms, slab / ms / 1e6);
+               mode == 0 ? "creation order" : (mode == 1 ? "strided" : (mode == 2 ? "round-robin over eighths" : "window-aligned runs")), ms, slab / ms / 1e6);
         CK(hipMemUnmap(va, slab));
         CK(hipMemAddressFree(va, slab));
     }
