@@ -823,3 +823,39 @@ def test_grid_pipeline_equals_single_stream():
     ref, _, _ = O.rsurf_stream(oc, ang, *spectra[1], want_K=False)
     got = a[4].view(small.nsza * small.nvza, small.nphi, wl.size).cpu().numpy()
     assert err(np.stack([got[3 * small.nvza + 5, 17], got[8 * small.nvza + 9, 200]]), ref) <= REGRESSION
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))        # RCCL, the calls bench.py makes at N > 1
+from gort_amd import api
+from gort_amd.shard import all_gather_lut, row_slab
+wl = np.linspace(400.0, 2500.0, 140)
+e = api.Engine(); e.set_canopy(api.gap_probabilities(api.make_canopy(lai=3.0))); e.set_spectra(*api.spectra(wl))
+g = api.hemisphere_grid(6, 8, 361)
+rows = g.nsza * g.nvza
+r0, r1 = row_slab(0, 1, rows)
+lut = torch.empty(((r1 - r0) * g.nphi, wl.size), dtype=torch.float64, device="cuda")
+e.rsurf_grid_dev(g, r0, r1, lut); e.synchronize(); torch.cuda.synchronize()
+dist.barrier()
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+full = all_gather_lut(lut.view(r1 - r0, g.nphi * wl.size), rows)
+torch.cuda.synchronize()
+assert float(t.item()) == 1.25 and torch.equal(full.view(torch.int64), lut.view(r1 - r0, -1).view(torch.int64))
+dist.destroy_process_group()
+print("rccl ok")
+"""
+
+
+def test_rccl_calls_of_the_multi_gpu_path_on_one_rank():
+    """The RCCL side of bench.py (nccl process group bound to the device, barrier, MAX all-reduce of a device
+    scalar, all_gather_into_tensor of the LUT slab) executed for real - with the one rank a 1-GPU box allows."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run(["python3", "-c", _RCCL_SCRIPT % root], capture_output=True, timeout=300)
+    assert run.returncode == 0, run.stderr.decode()[-3000:]
+    assert run.stdout.decode().strip().endswith("rccl ok")
