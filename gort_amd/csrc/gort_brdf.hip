@@ -300,33 +300,46 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 }
 
 // grid nodes generated from indices; identical to streaming "vza phi sza 0" (SURVEY 8d, C3).
-// One workgroup per LUT row = (member, sun zenith, view zenith): the azimuth-independent terms are
-// evaluated ONCE per row into LDS (one lane), then the lanes walk the nphi azimuth nodes.  With 361 nodes per
-// row this removes ~70 % of the transcendentals of the per-tuple form.
+// One workgroup per GEOM_ROWS LUT rows, a row = (member, sun zenith, view zenith): the azimuth-independent terms
+// of each row are evaluated ONCE into LDS, the rows side by side on the first lanes of one wavefront (the ~25
+// transcendentals of a row are a serial chain: four rows cost the issue time of one), then the lanes walk the
+// GEOM_ROWS x nphi azimuth nodes.  With 361 nodes per row this removes ~70 % of the transcendentals of the
+// per-tuple form.
 constexpr int GEOM_ROW_THREADS = 128;
+constexpr int GEOM_ROWS = 4;
 __global__ __launch_bounds__(GEOM_ROW_THREADS) void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
-                                                                          gort_grid g, long row_begin,
+                                                                          gort_grid g, long row_begin, long n_rows,
                                                                           double *__restrict__ coef, int compact)
 {
-    __shared__ RowTerms s_row;
+    __shared__ RowTerms s_row[GEOM_ROWS];
+    __shared__ int s_member[GEOM_ROWS];
+    __shared__ double s_vza_deg[GEOM_ROWS], s_sza_deg[GEOM_ROWS];
     const long rows_per_member = (long)g.nsza * g.nvza;
-    const long grow = row_begin + blockIdx.x;
-    const long member = grow / rows_per_member;
-    const long row = grow - member * rows_per_member;
-    const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
-    const gort_canopy &c = canopies[member];
-    const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
-    double vza, sza, saa, raa;
-    if (threadIdx.x == 0) {
+    const long first = (long)blockIdx.x * GEOM_ROWS;                   // first row of this block, relative to row_begin
+    const int rows_here = n_rows - first < GEOM_ROWS ? (int)(n_rows - first) : GEOM_ROWS;
+    if ((int)threadIdx.x < rows_here) {
+        const long grow = row_begin + first + threadIdx.x;
+        const long member = grow / rows_per_member;
+        const long row = grow - member * rows_per_member;
+        const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
+        const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
+        double vza, sza, saa, raa;
         normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
-        row_terms(c, vza, sza, s_row);
+        row_terms(canopies[member], vza, sza, s_row[threadIdx.x]);
+        s_member[threadIdx.x] = (int)member;
+        s_vza_deg[threadIdx.x] = vza_deg;
+        s_sza_deg[threadIdx.x] = sza_deg;
     }
     __syncthreads();
-    for (int l = threadIdx.x; l < g.nphi; l += GEOM_ROW_THREADS) {
-        normalise_angles(vza_deg, g.phi0 + l * g.dphi, sza_deg, 0.0, vza, sza, saa, raa);
+    const int nodes = rows_here * g.nphi;
+    for (int n = threadIdx.x; n < nodes; n += GEOM_ROW_THREADS) {
+        const int r = n / g.nphi, l = n - r * g.nphi;
+        const gort_canopy &c = canopies[s_member[r]];
+        double vza, sza, saa, raa;
+        normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
         GeomOut o;
-        finish_angle(c, s_row, raa, o);
-        const long i = (long)blockIdx.x * g.nphi + l;
+        finish_angle(c, s_row[r], raa, o);
+        const long i = first * g.nphi + n;
         if (compact) {
             // LUT path: only the five expansion coefficients, one 64-B record per node
             double rec[GORT_COEF_STRIDE];
@@ -1098,8 +1111,8 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
 {
     const long rows = row_end - row_begin;
     if (rows <= 0) return GORT_OK;
-    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)rows), dim3(GEOM_ROW_THREADS), 0, (hipStream_t)stream,
-                       canopy_dev, g, row_begin, coef_dev, compact ? 1 : 0);
+    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
+                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, coef_dev, compact ? 1 : 0);
     return check_launch("geometry_grid_kernel");
 }
 
