@@ -338,7 +338,8 @@ int main(int argc, char **argv)
     long na = 0;
     bool bad_line = false, eof = false;
     std::vector<double> ang, rsurf, scomp, K, energy;
-    std::string line;
+    std::string line, text;
+    std::vector<size_t> offsets;
     Out out;
     while (!eof && !bad_line) {
         ang.clear();
@@ -349,12 +350,35 @@ int main(int argc, char **argv)
             ang.resize(got - got % 4);
             if (got < (size_t)CHUNK * 4) eof = true;
         } else {
-            while ((long)(ang.size() / 4) < CHUNK) {
+            // the chunk's lines are collected NUL-terminated (strtod must not run on into the next line) and
+            // parsed by several threads; the first line that does not hold four numbers ends the input there
+            text.clear();
+            offsets.clear();
+            while ((long)offsets.size() < CHUNK) {
                 if (!read_line(stdin, line)) { eof = true; break; }
-                double v[4];
-                if (!parse_angles(line.c_str(), v)) { bad_line = true; break; }
-                ang.insert(ang.end(), v, v + 4);
+                offsets.push_back(text.size());
+                text += line;
+                text.push_back('\0');
             }
+            const long nl = (long)offsets.size();
+            ang.resize((size_t)nl * 4);
+            const unsigned workers = format_threads((size_t)nl * 64);            // ~4 strtod calls per line
+            std::vector<long> first_bad(workers, nl);
+            auto parse_lines = [&](unsigned t) {
+                const long a0 = nl * (long)t / workers, a1 = nl * (long)(t + 1) / workers;
+                for (long a = a0; a < a1; ++a)
+                    if (!parse_angles(text.data() + offsets[(size_t)a], &ang[(size_t)a * 4])) { first_bad[t] = a; break; }
+            };
+            if (workers <= 1) {
+                parse_lines(0);
+            } else {
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < workers; ++t) pool.emplace_back(parse_lines, t);
+                for (auto &th : pool) th.join();
+            }
+            long good = nl;
+            for (unsigned t = 0; t < workers; ++t) good = first_bad[t] < good ? first_bad[t] : good;
+            if (good < nl) { bad_line = true; ang.resize((size_t)good * 4); }
         }
         const long n = (long)(ang.size() / 4);
         if (n > 0) {
