@@ -238,6 +238,7 @@ def main():
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
                          "xcd_mapping": eng.xcd_mapping(), "xcd_weights_32nds": eng.xcd_weights()[0],
+                         "bare_store_pattern_gbs_equal_xcd_shares": eng.store_pattern_gbs(),
                          "traffic": traffic, "traffic_source": traffic_src},
             "parity": parity,
         }

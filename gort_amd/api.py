@@ -68,7 +68,7 @@ DECLARED_SYMBOLS = [
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
     "gort_rsurf_members_grid_dev", "gort_rsurf_members_stream", "gort_rsurf_members_stream_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
-    "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights",
+    "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
 ]
 
@@ -105,6 +105,8 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p]
         L.gort_engine_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.gort_engine_set_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.gort_engine_store_pattern_gbs.argtypes = [C.c_void_p]
+        L.gort_engine_store_pattern_gbs.restype = D
         L.gort_engine_set_canopy.argtypes = [C.c_void_p, C.POINTER(Canopy)]
         L.gort_engine_set_spectra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gort_rsurf_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -363,6 +365,10 @@ class Engine:
         """Eight weights 8..32, or None to calibrate again on the next big LUT slab."""
         w = (C.c_int * 8)(*weights) if weights is not None else None
         _check(lib().gort_engine_set_xcd_weights(self.h, w))
+
+    def store_pattern_gbs(self):
+        """GB/s of the bare store pattern during the XCD calibration pass (0 before it ran)."""
+        return lib().gort_engine_store_pattern_gbs(self.h)
 
     def xcd_mapping(self):
         """'static' where workgroup dispatch was probed to be round-robin over the XCDs, else 'slots'."""

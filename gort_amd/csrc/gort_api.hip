@@ -62,6 +62,7 @@ struct gort_engine {
     // duty weights of the XCDs (32nds) for the static mapping; calibrated on the first LUT slab big enough
     int xcd_weights[8] = {32, 32, 32, 32, 32, 32, 32, 32};
     bool xcd_calibrated = false;
+    double xcd_pattern_gbs = 0.0;        // rate of the bare store pattern during the calibration pass
     // Small LUT slabs (the per-rank slabs of a multi-GPU run) are pipelined over two streams: geometry and sun
     // table of call i+1 run on `aux` into the other half of a double buffer while the expansion of call i is
     // still writing.  Only while both halves stay in the 256 MB Infinity Cache (PIPELINE_MAX_BYTES per half):
@@ -221,6 +222,8 @@ extern "C" int gort_engine_xcd_weights(const gort_engine *e, int weights[8])
     for (int x = 0; x < 8; ++x) weights[x] = e->xcd_weights[x];
     return e->xcd_calibrated ? 1 : 0;
 }
+
+extern "C" double gort_engine_store_pattern_gbs(const gort_engine *e) { return e ? e->xcd_pattern_gbs : 0.0; }
 
 extern "C" int gort_engine_set_xcd_weights(gort_engine *e, const int weights[8])
 {
@@ -532,7 +535,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     if (!xcd_slots && !e->xcd_calibrated && nA * (long)nw >= (1L << 27)) {
         // first slab of 1 GiB or more: time the XCDs' write rates on it (it is overwritten right after)
-        if ((rc = calibrate_xcd_weights(e->stream, lut_dev, nA * (long)nw, e->xcd_weights))) return rc;
+        if ((rc = calibrate_xcd_weights(e->stream, lut_dev, nA * (long)nw, e->xcd_weights, &e->xcd_pattern_gbs))) return rc;
         e->xcd_calibrated = true;
     }
     // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to

@@ -642,8 +642,8 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 // (eight compact write windows, one per L2, instead of one window interleaved over all eight).
 //   mode 0  identity (interleaved)
 //   mode 1  static: workgroups b, b+8, ... run on one XCD each (round-robin dispatch, probed per engine).
-//           The XCDs do not write equally fast - on the parts measured the odd XCC_IDs sustain ~80 % of the
-//           even ones, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
+//           The XCDs do not write equally fast - on the parts measured the XCDs of one XCC_ID parity (odd on most
+//           devices, even on one) sustain ~80 % of the others, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
 //           workgroups (the others return at once) and owns a range of logical blocks in proportion
 //           (calibrate_xcd_weights; tools/xcd_stream_probe.hip: 7.06 -> 6.70 ms for the 50 GB slab).
 //   mode 2  dynamic: read the XCD the workgroup really runs on (HW_REG_XCC_ID) and take the next free slot of
@@ -1331,8 +1331,9 @@ __global__ __launch_bounds__(256) void xcd_pattern_kernel(double *__restrict__ s
 }
 }  // namespace
 
-int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weights[8])
+int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weights[8], double *pattern_gbs)
 {
+    if (pattern_gbs) *pattern_gbs = 0.0;
     for (int x = 0; x < 8; ++x) weights[x] = 32;
     // whole aligned chunks inside the slab
     const uintptr_t addr = reinterpret_cast<uintptr_t>(slab);
@@ -1374,13 +1375,22 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
             if (rate[x] > rmax) rmax = rate[x];
         }
         if (!ok) break;                                        // an XCD reported nothing: leave the weights alone
+        if (pattern_gbs) {
+            // the rate of the bare store pattern with equal shares, first start to last end (wall clock ticks)
+            unsigned long long t1 = 0;
+            for (int x = 0; x < 8; ++x) if (host[8 + x] > t1) t1 = host[8 + x];
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && khz > 0 && t1 > t0)
+                *pattern_gbs = (double)chunks * 1024.0 / ((double)(t1 - t0) / khz * 1e-3) / 1e9;
+        }
         for (int x = 0; x < 8; ++x) {
             int w = (int)(32.0 * rate[x] / rmax + 0.5);
             weights[x] = w < 16 ? 16 : (w > 32 ? 32 : w);
         }
     }
-    // What is being measured is a trait of the part - the XCDs with odd XCC_ID write ~15 % slower than the even
-    // ones on every MI355X seen so far - under a few % of run-to-run noise, and a weight that is off by one
+    // What is being measured is a trait of the device - the XCDs of one XCC_ID parity write ~15 % slower than the
+    // others on every MI355X seen so far (the odd ones on most devices, the even ones on one) - under a few % of
+    // run-to-run noise, and a weight that is off by one
     // costs more than it gains (tools/weights_sweep.py).  So the eight results are averaged within each parity.
     if (rc == GORT_OK) {
         double mean[2] = {0.0, 0.0};

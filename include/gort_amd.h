@@ -211,6 +211,9 @@ int  gort_engine_xcd_mapping(gort_engine *e);
 int  gort_engine_xcd_weights(const gort_engine *e, int weights[8]);
 /* set the weights (each 8..32) instead of calibrating; NULL = forget them and calibrate on the next big slab */
 int  gort_engine_set_xcd_weights(gort_engine *e, const int weights[8]);
+/* GB/s of the calibration pass: the LUT kernel's store pattern without any arithmetic, equal XCD shares, over the
+ * slab the weights were measured on - the write rate this device and placement give that pattern; 0 before */
+double gort_engine_store_pattern_gbs(const gort_engine *e);
 
 /* Spectral albedo, vegetation and soil absorption per angle line.  Replaces
  * gortt_energy/gortt_albedo (gortt_albedo.c:7-138): 32x16 Gauss-Legendre nodes over the
