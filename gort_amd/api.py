@@ -68,7 +68,7 @@ DECLARED_SYMBOLS = [
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
     "gort_rsurf_members_grid_dev", "gort_rsurf_members_stream", "gort_rsurf_members_stream_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
-    "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
+    "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs", "gort_selftest_index_math",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
 ]
 

@@ -223,6 +223,8 @@ extern "C" int gort_engine_xcd_weights(const gort_engine *e, int weights[8])
     return e->xcd_calibrated ? 1 : 0;
 }
 
+extern "C" int gort_selftest_index_math(void) { return selftest_index_math(); }
+
 extern "C" double gort_engine_store_pattern_gbs(const gort_engine *e) { return e ? e->xcd_pattern_gbs : 0.0; }
 
 extern "C" int gort_engine_set_xcd_weights(gort_engine *e, const int weights[8])

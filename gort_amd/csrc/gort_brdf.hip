@@ -16,6 +16,7 @@
 //
 // No MFMA: K=5 is not a matrix-core shape and the kernel is store-bound anyway.
 #include <hip/hip_runtime.h>
+#include <vector>
 
 #include <cstdint>
 #include <cstdlib>
@@ -651,22 +652,26 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 //           The ranges sum to the grid, so every workgroup finds a slot within 8 tries.  The launcher zeroes
 //           the counters (one per 128-B line) on the stream before every launch.
 // Returns -1 for a workgroup without work.
+// mode 1 for workgroup b (host-callable so that gort_selftest_index_math can check the bijection without a GPU)
+__host__ __device__ __forceinline__ long duty_logical_block(long b, const XcdDuty &duty, long useful)
+{
+    const unsigned sh = ((unsigned)b & 7u) * 8u;
+    const unsigned w = (unsigned)(duty.w8 >> sh) & 0xffu;
+    // sum of the weights of the XCDs in front (<= 7 x 32, fits the top byte of the byte-wise product)
+    const unsigned long long below = duty.w8 & ((1ull << sh) - 1ull);
+    const unsigned pw = (unsigned)((below * 0x0101010101010101ull) >> 56);
+    const long i = b >> 3;                               // < 32 q by the size of the grid
+    const long li = (i * w) >> 5;                        // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
+    if ((((i + 1) * w) >> 5) == li) return -1;
+    const long block = duty.q * pw + li;
+    return block < useful ? block : -1;
+}
+
 __device__ __forceinline__ long xcd_logical_block(int xcd_mode, const XcdDuty &duty, long useful,
                                                   int *__restrict__ xcd_slots)
 {
     const long b = blockIdx.x;
-    if (xcd_mode == 1) {
-        const unsigned sh = ((unsigned)b & 7u) * 8u;
-        const unsigned w = (unsigned)(duty.w8 >> sh) & 0xffu;
-        // sum of the weights of the XCDs in front (<= 7 x 32, fits the top byte of the byte-wise product)
-        const unsigned long long below = duty.w8 & ((1ull << sh) - 1ull);
-        const unsigned pw = (unsigned)((below * 0x0101010101010101ull) >> 56);
-        const long i = b >> 3;                               // < 32 q by the size of the grid
-        const long li = (i * w) >> 5;                        // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
-        if ((((i + 1) * w) >> 5) == li) return -1;
-        const long block = duty.q * pw + li;
-        return block < useful ? block : -1;
-    }
+    if (xcd_mode == 1) return duty_logical_block(b, duty, useful);
     if (xcd_mode == 2) {
         const long base = useful >> 3, rem = useful & 7;     // XCD y owns [y*base + min(y,rem), +base (+1 if y < rem))
         __shared__ long s_block;
@@ -694,7 +699,7 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 // exact n / d for n < 2^31 and a divisor fixed per launch: (n * mul) >> (31 + sh), mul and sh from the host
 // (make_fast_div); five scalar instructions instead of the ~35 of a 32-bit division with a run-time divisor
-__device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d)
+__host__ __device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d)
 {
     return (unsigned)(((unsigned long long)n * d.mul) >> (31u + d.sh));
 }
@@ -1299,6 +1304,45 @@ static long plan_xcd_duty(int xcd_mode, long useful, const int *weights, XcdDuty
     }
     duty.q = (useful + sumw - 1) / sumw;
     return xcd_mode == 1 ? 8 * 32 * duty.q : useful;
+}
+
+// Host-side check of the index arithmetic the flat kernels rely on (no GPU needed; tests/test_host_abi.py):
+// fast_div against '/', and the duty mapping as a bijection of the launch's workgroups onto the logical blocks.
+// Returns 0, or the line of the first failed check.
+int selftest_index_math()
+{
+    unsigned long long rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    const unsigned divisors[] = {1, 2, 3, 7, 128, 361, 2101, 2100, 4202, 32851, 65535, 65536, 1000003, 0x7fffffffu};
+    for (unsigned d : divisors) {
+        const FastDiv f = make_fast_div(d);
+        const unsigned edge[] = {0u, 1u, d - 1, d, d + 1, 2 * d - 1 < 0x7fffffffu ? 2 * d - 1 : 0u, 0x7fffffffu, 0x7ffffffeu};
+        for (unsigned n : edge) if (n <= 0x7fffffffu && fast_div(n, f) != n / d) return __LINE__;
+        for (int k = 0; k < 200000; ++k) {
+            const unsigned n = (unsigned)(next() >> 33);
+            if (fast_div(n, f) != n / d) return __LINE__;
+        }
+    }
+    for (int trial = 0; trial < 300; ++trial) {
+        int w[8];
+        for (int x = 0; x < 8; ++x) w[x] = trial == 0 ? 32 : (trial == 1 ? (x & 1 ? 27 : 32) : 8 + (int)(next() % 25));
+        const long useful = trial < 2 ? 2044799 / (trial + 1) / 100 : 1 + (long)(next() % 20000);
+        XcdDuty duty;
+        const long grid = plan_xcd_duty(1, useful, w, duty);
+        std::vector<unsigned char> seen((size_t)useful, 0);
+        long hit = 0;
+        for (long b = 0; b < grid; ++b) {
+            const long blk = duty_logical_block(b, duty, useful);
+            if (blk < 0) continue;
+            if (blk >= useful || seen[(size_t)blk]) return __LINE__;
+            seen[(size_t)blk] = 1;
+            ++hit;
+        }
+        if (hit != useful) return __LINE__;
+        XcdDuty plain;
+        if (plan_xcd_duty(0, useful, w, plain) != useful || plan_xcd_duty(2, useful, nullptr, plain) != useful) return __LINE__;
+    }
+    return 0;
 }
 
 namespace {

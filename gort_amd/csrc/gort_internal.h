@@ -84,6 +84,8 @@ struct FastDiv {
 // destroyed) and derive the duty weights that make all XCDs finish together; synchronises `stream`.
 // *pattern_gbs (may be null): the rate of that bare store pattern with equal XCD shares, GB/s
 int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weights[8], double *pattern_gbs);
+// host-side check of fast_div and of the duty mapping (0 = ok, else the failing source line)
+int selftest_index_math();
 // round_robin = 1 if workgroups b, b+8, ... of a launch share an XCD (then the static XCD mapping is exact);
 // expand_wants_xcd_slots: does the flat expansion need the slot counters (GORT_EXPAND_XCD or the probe says so)
 int probe_xcd_dispatch(void *stream, int *round_robin);

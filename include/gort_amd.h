@@ -214,6 +214,9 @@ int  gort_engine_set_xcd_weights(gort_engine *e, const int weights[8]);
 /* GB/s of the calibration pass: the LUT kernel's store pattern without any arithmetic, equal XCD shares, over the
  * slab the weights were measured on - the write rate this device and placement give that pattern; 0 before */
 double gort_engine_store_pattern_gbs(const gort_engine *e);
+/* host-only self-test of the LUT kernel's index arithmetic (multiply-shift divisions, XCD duty mapping as a
+ * bijection); 0 = ok.  Needs no GPU. */
+int  gort_selftest_index_math(void);
 
 /* Spectral albedo, vegetation and soil absorption per angle line.  Replaces
  * gortt_energy/gortt_albedo (gortt_albedo.c:7-138): 32x16 Gauss-Legendre nodes over the

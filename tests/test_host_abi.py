@@ -184,3 +184,9 @@ def test_ensemble_state_vector_to_gortt_inputs():
     # gort_canopy_newstyle takes the flags as float, like the reference's parser: rounding them beforehand is idempotent
     c3 = api.make_canopy(newstyle=(1.7, 2.4, 0.55), lai=3.1)
     assert c3.favd == c.favd and c3.r == c.r
+
+
+def test_index_math_selftest():
+    """Host-side self-test of the LUT kernel's index arithmetic: the multiply-shift divisions equal '/', and the
+    XCD duty mapping sends the workgroups of a launch onto every logical block exactly once (300 weightings)."""
+    assert api.lib().gort_selftest_index_math() == 0
