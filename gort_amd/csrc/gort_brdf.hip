@@ -643,8 +643,8 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 // (eight compact write windows, one per L2, instead of one window interleaved over all eight).
 //   mode 0  identity (interleaved)
 //   mode 1  static: workgroups b, b+8, ... run on one XCD each (round-robin dispatch, probed per engine).
-//           The XCDs do not write equally fast - on the parts measured the XCDs of one XCC_ID parity (odd on most
-//           devices, even on one) sustain ~80 % of the others, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
+//           The XCDs do not write equally fast - on the parts measured the XCDs of one parity (the odd XCC_IDs in
+//           every standalone probe; the even dispatch slots in one process) sustain ~80 % of the others, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
 //           workgroups (the others return at once) and owns a range of logical blocks in proportion
 //           (calibrate_xcd_weights; tools/xcd_stream_probe.hip: 7.06 -> 6.70 ms for the 50 GB slab).
 //   mode 2  dynamic: read the XCD the workgroup really runs on (HW_REG_XCC_ID) and take the next free slot of
@@ -1433,7 +1433,7 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
         }
     }
     // What is being measured is a trait of the device - the XCDs of one XCC_ID parity write ~15 % slower than the
-    // others on every MI355X seen so far (the odd ones on most devices, the even ones on one) - under a few % of
+    // others on every MI355X seen so far (the odd XCC_IDs in every standalone probe, the even dispatch slots in one process) - under a few % of
     // run-to-run noise, and a weight that is off by one
     // costs more than it gains (tools/weights_sweep.py).  So the eight results are averaged within each parity.
     if (rc == GORT_OK) {
