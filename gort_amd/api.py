@@ -70,6 +70,7 @@ DECLARED_SYMBOLS = [
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs", "gort_selftest_index_math",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
+    "gort_engine_stream_form", "gort_engine_set_stream_grouping", "gort_engine_last_stream_ms",
 ]
 
 _lib = None
@@ -103,6 +104,10 @@ def lib():
         for name in ("gort_engine_destroy", "gort_engine_synchronize", "gort_engine_stream", "gort_engine_nw",
                      "gort_engine_last_expand_ms", "gort_engine_xcd_mapping"):
             getattr(L, name).argtypes = [C.c_void_p]
+        L.gort_engine_stream_form.argtypes = [C.c_void_p]
+        L.gort_engine_set_stream_grouping.argtypes = [C.c_void_p, C.c_int]
+        L.gort_engine_last_stream_ms.argtypes = [C.c_void_p]
+        L.gort_engine_last_stream_ms.restype = D
         L.gort_engine_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.gort_engine_set_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.gort_engine_store_pattern_gbs.argtypes = [C.c_void_p]
@@ -348,6 +353,19 @@ class Engine:
     def rsurf_stream_dev(self, angles_t, rsurf_t, scomp_t=None, K_t=None):
         _check(lib().gort_rsurf_stream_dev(self.h, _ptr(angles_t), angles_t.shape[0], _ptr(rsurf_t),
                                            _ptr(scomp_t), _ptr(K_t)))
+
+    def stream_form(self):
+        """'narrow' | 'grouped' | 'per-line': which kernels expanded the last stream call (synchronises)."""
+        m = lib().gort_engine_stream_form(self.h)
+        if m < 0:
+            _check(m)
+        return {0: "narrow", 1: "grouped", 2: "per-line"}[m]
+
+    def set_stream_grouping(self, on):
+        _check(lib().gort_engine_set_stream_grouping(self.h, int(bool(on))))
+
+    def last_stream_ms(self):
+        return lib().gort_engine_last_stream_ms(self.h)
 
     def rsurf_grid_dev(self, grid, row_begin, row_end, lut_t):
         _check(lib().gort_rsurf_grid_dev(self.h, C.byref(grid), row_begin, row_end, _ptr(lut_t)))

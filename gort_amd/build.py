@@ -24,6 +24,7 @@ ARCH = "gfx950"
 UNITS = [
     ("gort_gap.hip", ["-ffp-contract=off"]),
     ("gort_brdf.hip", []),
+    ("gort_stream.hip", []),
     ("gort_spectra.hip", []),
     ("gort_api.hip", []),
     ("gort_host.cpp", ["-ffp-contract=off", '-DGORT_DATA_DIR="%s"' % os.path.join(PKG, "data")]),
@@ -54,7 +55,7 @@ def build(force=False, verbose_resources=False):
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     cc = hipcc()
     headers = [os.path.join(ROOT, "include", "gort_amd.h"), os.path.join(SRC, "gort_internal.h"),
-               os.path.abspath(__file__)]
+               os.path.join(SRC, "gort_device.h"), os.path.abspath(__file__)]
     data = [os.path.join(PKG, "data", f) for f in ("prospect_d_coeffs.f32", "price_soil_eofs.f64")]
     common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
               "-I" + SRC, "--offload-arch=" + ARCH]

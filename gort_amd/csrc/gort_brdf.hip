@@ -22,77 +22,10 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "gort_internal.h"
+#include "gort_device.h"
 
 namespace gort {
 namespace {
-
-constexpr double PI = 3.14159265358979323846;
-constexpr double INV_PI = 0.318309886183790671538;   // M_1_PI
-
-// reference MAX/MIN macros (gortt.h:9-10): a NaN in the second slot survives
-__device__ inline double ref_max(double x, double y) { return x > y ? x : y; }
-__device__ inline double ref_min(double x, double y) { return x < y ? x : y; }
-
-struct SunScalars { double fd, mu, t0, tp0, eps, pn0; };
-
-// rsurf = aC*C0 + aB*B + aZ*Z + aG*G + aT*T with ONE fixed association (an explicit FMA chain), so that
-// every kernel form and every template instantiation writes the same bits for the same inputs.
-__device__ __forceinline__ double dot5(double aC, double aB, double aZ, double aG, double aT,
-                                       double C0, double B, double Z, double G, double T)
-{
-    return __builtin_fma(aT, T, __builtin_fma(aG, G, __builtin_fma(aZ, Z, __builtin_fma(aB, B, aC * C0))));
-}
-
-// ------------------------------------------------------------------ geometry
-
-// linear interpolation in the 1-degree gap tables (gortt.c:872-915).  The reference
-// indexes past the table for zenith > 90 deg; defined here as NaN.
-__device__ inline void gap_lookup(const gort_canopy &c, double za, double &pn0, double &epg)
-{
-    const double pos = fabs(za) / c.dth;
-    const double cf = ceil(pos), ff = floor(pos);
-    if (!(cf <= (double)(GORT_NTH - 1))) { pn0 = epg = __builtin_nan(""); return; }
-    const int ci = (int)cf, fi = (int)ff;
-    const double d = pos - ff;
-    pn0 = d * c.p_n0[ci] + (1.0 - d) * c.p_n0[fi];
-    epg = d * c.epgap[ci] + (1.0 - d) * c.epgap[fi];
-}
-
-// sign / azimuth conventions of main() (gortt.c:240-279); degrees in, radians out
-__device__ inline void normalise_angles(double vza_deg, double vaa_deg, double sza_deg, double saa_deg,
-                                        double &vza, double &sza, double &saa, double &raa)
-{
-#pragma clang fp contract(off)
-    vza = vza_deg * PI / 180.0;
-    double vaa = vaa_deg * PI / 180.0;
-    sza = sza_deg * PI / 180.0;
-    saa = saa_deg * PI / 180.0;
-    if (sza < 0.0) { saa += PI; sza *= -1.0; }
-    if (vza < 0.0) { vaa += PI; vza *= -1.0; }
-    // the reference wraps by repeated subtraction; beyond +-64 turns fold first so that
-    // absurd inputs cannot stall a wavefront (documented deviation)
-    if (fabs(saa) > 128 * PI) saa = fmod(saa, 2 * PI);
-    if (fabs(vaa) > 128 * PI) vaa = fmod(vaa, 2 * PI);
-    while (saa > 2 * PI) saa -= 2 * PI;
-    while (vaa > 2 * PI) vaa -= 2 * PI;
-    while (saa < 0) saa += 2 * PI;
-    while (vaa < 0) vaa += 2 * PI;
-    raa = saa - vaa;
-    raa = fabs((raa - 2 * PI * (int)(0.5 + raa * INV_PI * 0.5)));    // C truncation toward zero
-}
-
-struct Primed { double ang, s, c, sec, t; };     // theta' = atan((b/r) tan theta)  (gortt.c:581-588)
-
-__device__ inline Primed prime(double ell, double tan_za)
-{
-    Primed p;
-    p.ang = atan(ell * tan_za);
-    sincos(p.ang, &p.s, &p.c);
-    p.sec = 1.0 / p.c;
-    p.t = p.s / p.c;
-    return p;
-}
 
 // mutual-shadowing overlap O(theta_s', theta_v', phi)  (gortt_brdf.c:23-100)
 // Unfused on purpose: for equal primed zeniths and phi = 0 the reference gets d = t^2 + t^2 - 2 t t = 0
@@ -195,20 +128,15 @@ __device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms
     }
 
     // zenith-dependent gap probabilities; path lengths of Kuusk's hot spot
-    double pn0_s, pn0_v;
-    gap_lookup(c, sza, pn0_s, r.eps_s);
+    double pn0_v;
+    r.sun = sun_scalars(c, sza, r.cos_sz, s);
+    r.eps_s = r.sun.eps;
     gap_lookup(c, vza, pn0_v, r.eps_v);
     r.kf = c.k * c.favd;
     r.ls = -log(r.eps_s) / r.kf;
     r.lv = -log(r.eps_v) / (0.5 * c.favd);
     r.h1 = (r.ls * r.lv) > 0.0 ? sqrt(r.ls * r.lv) : 0.0;
 
-    r.sun.fd = c.use_user_fd ? c.fd_user : r.cos_sz / (r.cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291
-    r.sun.mu = s.c;
-    r.sun.t0 = exp(-(c.k * c.elai * s.sec));
-    r.sun.tp0 = pn0_s + r.eps_s;
-    r.sun.eps = r.eps_s;
-    r.sun.pn0 = pn0_s;
 }
 
 // The azimuth-dependent rest: overlap and Kg at the actual azimuth, the interpolated Kc, the other
@@ -395,59 +323,6 @@ __global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__
     L[L_B * nw + i] = (1.0 - omega) * omega * (1.0 - gfun);
 }
 
-struct SunTerms { double C0, B, Z, G, T; };
-struct BandTerms { double gam, omega, Rff, Tff, tff, pff, rs, mgk, Zf, Tf, B; };
-
-__device__ inline BandTerms load_band(const double *__restrict__ L, int nw, int i)
-{
-    BandTerms t;
-    t.gam = L[L_GAMMA * nw + i];  t.omega = L[L_OMEGA * nw + i];
-    t.Rff = L[L_RFF * nw + i];    t.Tff = L[L_TFF * nw + i];
-    t.tff = L[L_tFF * nw + i];    t.pff = L[L_PFF * nw + i];
-    t.rs = L[L_RS * nw + i];      t.mgk = L[L_MGK * nw + i];
-    t.Zf = L[L_ZF * nw + i];      t.Tf = L[L_TF * nw + i];
-    t.B = L[L_B * nw + i];
-    return t;
-}
-
-// the five (sun zenith, band) numbers.  The two quotients of the reference, 1/(1+2 mu gamma) and
-// 1/(1-(2 gamma mu)^2), share ONE fp64 division: 1-(g2)^2 = (1+g2)(1-g2).
-__device__ inline SunTerms sun_terms(const BandTerms &t, const SunScalars &s, double ko, double kep)
-{
-    const double mu = s.mu, fd = s.fd;
-    const double g2 = 2. * t.gam * mu;
-    const double inv = 1.0 / ((1.0 + g2) * (1.0 - g2));
-    const double Rdf = (1.0 - t.gam) * ((1.0 - g2) * inv);                      // (1-gamma)/(1+2 mu gamma), gortt_brdf.c:552
-    const double Tdf = (t.omega / 2.0) * ((1. + 2. * mu) * inv) * (t.Tff - s.t0);   // :467-471
-    const double X = s.t0 * Rdf + Tdf * t.Rff;
-    const double tdf = Tdf - t.pff * X;                                         // :423-424
-    const double pdf = Rdf - t.tff * X;                                         // :628-630
-    const double tpdf = tdf * (1 - s.tp0);                                      // :361
-    SunTerms o;
-    o.B = t.B;
-    o.G = fd * t.rs + (1 - fd) * t.rs;                                          // gortt.c:481-484
-    o.Z = fd * ((tpdf + s.eps) * t.rs) + (1 - fd) * t.Zf;                       // gortt.c:491-494
-    const double Td = (tpdf + s.tp0) * t.mgk;                                   // gortt.c:541-543
-    o.T = fd * Td + (1 - fd) * t.Tf;                                            // gortt.c:550
-    const double kk = kep + ko;
-    const double CfG = (kk * o.G + (1 - kk) * o.Z) * kep;                       // gortt.c:516-517
-    o.C0 = fd * (pdf + Td) + (1 - fd) * (t.pff + CfG + t.Tf);
-    return o;
-}
-
-__device__ inline SunTerms sun_terms(const double *__restrict__ L, int nw, int i, const SunScalars &s,
-                                     double ko, double kep)
-{
-    return sun_terms(load_band(L, nw, i), s, ko, kep);
-}
-
-__device__ inline SunScalars load_sun(const double *__restrict__ rec)
-{
-    SunScalars s;
-    s.fd = rec[S_FD];  s.mu = rec[S_MU];  s.t0 = rec[S_T0];  s.tp0 = rec[S_TP0];
-    s.eps = rec[S_EPS];  s.pn0 = rec[S_PN0];
-    return s;
-}
 
 // ------------------------------------------------ stream expansion (any angles)
 
@@ -537,15 +412,7 @@ __global__ __launch_bounds__(256) void sun_table_kernel(const gort_canopy *__res
     // sun-only scalars exactly as geometry_core derives them for "vza phi sza 0"
     double vza, sza, saa, raa;
     normalise_angles(0.0, 0.0, g.sza0 + isza * g.dsza, 0.0, vza, sza, saa, raa);
-    double sin_sz, cos_sz;
-    sincos(sza, &sin_sz, &cos_sz);
-    const Primed sp = prime(c.b / c.r, sin_sz / cos_sz);
-    SunScalars s;
-    gap_lookup(c, sza, s.pn0, s.eps);
-    s.fd = c.use_user_fd ? c.fd_user : cos_sz / (cos_sz + 0.09);
-    s.mu = sp.c;
-    s.t0 = exp(-(c.k * c.elai * sp.sec));
-    s.tp0 = s.pn0 + s.eps;
+    const SunScalars s = sun_from_zenith(c, sza);
     const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
     double *o = sun + (long)js * 5 * nw;
     o[0 * nw + i] = b.C0;
@@ -638,71 +505,6 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 // the chunk, i.e. the chunk spans two angles: those waves fetch both records and each
 // element picks its own.  The coefficient buffer carries one pad record in front and a
 // tail pad so that the record prefetch needs no bounds logic.
-// ---- which logical block (= 4 consecutive waves of the flat kernels) does this workgroup work on ----
-// Any bijection is correct; only speed depends on it.  Each XCD gets ONE contiguous range of logical blocks
-// (eight compact write windows, one per L2, instead of one window interleaved over all eight).
-//   mode 0  identity (interleaved)
-//   mode 1  static: workgroups b, b+8, ... run on one XCD each (round-robin dispatch, probed per engine).
-//           The XCDs do not write equally fast - on the parts measured the XCDs of one parity (the odd XCC_IDs in
-//           every standalone probe; the even dispatch slots in one process) sustain ~80 % of the others, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
-//           workgroups (the others return at once) and owns a range of logical blocks in proportion
-//           (calibrate_xcd_weights; tools/xcd_stream_probe.hip: 7.06 -> 6.70 ms for the 50 GB slab).
-//   mode 2  dynamic: read the XCD the workgroup really runs on (HW_REG_XCC_ID) and take the next free slot of
-//           that XCD's range with one returning atomic; if the range is used up take one from the next XCD.
-//           The ranges sum to the grid, so every workgroup finds a slot within 8 tries.  The launcher zeroes
-//           the counters (one per 128-B line) on the stream before every launch.
-// Returns -1 for a workgroup without work.
-// mode 1 for workgroup b (host-callable so that gort_selftest_index_math can check the bijection without a GPU)
-__host__ __device__ __forceinline__ long duty_logical_block(long b, const XcdDuty &duty, long useful)
-{
-    const unsigned sh = ((unsigned)b & 7u) * 8u;
-    const unsigned w = (unsigned)(duty.w8 >> sh) & 0xffu;
-    // sum of the weights of the XCDs in front (<= 7 x 32, fits the top byte of the byte-wise product)
-    const unsigned long long below = duty.w8 & ((1ull << sh) - 1ull);
-    const unsigned pw = (unsigned)((below * 0x0101010101010101ull) >> 56);
-    const long i = b >> 3;                               // < 32 q by the size of the grid
-    const long li = (i * w) >> 5;                        // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
-    if ((((i + 1) * w) >> 5) == li) return -1;
-    const long block = duty.q * pw + li;
-    return block < useful ? block : -1;
-}
-
-__device__ __forceinline__ long xcd_logical_block(int xcd_mode, const XcdDuty &duty, long useful,
-                                                  int *__restrict__ xcd_slots)
-{
-    const long b = blockIdx.x;
-    if (xcd_mode == 1) return duty_logical_block(b, duty, useful);
-    if (xcd_mode == 2) {
-        const long base = useful >> 3, rem = useful & 7;     // XCD y owns [y*base + min(y,rem), +base (+1 if y < rem))
-        __shared__ long s_block;
-        if (threadIdx.x == 0) {
-            unsigned x;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-            long L = -1;
-            for (int t = 0; t < 8 && L < 0; ++t) {
-                const long y = (x + t) & 7;
-                const long quota = base + (y < rem ? 1 : 0);
-                const long s = atomicAdd(&xcd_slots[y * XCD_SLOT_PITCH], 1);
-                if (s < quota) L = y * base + (y < rem ? y : rem) + s;
-            }
-            s_block = L;
-        }
-        __syncthreads();
-        return s_block;                                       // never -1 (pigeonhole), checked by the caller anyway
-    }
-    return b < useful ? b : -1;
-}
-
-constexpr int EPL = 2;                  // elements (adjacent bands) per lane and step
-constexpr int CHUNK = 64 * EPL;         // doubles per wave-step
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-
-// exact n / d for n < 2^31 and a divisor fixed per launch: (n * mul) >> (31 + sh), mul and sh from the host
-// (make_fast_div); five scalar instructions instead of the ~35 of a 32-bit division with a run-time divisor
-__host__ __device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d)
-{
-    return (unsigned)(((unsigned long long)n * d.mul) >> (31u + d.sh));
-}
 
 // The steps of one wave.  What a lane carries is its sun terms b (20 VGPRs) and its bands; everything that
 // moves is wave-uniform: the output chunk, the record address and the sun zenith of the chunk's first angle
@@ -963,8 +765,11 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const gort_cano
                                                                   int shift, long stride_chunks,
                                                                   double *__restrict__ out, int xcd_mode,
                                                                   XcdDuty duty, long useful_blocks,
-                                                                  int *__restrict__ xcd_slots)
+                                                                  int *__restrict__ xcd_slots,
+                                                                  const int *__restrict__ direct_flag)
 {
+    // behind the grouped form (gort_stream.hip) this kernel runs only when that one gave the stream up
+    if (direct_flag && *direct_flag == -1) return;          // -1 = clear
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long block = xcd_logical_block(xcd_mode, duty, useful_blocks, xcd_slots);
     if (block < 0) return;
@@ -1141,16 +946,38 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
 static bool stream_uses_flat(int nw, long nA, bool want_scomp);
 static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double *L_dev, int nw,
                                      const double *coef_dev, long nA, double *rsurf_dev, int *xcd_slots_dev,
-                                     hipStream_t s);
+                                     const int *direct_flag_dev, hipStream_t s);
 
-int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
-                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream)
+bool expand_stream_workspace(int nw, long nA, bool want_scomp, size_t *ws_bytes, size_t *sun_bytes)
+{
+    *ws_bytes = 0;
+    *sun_bytes = 0;
+    if (!stream_uses_flat(nw, nA, want_scomp)) return false;
+    stream_group_workspace(nw, nA, ws_bytes, sun_bytes);
+    return true;
+}
+
+int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
+                         const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev,
+                         void *group_ws_dev, double *group_sun_dev, void *stream, void *coef_ready_event)
 {
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (stream_uses_flat(nw, nA, scomp_dev != nullptr))
-        return launch_expand_stream_flat(canopy_dev, L_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, s);
+    const bool grouped = stream_uses_flat(nw, nA, scomp_dev != nullptr) && angles_dev && group_ws_dev && group_sun_dev;
+    if (coef_ready_event && !grouped &&
+        hipStreamWaitEvent(s, (hipEvent_t)coef_ready_event, 0) != hipSuccess)
+        return fail(GORT_ENODEVICE, "stream expansion: cannot wait for the geometry kernel");
+    if (stream_uses_flat(nw, nA, scomp_dev != nullptr)) {
+        // wide streams: lines grouped by sun zenith where the stream allows it, per-line sun terms otherwise
+        const int *direct_flag = nullptr;
+        if (grouped) {
+            const int rc = launch_expand_stream_grouped(canopy_dev, L_dev, nw, angles_dev, coef_dev, nA, rsurf_dev,
+                                                        group_ws_dev, group_sun_dev, stream, coef_ready_event, &direct_flag);
+            if (rc) return rc;
+        }
+        return launch_expand_stream_flat(canopy_dev, L_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, direct_flag, s);
+    }
     const long groups = (nA + STREAM_LINES - 1) / STREAM_LINES;
     if (nw >= 64 && groups <= 65535) {
         const dim3 grid((unsigned)((nw + 255) / 256), (unsigned)groups), block(256);
@@ -1575,7 +1402,7 @@ long expand_stream_tail_pad_records(int nw, long nA)
 
 static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double *L_dev, int nw,
                                      const double *coef_dev, long nA, double *rsurf_dev, int *xcd_slots_dev,
-                                     hipStream_t s)
+                                     const int *direct_flag_dev, hipStream_t s)
 {
     const ExpandTuning &tune = tuning();
     const long n_total = nA * (long)nw;
@@ -1589,10 +1416,10 @@ static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double
     const dim3 grid((unsigned)plan_xcd_duty(xcd_mode, useful, nullptr, duty));
     if (tune.nt)
         hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev);
+                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev, direct_flag_dev);
     else
         hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev);
+                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev, direct_flag_dev);
     return check_launch("expand_flat_stream_kernel");
 }
 

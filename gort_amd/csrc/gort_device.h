@@ -1,0 +1,233 @@
+// gort_device.h -- device-side building blocks shared by the HIP translation units (gort_brdf.hip, gort_stream.hip):
+// angle conventions, gap-table lookup, the (sun zenith, band) two-stream terms, the 5-term expansion and the
+// workgroup -> XCD-range mapping of the flat kernels.  Every kernel form calls THESE functions, so that all of them
+// write the same bits for the same inputs (tests: stream == grid, grouped == per-line).
+#ifndef GORT_DEVICE_H
+#define GORT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include "gort_internal.h"
+
+namespace gort {
+namespace {
+
+constexpr double PI = 3.14159265358979323846;
+constexpr double INV_PI = 0.318309886183790671538;   // M_1_PI
+
+// reference MAX/MIN macros (gortt.h:9-10): a NaN in the second slot survives
+__device__ inline double ref_max(double x, double y) { return x > y ? x : y; }
+__device__ inline double ref_min(double x, double y) { return x < y ? x : y; }
+
+struct SunScalars { double fd, mu, t0, tp0, eps, pn0; };
+
+// rsurf = aC*C0 + aB*B + aZ*Z + aG*G + aT*T with ONE fixed association (an explicit FMA chain), so that
+// every kernel form and every template instantiation writes the same bits for the same inputs.
+__device__ __forceinline__ double dot5(double aC, double aB, double aZ, double aG, double aT,
+                                       double C0, double B, double Z, double G, double T)
+{
+    return __builtin_fma(aT, T, __builtin_fma(aG, G, __builtin_fma(aZ, Z, __builtin_fma(aB, B, aC * C0))));
+}
+
+// ------------------------------------------------------------------ geometry
+
+// linear interpolation in the 1-degree gap tables (gortt.c:872-915).  The reference
+// indexes past the table for zenith > 90 deg; defined here as NaN.
+__device__ inline void gap_lookup(const gort_canopy &c, double za, double &pn0, double &epg)
+{
+    const double pos = fabs(za) / c.dth;
+    const double cf = ceil(pos), ff = floor(pos);
+    if (!(cf <= (double)(GORT_NTH - 1))) { pn0 = epg = __builtin_nan(""); return; }
+    const int ci = (int)cf, fi = (int)ff;
+    const double d = pos - ff;
+    pn0 = d * c.p_n0[ci] + (1.0 - d) * c.p_n0[fi];
+    epg = d * c.epgap[ci] + (1.0 - d) * c.epgap[fi];
+}
+
+// sign / azimuth conventions of main() (gortt.c:240-279); degrees in, radians out
+__device__ inline void normalise_angles(double vza_deg, double vaa_deg, double sza_deg, double saa_deg,
+                                        double &vza, double &sza, double &saa, double &raa)
+{
+#pragma clang fp contract(off)
+    vza = vza_deg * PI / 180.0;
+    double vaa = vaa_deg * PI / 180.0;
+    sza = sza_deg * PI / 180.0;
+    saa = saa_deg * PI / 180.0;
+    if (sza < 0.0) { saa += PI; sza *= -1.0; }      // normalised_sza() below restates these two lines
+    if (vza < 0.0) { vaa += PI; vza *= -1.0; }
+    // the reference wraps by repeated subtraction; beyond +-64 turns fold first so that
+    // absurd inputs cannot stall a wavefront (documented deviation)
+    if (fabs(saa) > 128 * PI) saa = fmod(saa, 2 * PI);
+    if (fabs(vaa) > 128 * PI) vaa = fmod(vaa, 2 * PI);
+    while (saa > 2 * PI) saa -= 2 * PI;
+    while (vaa > 2 * PI) vaa -= 2 * PI;
+    while (saa < 0) saa += 2 * PI;
+    while (vaa < 0) vaa += 2 * PI;
+    raa = saa - vaa;
+    raa = fabs((raa - 2 * PI * (int)(0.5 + raa * INV_PI * 0.5)));    // C truncation toward zero
+}
+
+// the sun zenith in radians exactly as normalise_angles() leaves it: the key under which the stream path groups lines
+__device__ inline double normalised_sza(double sza_deg)
+{
+#pragma clang fp contract(off)
+    double sza = sza_deg * PI / 180.0;
+    if (sza < 0.0) sza *= -1.0;
+    return sza;
+}
+
+struct Primed { double ang, s, c, sec, t; };     // theta' = atan((b/r) tan theta)  (gortt.c:581-588)
+
+__device__ inline Primed prime(double ell, double tan_za)
+{
+    Primed p;
+    p.ang = atan(ell * tan_za);
+    sincos(p.ang, &p.s, &p.c);
+    p.sec = 1.0 / p.c;
+    p.t = p.s / p.c;
+    return p;
+}
+
+// the scalars of a line that depend on its sun zenith only (gortt.c:290-291, 872-915; gortt_brdf.c:447,534)
+__device__ inline SunScalars sun_scalars(const gort_canopy &c, double sza, double cos_sz, const Primed &sp)
+{
+    SunScalars s;
+    gap_lookup(c, sza, s.pn0, s.eps);
+    s.fd = c.use_user_fd ? c.fd_user : cos_sz / (cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291
+    s.mu = sp.c;
+    s.t0 = exp(-(c.k * c.elai * sp.sec));
+    s.tp0 = s.pn0 + s.eps;
+    return s;
+}
+
+// the same from the normalised zenith alone, as row_terms() derives them for a line with that sun zenith
+__device__ inline SunScalars sun_from_zenith(const gort_canopy &c, double sza)
+{
+    double sin_sz, cos_sz;
+    sincos(sza, &sin_sz, &cos_sz);
+    const Primed sp = prime(c.b / c.r, sin_sz / cos_sz);
+    return sun_scalars(c, sza, cos_sz, sp);
+}
+
+struct SunTerms { double C0, B, Z, G, T; };
+struct BandTerms { double gam, omega, Rff, Tff, tff, pff, rs, mgk, Zf, Tf, B; };
+
+__device__ inline BandTerms load_band(const double *__restrict__ L, int nw, int i)
+{
+    BandTerms t;
+    t.gam = L[L_GAMMA * nw + i];  t.omega = L[L_OMEGA * nw + i];
+    t.Rff = L[L_RFF * nw + i];    t.Tff = L[L_TFF * nw + i];
+    t.tff = L[L_tFF * nw + i];    t.pff = L[L_PFF * nw + i];
+    t.rs = L[L_RS * nw + i];      t.mgk = L[L_MGK * nw + i];
+    t.Zf = L[L_ZF * nw + i];      t.Tf = L[L_TF * nw + i];
+    t.B = L[L_B * nw + i];
+    return t;
+}
+
+// the five (sun zenith, band) numbers.  The two quotients of the reference, 1/(1+2 mu gamma) and
+// 1/(1-(2 gamma mu)^2), share ONE fp64 division: 1-(g2)^2 = (1+g2)(1-g2).
+__device__ inline SunTerms sun_terms(const BandTerms &t, const SunScalars &s, double ko, double kep)
+{
+    const double mu = s.mu, fd = s.fd;
+    const double g2 = 2. * t.gam * mu;
+    const double inv = 1.0 / ((1.0 + g2) * (1.0 - g2));
+    const double Rdf = (1.0 - t.gam) * ((1.0 - g2) * inv);                      // (1-gamma)/(1+2 mu gamma), gortt_brdf.c:552
+    const double Tdf = (t.omega / 2.0) * ((1. + 2. * mu) * inv) * (t.Tff - s.t0);   // :467-471
+    const double X = s.t0 * Rdf + Tdf * t.Rff;
+    const double tdf = Tdf - t.pff * X;                                         // :423-424
+    const double pdf = Rdf - t.tff * X;                                         // :628-630
+    const double tpdf = tdf * (1 - s.tp0);                                      // :361
+    SunTerms o;
+    o.B = t.B;
+    o.G = fd * t.rs + (1 - fd) * t.rs;                                          // gortt.c:481-484
+    o.Z = fd * ((tpdf + s.eps) * t.rs) + (1 - fd) * t.Zf;                       // gortt.c:491-494
+    const double Td = (tpdf + s.tp0) * t.mgk;                                   // gortt.c:541-543
+    o.T = fd * Td + (1 - fd) * t.Tf;                                            // gortt.c:550
+    const double kk = kep + ko;
+    const double CfG = (kk * o.G + (1 - kk) * o.Z) * kep;                       // gortt.c:516-517
+    o.C0 = fd * (pdf + Td) + (1 - fd) * (t.pff + CfG + t.Tf);
+    return o;
+}
+
+__device__ inline SunTerms sun_terms(const double *__restrict__ L, int nw, int i, const SunScalars &s,
+                                     double ko, double kep)
+{
+    return sun_terms(load_band(L, nw, i), s, ko, kep);
+}
+
+__device__ inline SunScalars load_sun(const double *__restrict__ rec)
+{
+    SunScalars s;
+    s.fd = rec[S_FD];  s.mu = rec[S_MU];  s.t0 = rec[S_T0];  s.tp0 = rec[S_TP0];
+    s.eps = rec[S_EPS];  s.pn0 = rec[S_PN0];
+    return s;
+}
+
+// ---- which logical block (= 4 consecutive waves of the flat kernels) does this workgroup work on ----
+// Any bijection is correct; only speed depends on it.  Each XCD gets ONE contiguous range of logical blocks
+// (eight compact write windows, one per L2, instead of one window interleaved over all eight).
+//   mode 0  identity (interleaved)
+//   mode 1  static: workgroups b, b+8, ... run on one XCD each (round-robin dispatch, probed per engine).
+//           The XCDs do not write equally fast - on the parts measured the XCDs of one parity (the odd XCC_IDs in
+//           every standalone probe; the even dispatch slots in one process) sustain ~80 % of the others, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
+//           workgroups (the others return at once) and owns a range of logical blocks in proportion
+//           (calibrate_xcd_weights; tools/xcd_stream_probe.hip: 7.06 -> 6.70 ms for the 50 GB slab).
+//   mode 2  dynamic: read the XCD the workgroup really runs on (HW_REG_XCC_ID) and take the next free slot of
+//           that XCD's range with one returning atomic; if the range is used up take one from the next XCD.
+//           The ranges sum to the grid, so every workgroup finds a slot within 8 tries.  The launcher zeroes
+//           the counters (one per 128-B line) on the stream before every launch.
+// Returns -1 for a workgroup without work.
+// mode 1 for workgroup b (host-callable so that gort_selftest_index_math can check the bijection without a GPU)
+__host__ __device__ __forceinline__ long duty_logical_block(long b, const XcdDuty &duty, long useful)
+{
+    const unsigned sh = ((unsigned)b & 7u) * 8u;
+    const unsigned w = (unsigned)(duty.w8 >> sh) & 0xffu;
+    // sum of the weights of the XCDs in front (<= 7 x 32, fits the top byte of the byte-wise product)
+    const unsigned long long below = duty.w8 & ((1ull << sh) - 1ull);
+    const unsigned pw = (unsigned)((below * 0x0101010101010101ull) >> 56);
+    const long i = b >> 3;                               // < 32 q by the size of the grid
+    const long li = (i * w) >> 5;                        // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
+    if ((((i + 1) * w) >> 5) == li) return -1;
+    const long block = duty.q * pw + li;
+    return block < useful ? block : -1;
+}
+
+__device__ __forceinline__ long xcd_logical_block(int xcd_mode, const XcdDuty &duty, long useful,
+                                                  int *__restrict__ xcd_slots)
+{
+    const long b = blockIdx.x;
+    if (xcd_mode == 1) return duty_logical_block(b, duty, useful);
+    if (xcd_mode == 2) {
+        const long base = useful >> 3, rem = useful & 7;     // XCD y owns [y*base + min(y,rem), +base (+1 if y < rem))
+        __shared__ long s_block;
+        if (threadIdx.x == 0) {
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            long L = -1;
+            for (int t = 0; t < 8 && L < 0; ++t) {
+                const long y = (x + t) & 7;
+                const long quota = base + (y < rem ? 1 : 0);
+                const long s = atomicAdd(&xcd_slots[y * XCD_SLOT_PITCH], 1);
+                if (s < quota) L = y * base + (y < rem ? y : rem) + s;
+            }
+            s_block = L;
+        }
+        __syncthreads();
+        return s_block;                                       // never -1 (pigeonhole), checked by the caller anyway
+    }
+    return b < useful ? b : -1;
+}
+
+constexpr int EPL = 2;                  // elements (adjacent bands) per lane and step
+constexpr int CHUNK = 64 * EPL;         // doubles per wave-step
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+// exact n / d for n < 2^31 and a divisor fixed per launch: (n * mul) >> (31 + sh), mul and sh from the host
+// (make_fast_div); five scalar instructions instead of the ~35 of a 32-bit division with a run-time divisor
+__host__ __device__ __forceinline__ unsigned fast_div(unsigned n, FastDiv d)
+{
+    return (unsigned)(((unsigned long long)n * d.mul) >> (31u + d.sh));
+}
+}  // namespace
+}  // namespace gort
+#endif

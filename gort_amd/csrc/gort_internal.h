@@ -94,8 +94,21 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin);
 // expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the
 // call, or nullptr for the static XCD mapping
 long expand_stream_tail_pad_records(int nw, long nA);
-int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
-                         long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream);
+// Wide streams without component spectra are expanded line group by line group (gort_stream.hip): device
+// workspace of expand_stream_workspace() bytes (0 = that form does not apply), angles_dev = the lines themselves.
+// Without workspace (or GORT_STREAM_GROUP=0) every line gets its own sun terms.  Returns whether the stream is
+// wide enough for the flat forms at all.  coef_ready_event (hipEvent_t or null): the records are being written on
+// another stream; `stream` waits for the event before its first kernel that reads them.
+bool expand_stream_workspace(int nw, long nA, bool want_scomp, size_t *ws_bytes, size_t *sun_bytes);
+int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
+                         const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev,
+                         void *group_ws_dev, double *group_sun_dev, void *stream, void *coef_ready_event);
+// gort_stream.hip
+bool stream_group_enabled();
+void stream_group_workspace(int nw, long nA, size_t *ws_bytes, size_t *sun_bytes);
+int launch_expand_stream_grouped(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
+                                 const double *coef_dev, long nA, double *rsurf_dev, void *ws_dev, double *sun_dev,
+                                 void *stream, void *coef_ready_event, const int **direct_flag_dev);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);

@@ -173,6 +173,22 @@ int  gort_rsurf_stream(gort_engine *e, const double *angles, long nA,
 int  gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA,
                            double *rsurf_dev, double *scomp_dev, double *K_dev);
 
+/* Wide streams (>= 4M samples, >= 128 bands, no component spectra) are expanded in one of two forms, chosen on
+ * the device per call: lines grouped by sun zenith (few distinct sun zeniths: the five (sun zenith, band) terms
+ * are shared, 5 FMAs per sample) or per-line sun terms (every line its own sun zenith).  Same bits either way.
+ *   gort_engine_stream_form         form of the last gort_rsurf_stream[_dev] call: 0 = narrow stream (other
+ *                                   kernels), 1 = grouped, 2 = per line; synchronises the engine's stream
+ *   gort_engine_set_stream_grouping 0 = always per line (also GORT_STREAM_GROUP=0), 1 = automatic (default);
+ *                                   automatic: after a call whose lines had too many distinct sun zeniths the next
+ *                                   15 calls go per line without trying (streams are mostly of one kind);
+ *                                   calling this function forgets that history
+ *   gort_engine_last_stream_ms      duration (ms, HIP events on the engine's stream) of the expansion stage of
+ *                                   the last stream call - grouping, sun table and expansion kernels; <0 if none.
+ * New surface for tests and bench tools, not reference surface. */
+int  gort_engine_stream_form(gort_engine *e);
+int  gort_engine_set_stream_grouping(gort_engine *e, int on);
+double gort_engine_last_stream_ms(gort_engine *e);
+
 /* Regular-grid LUT: every (sun zenith, view zenith, relative azimuth) node in integer
  * steps, equivalent to streaming the lines "vza phi sza 0" (SURVEY.md 8d, C3):
  *   sza = sza0 + i*dsza (i<nsza), vza = vza0 + j*dvza (j<nvza), phi = phi0 + l*dphi (l<nphi)

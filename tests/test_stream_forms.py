@@ -1,0 +1,167 @@
+"""The two forms of the wide-stream expansion (gort_amd/csrc/gort_stream.hip): lines grouped by sun zenith and
+per-line sun terms must write the SAME BITS, equal the LUT path on grid angles and agree with the oracle.
+
+Reference interface: the per-line loop of main(), gortt.c:232-329 (+ gortt_rsurf, gortt.c:385-578)."""
+import numpy as np
+import pytest
+
+from conftest import relerr
+from gort_amd import api
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REGRESSION = 1e-9
+
+
+def _oracle_like(c):
+    o = O.make_canopy(favd=c.favd, r=c.r, b=c.b, h1=c.h1, h2=c.h2, lam=c.lambda_, gaps=False)
+    O.set_gap_tables(o, np.array(c.p_n0), np.array(c.epgap), c.k_open, c.k_openep)
+    return o
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    c = api.gap_probabilities(api.make_canopy(lai=4.0))
+    eng = api.Engine()
+    eng.set_canopy(c)
+    yield eng, c, torch
+    eng.close()
+
+
+def _run(eng, torch, ang, nw, grouping, out=None):
+    a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
+    if out is None:
+        out = torch.full((ang.shape[0], nw), -7.0, dtype=torch.float64, device="cuda")
+    eng.set_stream_grouping(grouping)
+    torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
+    eng.rsurf_stream_dev(a, out)
+    eng.synchronize()
+    form = eng.stream_form()
+    eng.set_stream_grouping(True)
+    return out, form
+
+
+def _bits_equal(x, y):
+    return bool((x.view(dtype=__import__("torch").int64) == y.view(dtype=__import__("torch").int64)).all())
+
+
+def _lines(rng, n, sza_pool):
+    sza = rng.choice(sza_pool, n)
+    return np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), sza, rng.uniform(-400, 400, n)], 1)
+
+
+def test_grouped_equals_per_line_bitwise_and_oracle(setup):
+    """70 001 lines (ragged last tile) x 2101 bands, 91 integer sun zeniths in random order, some of them negative
+    (zenith -> |zenith|, azimuth + 180: same group)."""
+    eng, c, torch = setup
+    rng = np.random.default_rng(91)
+    wl = np.arange(400.0, 2501.0)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_spectra(rs, rl, tl)
+    pool = np.concatenate([np.arange(0.0, 90.0), -np.arange(1.0, 45.0)])
+    ang = _lines(rng, 70001, pool)
+    g, form_g = _run(eng, torch, ang, wl.size, True)
+    assert form_g == "grouped"
+    p, form_p = _run(eng, torch, ang, wl.size, False)
+    assert form_p == "per-line"
+    assert _bits_equal(g, p)
+    idx = np.sort(rng.choice(ang.shape[0], 40, replace=False))
+    idx[0], idx[-1] = 0, ang.shape[0] - 1
+    ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[idx], rs, rl, tl, want_K=False)
+    got = g[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+    assert relerr(got, ref, floor=1e-12) <= REGRESSION
+
+
+@pytest.mark.parametrize("nw", [128, 129, 143, 144, 1000, 1999, 2048, 3000])
+def test_grouped_band_counts_and_row_alignments(setup, nw):
+    """Rows of nw doubles start at every alignment class (nw odd) or only some (nw even); the last segment is
+    ragged; the output itself may start off a 128-B boundary."""
+    eng, c, torch = setup
+    rng = np.random.default_rng(nw)
+    wl = np.linspace(400.0, 2500.0, nw)
+    eng.set_spectra(*api.spectra(wl))
+    n = (1 << 22) // nw + 4097
+    ang = _lines(rng, n, np.array([0.0, 12.5, 30.0, 47.25, 60.0, 75.0, 88.0]))
+    for offset in (0, 1, 5, 16):                         # doubles in front of the output
+        buf = torch.full((n * nw + 32,), -7.0, dtype=torch.float64, device="cuda")
+        out = buf[offset:offset + n * nw].view(n, nw)
+        g, form = _run(eng, torch, ang, nw, True, out)
+        assert form == "grouped"
+        p, _ = _run(eng, torch, ang, nw, False)
+        assert _bits_equal(g, p), (nw, offset)
+        assert float(buf[:offset].min() if offset else -7.0) == -7.0 and float(buf[offset + n * nw:].max()) == -7.0
+
+
+def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
+    """A principal-plane style stream (ONE sun zenith, 300 000 lines): the skewed case of the grouping.  Plus lines
+    beyond the horizon and NaN zeniths, which form groups of their own and give NaN rows in both forms."""
+    eng, c, torch = setup
+    rng = np.random.default_rng(7)
+    wl = np.linspace(400.0, 2500.0, 300)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_spectra(rs, rl, tl)
+    n = 300000
+    ang = _lines(rng, n, np.array([30.0]))
+    ang[rng.choice(n, 50, replace=False), 2] = 95.0
+    ang[rng.choice(n, 50, replace=False), 2] = np.nan
+    ang[rng.choice(n, 50, replace=False), 0] = 90.0
+    g, form = _run(eng, torch, ang, wl.size, True)
+    assert form == "grouped"
+    p, _ = _run(eng, torch, ang, wl.size, False)
+    assert _bits_equal(g, p)
+    bad = np.isnan(ang[:, 2]) | (np.abs(ang[:, 2]) > 90) | (np.abs(ang[:, 0]) >= 90)
+    nan_rows = torch.isnan(g).all(dim=1).cpu().numpy()
+    assert np.array_equal(nan_rows, bad)
+    idx = np.flatnonzero(~bad)[:25]
+    ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[idx], rs, rl, tl, want_K=False)
+    assert relerr(g[torch.as_tensor(idx, device="cuda")].cpu().numpy(), ref, floor=1e-12) <= REGRESSION
+
+
+def test_too_many_sun_zeniths_fall_back_on_the_device(setup):
+    """129 distinct sun zeniths inside one tile, or 600 over the whole call with few per tile: the grouped form
+    gives the stream up (flag raised on the device) and the per-line kernel writes it."""
+    eng, c, torch = setup
+    rng = np.random.default_rng(3)
+    wl = np.arange(400.0, 2501.0)
+    eng.set_spectra(*api.spectra(wl))
+    n = 6000
+    ang = _lines(rng, n, np.linspace(0.0, 89.0, 129))
+    g, form = _run(eng, torch, ang, wl.size, True)
+    assert form == "per-line"
+    p, _ = _run(eng, torch, ang, wl.size, False)
+    assert _bits_equal(g, p)
+    # 600 distinct zeniths, 100 per 2048-line tile
+    n = 6 * 2048
+    ang = _lines(rng, n, np.array([0.0]))
+    for t in range(6):
+        ang[t * 2048:(t + 1) * 2048, 2] = rng.choice(np.linspace(0.0 + t, 80.0 + t, 100) + 0.001 * t, 2048)
+    g, form = _run(eng, torch, ang, wl.size, True)
+    assert form == "per-line"
+    p, _ = _run(eng, torch, ang, wl.size, False)
+    assert _bits_equal(g, p)
+    # 128 in every tile and the same 128 everywhere: grouped
+    ang[:, 2] = rng.choice(np.linspace(0.0, 88.9, 128), n)
+    g, form = _run(eng, torch, ang, wl.size, True)
+    assert form == "grouped"
+    p, _ = _run(eng, torch, ang, wl.size, False)
+    assert _bits_equal(g, p)
+
+
+def test_grid_lines_through_the_stream_equal_the_lut(setup):
+    """The metric grid's angles (a slab of it) streamed as lines `vza phi sza 0`: grouped stream == LUT kernel, bit for bit
+    (both take their sun terms from sun_terms() and expand with dot5())."""
+    eng, c, torch = setup
+    wl = np.arange(400.0, 2501.0)
+    eng.set_spectra(*api.spectra(wl))
+    g = api.hemisphere_grid()
+    r0, r1 = 3 * 91 + 17, 3 * 91 + 17 + 12                   # 12 rows x 361 azimuths = 4332 lines, one sun zenith ... two
+    lut = torch.empty(((r1 - r0) * g.nphi, wl.size), dtype=torch.float64, device="cuda")
+    eng.rsurf_grid_dev(g, r0, r1, lut)
+    eng.synchronize()
+    rows = np.arange(r0, r1)
+    ang = np.array([[float(r % 91), float(l), float(r // 91), 0.0] for r in rows for l in range(361)])
+    s, form = _run(eng, torch, ang, wl.size, True)
+    assert form == "grouped"
+    assert _bits_equal(s, lut)

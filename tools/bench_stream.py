@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""The arbitrary-angle stream (gortt.c:232-329) on device-resident buffers: N random lines x 2101 bands, with
+91 distinct sun zeniths (grouped form), every line its own sun zenith (per-line form) and one sun zenith.
+Prints, per case, the time of the expansion stage (HIP events on the engine's stream: grouping + sun table +
+expansion kernels), the whole call (geometry included, wall clock around a stream synchronisation), the samples/s
+and the fraction of the 8 TB/s HBM peak at 8 B per sample + 32 B per line."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from gort_amd import api
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+only = sys.argv[3] if len(sys.argv) > 3 else None
+wl = np.arange(400.0, 2501.0)
+c = api.gap_probabilities(api.make_canopy(lai=4.0))
+eng = api.Engine(); eng.set_canopy(c); eng.set_spectra(*api.spectra(wl))
+rng = np.random.default_rng(0)
+cases = {
+    "91 sun zeniths": rng.integers(0, 90, n).astype(float),
+    "all distinct": rng.uniform(0, 89, n),
+    "1 sun zenith": np.full(n, 30.0),
+    "91 in runs of 32": ((np.arange(n) // 32) % 91).astype(float),
+    "91 in runs of 4": ((np.arange(n) // 4) % 91).astype(float),
+}
+out = torch.empty((n, wl.size), dtype=torch.float64, device="cuda")
+for name, sza in cases.items():
+    if only and only not in name:
+        continue
+    a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), sza, np.zeros(n)], 1), device="cuda")
+    for grouping in (True, False):
+        if name == "all distinct" and not grouping:
+            continue
+        eng.set_stream_grouping(grouping)
+        for _ in range(3):
+            eng.rsurf_stream_dev(a, out)
+        eng.synchronize()
+        ex, wall = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            eng.rsurf_stream_dev(a, out)
+            eng.synchronize()
+            wall.append(time.perf_counter() - t0)
+            ex.append(eng.last_stream_ms() * 1e-3)
+        form = eng.stream_form()
+        byts = n * wl.size * 8 + n * 32
+        e, w = float(np.median(ex)), float(np.median(wall))
+        print("%-15s grouping=%d form=%-8s expansion %7.1f us (%5.0f GB/s, %.3f of 8 TB/s) | call %7.1f us  %.3e samples/s (%.3f)"
+              % (name, grouping, form, e * 1e6, byts / e / 1e9, byts / e / 8e12, w * 1e6, n * wl.size / w, byts / w / 8e12), flush=True)
+eng.set_stream_grouping(True)
