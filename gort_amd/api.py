@@ -57,6 +57,14 @@ class Grid(C.Structure):
     ]
 
 
+class PipeChunk(C.Structure):
+    """struct gort_pipe_chunk"""
+    _fields_ = [("n", C.c_long), ("angles", C.POINTER(D)), ("rsurf", C.POINTER(D)), ("scomp", C.POINTER(D)),
+                ("K", C.POINTER(D)), ("energy", C.POINTER(D))]
+
+
+PIPE_SCOMP, PIPE_ENERGY, PIPE_ENERGY_ONLY = 1, 2, 4
+
 DECLARED_SYMBOLS = [
     "gort_last_error", "gort_version", "gort_canopy_defaults", "gort_leaf_soil_defaults",
     "gort_canopy_newstyle", "gort_canopy_set_lai", "gort_canopy_init", "gort_price_soil",
@@ -71,6 +79,8 @@ DECLARED_SYMBOLS = [
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs", "gort_selftest_index_math",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
     "gort_engine_stream_form", "gort_engine_set_stream_grouping", "gort_engine_last_stream_ms",
+    "gort_host_malloc", "gort_host_free", "gort_set_device", "gort_get_device",
+    "gort_pipe_create", "gort_pipe_acquire", "gort_pipe_submit", "gort_pipe_wait", "gort_pipe_release", "gort_pipe_destroy",
 ]
 
 _lib = None
@@ -104,6 +114,16 @@ def lib():
         for name in ("gort_engine_destroy", "gort_engine_synchronize", "gort_engine_stream", "gort_engine_nw",
                      "gort_engine_last_expand_ms", "gort_engine_xcd_mapping"):
             getattr(L, name).argtypes = [C.c_void_p]
+        L.gort_host_malloc.restype = C.c_void_p
+        L.gort_host_malloc.argtypes = [C.c_size_t]
+        L.gort_host_free.argtypes = [C.c_void_p]
+        L.gort_pipe_create.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
+        L.gort_pipe_acquire.argtypes = [C.c_void_p, C.POINTER(C.POINTER(D))]
+        L.gort_pipe_submit.argtypes = [C.c_void_p, C.c_long]
+        L.gort_pipe_wait.argtypes = [C.c_void_p, C.POINTER(PipeChunk)]
+        L.gort_pipe_release.argtypes = [C.c_void_p]
+        L.gort_pipe_destroy.argtypes = [C.c_void_p]
+        L.gort_pipe_destroy.restype = None
         L.gort_engine_stream_form.argtypes = [C.c_void_p]
         L.gort_engine_set_stream_grouping.argtypes = [C.c_void_p, C.c_int]
         L.gort_engine_last_stream_ms.argtypes = [C.c_void_p]
@@ -184,6 +204,71 @@ class DeviceBuffer:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """float64 numpy array over pinned host memory (gort_host_malloc): DMA target of the host entry points."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(x) for x in (shape if hasattr(shape, "__len__") else (shape,)))
+        n = int(np.prod(self.shape)) if self.shape else 1
+        self.ptr = lib().gort_host_malloc(8 * max(n, 1))
+        if not self.ptr:
+            raise GortError(ENOMEM, lib().gort_last_error().decode())
+        buf = (D * n).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=np.float64, count=n).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().gort_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Pipe:
+    """gort_pipe: chunks of an angle stream in flight (see include/gort_amd.h)."""
+
+    def __init__(self, engine, max_lines, depth=3, flags=0):
+        h = C.c_void_p()
+        _check(lib().gort_pipe_create(engine.h, max_lines, depth, flags, C.byref(h)))
+        self.h, self.nw, self.max_lines = h, engine.nw, max_lines
+
+    def acquire(self):
+        p = C.POINTER(D)()
+        _check(lib().gort_pipe_acquire(self.h, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(self.max_lines, 4))
+
+    def submit(self, n):
+        _check(lib().gort_pipe_submit(self.h, n))
+
+    def wait(self):
+        """dict of numpy views into the slot's pinned buffers, valid until release()."""
+        c = PipeChunk()
+        _check(lib().gort_pipe_wait(self.h, C.byref(c)))
+        n, nw = c.n, self.nw
+        v = lambda p, shape: np.ctypeslib.as_array(p, shape=shape) if p and n > 0 else None
+        return {"n": n, "angles": v(c.angles, (n, 4)), "rsurf": v(c.rsurf, (n, nw)), "scomp": v(c.scomp, (n, nw, 4)),
+                "K": v(c.K, (n, 4)), "energy": v(c.energy, (n, nw, 3))}
+
+    def release(self):
+        _check(lib().gort_pipe_release(self.h))
+
+    def close(self):
+        if self.h:
+            lib().gort_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 
@@ -341,10 +426,13 @@ class Engine:
     def synchronize(self):
         _check(lib().gort_engine_synchronize(self.h))
 
-    def rsurf_stream(self, angles_deg, want_scomp=False, want_K=True):
+    def rsurf_stream(self, angles_deg, want_scomp=False, want_K=True, out=None):
+        """out: optional PinnedArray.array of shape (nA, nw) - results then arrive by ONE DMA at the PCIe rate."""
         ang = _f64(angles_deg).reshape(-1, 4)
         nA = ang.shape[0]
-        out = np.zeros((nA, self.nw))
+        if out is None:
+            out = np.zeros((nA, self.nw))
+        assert out.shape == (nA, self.nw) and out.dtype == np.float64 and out.flags.c_contiguous
         sc = np.zeros((nA, self.nw, 4)) if want_scomp else None
         K = np.zeros((nA, 4)) if want_K else None
         _check(lib().gort_rsurf_stream(self.h, _ptr(ang), nA, _ptr(out), _ptr(sc), _ptr(K)))

@@ -25,6 +25,7 @@ UNITS = [
     ("gort_gap.hip", ["-ffp-contract=off"]),
     ("gort_brdf.hip", []),
     ("gort_stream.hip", []),
+    ("gort_pipe.hip", []),
     ("gort_spectra.hip", []),
     ("gort_api.hip", []),
     ("gort_host.cpp", ["-ffp-contract=off", '-DGORT_DATA_DIR="%s"' % os.path.join(PKG, "data")]),

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <sched.h>
+#include <thread>
 #include <vector>
 
 #include "gort_internal.h"
@@ -66,6 +68,10 @@ struct gort_engine {
     hipEvent_t ev_verdict = nullptr;
     bool group_verdict_pending = false;
     int group_skip = 0;                  // calls left before the grouped form is tried again
+    gort_pipe *hpipe = nullptr;          // pinned staging of the host-buffer entry points, created on first use
+    int hpipe_nw = 0;
+    unsigned hpipe_flags = 0;
+    long hpipe_lines = 0;
     DevBuf xcd_slots;                    // XCD_SLOT_BYTES: per-XCD slot counters of the flat expansion kernels
     int xcd_round_robin = -1;            // probe_xcd_dispatch(): -1 not probed yet, 0 no, 1 yes
     // duty weights of the XCDs (32nds) for the static mapping; calibrated on the first LUT slab big enough
@@ -92,6 +98,19 @@ extern "C" int gort_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+extern "C" int gort_set_device(int device)
+{
+    GORT_HIP(hipSetDevice(device));
+    return GORT_OK;
+}
+
+extern "C" int gort_get_device(void)
+{
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return fail(GORT_ENODEVICE, "gort_get_device: no HIP device");
+    return d;
 }
 
 extern "C" void *gort_dev_malloc(size_t bytes)
@@ -184,6 +203,8 @@ extern "C" int gort_engine_create(gort_engine **out)
 extern "C" void gort_engine_destroy(gort_engine *e)
 {
     if (!e) return;
+    if (e->hpipe) gort_pipe_destroy(e->hpipe);
+    e->hpipe = nullptr;
     if (e->aux) (void)hipStreamSynchronize(e->aux);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->gcoef[0], &e->gcoef[1], &e->gsun[0], &e->gsun[1]}) b->release();
@@ -485,6 +506,113 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     return rc;
 }
 
+// ---- host buffers in, host buffers out ----
+// Pageable memory cannot be the target of a DMA: the runtime stages such copies itself at ~10 GB/s.  Results
+// therefore go either straight into the caller's buffer when that is pinned (gort_host_malloc, hipHostMalloc,
+// hipHostRegister: one copy at the PCIe rate) or through the pinned slots of an internal gort_pipe, chunk by
+// chunk with `depth` chunks in flight, and are copied out of the slots by several host threads while the next
+// chunks are still on their way.
+
+static bool is_pinned_host(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();            // unregistered host memory is reported as an error: clear it
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+static void parallel_copy(void *dst, const void *src, size_t bytes)
+{
+    constexpr size_t PER_THREAD = 8u << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = (unsigned)CPU_COUNT(&set);
+    unsigned nt = (unsigned)(bytes / PER_THREAD);
+    if (nt > hw) nt = hw;
+    if (nt > 8) nt = 8;
+    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t a = bytes * t / nt / 64 * 64, b = t + 1 == nt ? bytes : bytes * (t + 1) / nt / 64 * 64;
+        pool.emplace_back([=] { std::memcpy((char *)dst + a, (const char *)src + a, b - a); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+// lines per slot of the internal pipe: ~32 MiB of rsurf, a few chunks per call
+static long host_chunk_lines(int nw, bool scomp, bool energy)
+{
+    const size_t per_line = sizeof(double) * (size_t)(nw > 0 ? nw : 1) * (1 + (scomp ? 4 : 0) + (energy ? 3 : 0));
+    long n = (long)((32u << 20) / per_line);
+    return n < 256 ? 256 : (n > 65536 ? 65536 : n);
+}
+
+static int host_pipe(gort_engine *e, unsigned flags, gort_pipe **out)
+{
+    const long lines = host_chunk_lines(e->nw, flags & GORT_PIPE_SCOMP, flags & GORT_PIPE_ENERGY);
+    if (e->hpipe && (e->hpipe_nw != e->nw || e->hpipe_flags != flags)) {
+        gort_pipe_destroy(e->hpipe);
+        e->hpipe = nullptr;
+    }
+    if (!e->hpipe) {
+        const int rc = gort_pipe_create(e, lines, 3, flags, &e->hpipe);
+        if (rc) return rc;
+        e->hpipe_nw = e->nw;
+        e->hpipe_flags = flags;
+        e->hpipe_lines = lines;
+    }
+    *out = e->hpipe;
+    return GORT_OK;
+}
+
+// nA lines through the internal pipe; `energy` selects what is collected
+static int staged_stream(gort_engine *e, const double *angles, long nA, double *rsurf, double *scomp, double *K,
+                         double *energy)
+{
+    gort_pipe *p = nullptr;
+    const unsigned flags = (scomp ? GORT_PIPE_SCOMP : 0u) | (energy ? (rsurf ? GORT_PIPE_ENERGY : GORT_PIPE_ENERGY_ONLY) : 0u);
+    int rc = host_pipe(e, flags, &p);
+    if (rc) return rc;
+    const long L = e->hpipe_lines;
+    const size_t nw = (size_t)e->nw, D = sizeof(double);
+    long sent = 0, got = 0;
+    int in_flight = 0;
+    auto collect = [&]() -> int {
+        gort_pipe_chunk c;
+        int r = gort_pipe_wait(p, &c);
+        if (r == GORT_OK) {
+            const size_t o = (size_t)got;
+            if (rsurf) parallel_copy(rsurf + o * nw, c.rsurf, D * (size_t)c.n * nw);
+            if (scomp) parallel_copy(scomp + o * nw * 4, c.scomp, D * 4 * (size_t)c.n * nw);
+            if (K) std::memcpy(K + o * 4, c.K, D * 4 * (size_t)c.n);
+            if (energy) parallel_copy(energy + o * nw * 3, c.energy, D * 3 * (size_t)c.n * nw);
+            got += c.n;
+        }
+        const int r2 = gort_pipe_release(p);
+        --in_flight;
+        return r ? r : r2;
+    };
+    while (sent < nA) {
+        if (in_flight == 3 && (rc = collect())) break;
+        double *slot = nullptr;
+        if ((rc = gort_pipe_acquire(p, &slot))) break;
+        const long n = nA - sent < L ? nA - sent : L;
+        std::memcpy(slot, angles + 4 * sent, D * 4 * (size_t)n);
+        rc = gort_pipe_submit(p, n);
+        ++in_flight;
+        sent += n;
+        if (rc) break;
+    }
+    while (in_flight > 0) {
+        const int r = collect();
+        if (rc == GORT_OK) rc = r;
+    }
+    return rc;
+}
+
 extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, double *rsurf, double *scomp,
                                  double *K)
 {
@@ -493,6 +621,10 @@ extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, 
     if (nA < 0 || (nA > 0 && (!angles || !rsurf))) return fail(GORT_EINVAL, "gort_rsurf_stream: bad argument");
     if (nA == 0) return GORT_OK;
     const size_t nw = (size_t)e->nw, n = (size_t)nA;
+    const size_t out_bytes = sizeof(double) * n * nw * (scomp ? 5 : 1);
+    const bool direct = out_bytes < (4u << 20) || (is_pinned_host(rsurf) && (!scomp || is_pinned_host(scomp)));
+    if (!direct) return staged_stream(e, angles, nA, rsurf, scomp, K, nullptr);
+    // small calls, and callers with pinned buffers: one copy in, the kernels, one copy out
     if ((rc = e->angles.reserve(sizeof(double) * 4 * n))) return rc;
     if ((rc = e->out.reserve(sizeof(double) * n * nw))) return rc;
     if (scomp && (rc = e->out2.reserve(sizeof(double) * 4 * n * nw))) return rc;
@@ -771,6 +903,8 @@ extern "C" int gort_energy_stream(gort_engine *e, const double *angles, long nA,
     if (nA < 0 || (nA > 0 && (!angles || !energy))) return fail(GORT_EINVAL, "gort_energy_stream: bad argument");
     if (nA == 0) return GORT_OK;
     const size_t n = (size_t)nA, nw = (size_t)e->nw;
+    if (sizeof(double) * 3 * n * nw >= (4u << 20) && !is_pinned_host(energy))
+        return staged_stream(e, angles, nA, nullptr, nullptr, nullptr, energy);
     if ((rc = e->angles.reserve(sizeof(double) * 4 * n))) return rc;
     if ((rc = e->out.reserve(sizeof(double) * 3 * n * nw))) return rc;
     GORT_HIP(hipMemcpyAsync(e->angles.p, angles, sizeof(double) * 4 * n, hipMemcpyHostToDevice, e->stream));

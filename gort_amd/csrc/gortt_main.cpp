@@ -14,17 +14,28 @@
 //     beyond 32);
 //   * -soil_spectra, which in the reference only dumps a table and exits with failure,
 //     is rejected with a message.
-// Extensions (double-dash, unknown options to the reference): --binary-in, --binary-out, --lut-hex.
+// Extensions (double-dash, unknown options to the reference): --binary-in, --binary-out, --lut-hex, --gpus N.
+//
+// The per-line loop of the reference (read, evaluate, print: gortt.c:232-329) is a three-stage pipeline here:
+// this thread reads and parses chunk i+1 into a pinned slot of a gort_pipe while the GPU evaluates chunk i and
+// a second thread formats and writes chunk i-1; the copies to and from the device run on streams of their own.
+#include <algorithm>
 #include <cctype>
+#include <cerrno>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <sched.h>
 #include <string>
 #include <strings.h>
+#include <sys/uio.h>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "gort_amd.h"
@@ -117,6 +128,7 @@ struct Options {
     bool binary_in = false;    // --binary-in : after the text header, angle lines are records of 4 raw doubles
     bool binary_out = false;   // --binary-out: rows are raw doubles in print order (angles, then per band ..., K, energy)
     bool lut_hex = false;      // --lut-hex   : -W writes C99 hex floats (exact; -P of either program reads them)
+    std::vector<int> devices;  // --gpus N (devices 0..N-1) or GORTT_DEVICES="0,2,3": chunks go round the devices
     std::string lut_file;
 };
 
@@ -145,6 +157,15 @@ void parse_args(int argc, char **argv, Options &o)
         if (!std::strcmp(a, "--binary-in")) o.binary_in = true;
         else if (!std::strcmp(a, "--binary-out")) o.binary_out = true;
         else if (!std::strcmp(a, "--lut-hex")) o.lut_hex = true;
+        else if (!std::strcmp(a, "--gpus")) {
+            const int n = atoi(val());
+            if (n < 1 || n > 64) {
+                std::fprintf(stderr, "%s: --gpus needs a count between 1 and 64\n", argv[0]);
+                std::exit(EXIT_FAILURE);
+            }
+            o.devices.clear();
+            for (int d = 0; d < n; ++d) o.devices.push_back(d);
+        }
         else if (ci(a, "-favd", 5)) o.canopy.favd = atof(val());
         else if (ci(a, "-h1", 3)) o.canopy.h1 = atof(val());
         else if (ci(a, "-h2", 3)) o.canopy.h2 = atof(val());
@@ -188,6 +209,18 @@ void parse_args(int argc, char **argv, Options &o)
             std::exit(EXIT_FAILURE);
         }
     }
+    if (o.devices.empty())
+        if (const char *v = std::getenv("GORTT_DEVICES")) {
+            // a list of device ordinals; one may appear more than once (two pipes on one GPU)
+            for (const char *q = v; *q;) {
+                char *end;
+                const long d = std::strtol(q, &end, 10);
+                if (end == q || d < 0) break;
+                o.devices.push_back((int)d);
+                q = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') break;
+            }
+        }
     if (use_true_p) gort_canopy_newstyle(&o.canopy, hb, br, pcc);
     if (use_lai) gort_canopy_set_lai(&o.canopy, lai);
 }
@@ -326,28 +359,175 @@ int main(int argc, char **argv)
     if (gort_spectra(&o.leaf, wl.data(), nw, rsoil.data(), rleaf.data(), tleaf.data()) != GORT_OK)
         die("%s\n", gort_last_error());
 
-    gort_engine *eng = nullptr;
-    check(gort_engine_create(&eng));
-    check(gort_engine_set_canopy(eng, &o.canopy));
-    if (nw > 0) check(gort_engine_set_spectra(eng, nw, rsoil.data(), rleaf.data(), tleaf.data()));
+    // one engine + one pipe of chunks in flight per device (--gpus N / GORTT_DEVICES="0,1,..": chunk k goes to
+    // device k mod N, rows leave in input order)
+    std::vector<int> devices = o.devices;
+    if (devices.empty()) devices.push_back(-1);                 // -1: whatever device is current
+    const size_t per_line_out = (size_t)nw * (1 + (o.prnspec ? 4 : 0) + (o.energy ? 3 : 0)) + 8;
+    size_t chunk_mb = 48;                                        // GORTT_CHUNK_MB: output bytes per chunk
+    if (const char *v = std::getenv("GORTT_CHUNK_MB")) { const long m = atol(v); if (m >= 1 && m <= 4096) chunk_mb = (size_t)m; }
+    const bool verbose = std::getenv("GORTT_VERBOSE") != nullptr;   // stage timings on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
+    double t_acquire = 0, t_read = 0, t_submit = 0, t_wait = 0, t_write = 0;
+    long CHUNK = (long)((chunk_mb << 20) / (sizeof(double) * per_line_out));
+    CHUNK = CHUNK < 1024 ? 1024 : (CHUNK > 262144 ? 262144 : CHUNK);
+    // small inputs: small pinned buffers and one slot (a stream longer than its header says still works, unpipelined)
+    if (na_check > 0 && na_check < CHUNK) CHUNK = na_check < 256 ? 256 : na_check;
+    const int depth = (na_check > 0 && na_check <= CHUNK) ? 1 : 3;
+    const unsigned pflags = (o.prnspec ? GORT_PIPE_SCOMP : 0u) | (o.energy ? GORT_PIPE_ENERGY : 0u);
+    struct Dev { gort_engine *eng = nullptr; gort_pipe *pipe = nullptr; int id = -1; };
+    std::vector<Dev> devs(devices.size());
+    for (size_t d = 0; d < devs.size(); ++d) {
+        devs[d].id = devices[d];
+        if (devices[d] >= 0) check(gort_set_device(devices[d]));
+        check(gort_engine_create(&devs[d].eng));
+        check(gort_engine_set_canopy(devs[d].eng, &o.canopy));
+        if (nw > 0) check(gort_engine_set_spectra(devs[d].eng, nw, rsoil.data(), rleaf.data(), tleaf.data()));
+        check(gort_pipe_create(devs[d].eng, CHUNK, depth, pflags, &devs[d].pipe));
+    }
 
     std::fputs(header.c_str(), stdout);
+    std::fflush(stdout);
+    const double t_setup = since(t_start);
 
-    // angle lines, batched to the device (gortt.c:232-329)
-    const long CHUNK = 1L << 16;
+    // ---- consumer: collects the chunks in order, formats (or gathers, --binary-out) and writes them ----
+    std::mutex mu;
+    std::condition_variable cv;
+    long chunks_submitted = 0;
+    bool producer_done = false;
+    std::string consumer_error;
     long na = 0;
+    auto format_lines = [&](const gort_pipe_chunk &c, long a0, long a1, Out &dst) {
+        for (long a = a0; a < a1; ++a) {
+            for (int q = 0; q < 4; ++q) dst.raw(c.angles[4 * a + q]);
+            for (int i = 0; i < nw; ++i) {
+                dst.num(c.rsurf[(size_t)a * nw + i]);
+                if (o.prnspec) {
+                    dst.buf += "{ ";
+                    for (int q = 0; q < 4; ++q) dst.num(c.scomp[((size_t)a * nw + i) * 4 + q]);
+                    dst.buf += "} ";
+                }
+            }
+            if (o.prnprop) {
+                dst.buf += "[ ";
+                for (int q = 0; q < 4; ++q) dst.num(nw > 0 ? c.K[4 * a + q] : 0.0);
+                dst.buf += "] ";
+            }
+            if (o.energy)
+                for (int i = 0; i < 3 * nw; ++i) dst.num(c.energy[(size_t)a * nw * 3 + i]);
+            dst.buf += "\n";
+        }
+    };
+    // --binary-out rows are gathered with writev straight from the pinned buffers (same field order as the text row)
+    auto write_binary = [&](const gort_pipe_chunk &c) -> bool {
+        std::vector<struct iovec> iov;
+        iov.reserve(1024);
+        auto flush = [&]() -> bool {
+            size_t i = 0;
+            while (i < iov.size()) {
+                const ssize_t w = writev(STDOUT_FILENO, &iov[i], (int)std::min<size_t>(iov.size() - i, 1024));
+                if (w < 0) { if (errno == EINTR) continue; return false; }
+                size_t left = (size_t)w;
+                while (left > 0 && i < iov.size()) {
+                    if (left >= iov[i].iov_len) { left -= iov[i].iov_len; ++i; }
+                    else { iov[i].iov_base = (char *)iov[i].iov_base + left; iov[i].iov_len -= left; left = 0; }
+                }
+            }
+            iov.clear();
+            return true;
+        };
+        auto add = [&](const double *p, size_t n) { if (n) iov.push_back({(void *)p, n * sizeof(double)}); };
+        for (long a = 0; a < c.n; ++a) {
+            add(c.angles + 4 * a, 4);
+            if (!o.prnspec) {
+                add(c.rsurf + (size_t)a * nw, (size_t)nw);
+            } else {
+                for (int i = 0; i < nw; ++i) {
+                    add(c.rsurf + (size_t)a * nw + i, 1);
+                    add(c.scomp + ((size_t)a * nw + i) * 4, 4);
+                }
+            }
+            if (o.prnprop) add(c.K + 4 * a, 4);
+            if (o.energy) add(c.energy + (size_t)a * nw * 3, (size_t)nw * 3);
+            if (iov.size() + 8 + (o.prnspec ? 2 * (size_t)nw : 0) > 1024 && !flush()) return false;
+        }
+        return flush();
+    };
+    std::thread consumer([&] {
+        long k = 0;
+        Out out;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return chunks_submitted > k || producer_done; });
+                if (chunks_submitted <= k) break;
+            }
+            Dev &dv = devs[(size_t)(k % (long)devs.size())];
+            if (dv.id >= 0) gort_set_device(dv.id);
+            gort_pipe_chunk c;
+            const auto tw = std::chrono::steady_clock::now();
+            const int wrc = gort_pipe_wait(dv.pipe, &c);
+            t_wait += since(tw);
+            const auto tf = std::chrono::steady_clock::now();
+            if (wrc != GORT_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (consumer_error.empty()) consumer_error = gort_last_error();
+                gort_pipe_release(dv.pipe);
+                ++k;
+                continue;
+            }
+            const long n = c.n;
+            if (o.binary_out) {
+                if (!write_binary(c)) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (consumer_error.empty()) consumer_error = "write error on stdout";
+                }
+            } else {
+                // text rows: the formatting (exact "%f", gort_format_f6) is the slowest stage of the whole program, so
+                // the lines of a chunk are formatted by several threads into their own buffers and written in order
+                const size_t per_line = 4 + (size_t)nw * (o.prnspec ? 5 : 1) + (o.prnprop ? 4 : 0) + (o.energy ? 3 * (size_t)nw : 0);
+                const unsigned workers = format_threads((size_t)n * per_line);
+                if (workers <= 1) {
+                    for (long a0 = 0; a0 < n; a0 += 4096) {
+                        format_lines(c, a0, a0 + 4096 < n ? a0 + 4096 : n, out);
+                        out.flush();
+                    }
+                } else {
+                    std::vector<Out> parts(workers);
+                    std::vector<std::thread> pool;
+                    for (unsigned t = 0; t < workers; ++t)
+                        pool.emplace_back([&, t] { format_lines(c, n * (long)t / workers, n * (long)(t + 1) / workers, parts[t]); });
+                    for (auto &th : pool) th.join();
+                    for (auto &part : parts) part.flush();
+                }
+                std::fflush(stdout);
+            }
+            t_write += since(tf);
+            gort_pipe_release(dv.pipe);
+            ++k;
+        }
+    });
+
+    // ---- producer (this thread): reads and parses chunk after chunk into the pipes' pinned slots (gortt.c:232-237) ----
     bool bad_line = false, eof = false;
-    std::vector<double> ang, rsurf, scomp, K, energy;
     std::string line, text;
     std::vector<size_t> offsets;
-    Out out;
-    while (!eof && !bad_line) {
-        ang.clear();
+    std::string producer_error;
+    long k_chunk = 0;
+    while (!eof && !bad_line && producer_error.empty()) {
+        Dev &dv = devs[(size_t)(k_chunk % (long)devs.size())];
+        if (dv.id >= 0) gort_set_device(dv.id);
+        double *ang = nullptr;
+        const auto ta = std::chrono::steady_clock::now();
+        if (gort_pipe_acquire(dv.pipe, &ang) != GORT_OK) { producer_error = gort_last_error(); break; }
+        t_acquire += since(ta);
+        const auto tr = std::chrono::steady_clock::now();
+        long n = 0;
         if (o.binary_in) {
-            ang.resize((size_t)CHUNK * 4);
-            const size_t got = std::fread(ang.data(), sizeof(double), (size_t)CHUNK * 4, stdin);
+            const size_t got = std::fread(ang, sizeof(double), (size_t)CHUNK * 4, stdin);
             if (got % 4 != 0) bad_line = true;           // truncated record
-            ang.resize(got - got % 4);
+            n = (long)(got / 4);
             if (got < (size_t)CHUNK * 4) eof = true;
         } else {
             // the chunk's lines are collected NUL-terminated (strtod must not run on into the next line) and
@@ -361,7 +541,6 @@ int main(int argc, char **argv)
                 text.push_back('\0');
             }
             const long nl = (long)offsets.size();
-            ang.resize((size_t)nl * 4);
             const unsigned workers = format_threads((size_t)nl * 64);            // ~4 strtod calls per line
             std::vector<long> first_bad(workers, nl);
             auto parse_lines = [&](unsigned t) {
@@ -378,78 +557,39 @@ int main(int argc, char **argv)
             }
             long good = nl;
             for (unsigned t = 0; t < workers; ++t) good = first_bad[t] < good ? first_bad[t] : good;
-            if (good < nl) { bad_line = true; ang.resize((size_t)good * 4); }
+            if (good < nl) bad_line = true;
+            n = good;
         }
-        const long n = (long)(ang.size() / 4);
-        if (n > 0) {
-            rsurf.resize((size_t)n * nw);
-            if (o.prnspec) scomp.resize((size_t)n * nw * 4);
-            K.resize((size_t)n * 4);
-            if (nw > 0)
-                check(gort_rsurf_stream(eng, ang.data(), n, rsurf.data(), o.prnspec ? scomp.data() : nullptr, K.data()));
-            if (o.energy && nw > 0) {
-                energy.resize((size_t)n * nw * 3);
-                check(gort_energy_stream(eng, ang.data(), n, energy.data()));
-            }
-            for (long a = 0; o.binary_out && a < n; ++a) {
-                // same field order as the text row, raw little-endian doubles
-                std::fwrite(&ang[4 * a], sizeof(double), 4, stdout);
-                if (!o.prnspec) {
-                    std::fwrite(&rsurf[(size_t)a * nw], sizeof(double), (size_t)nw, stdout);
-                } else {
-                    for (int i = 0; i < nw; ++i) {
-                        std::fwrite(&rsurf[(size_t)a * nw + i], sizeof(double), 1, stdout);
-                        std::fwrite(&scomp[((size_t)a * nw + i) * 4], sizeof(double), 4, stdout);
-                    }
-                }
-                if (o.prnprop) std::fwrite(&K[4 * a], sizeof(double), 4, stdout);
-                if (o.energy) std::fwrite(&energy[(size_t)a * nw * 3], sizeof(double), (size_t)nw * 3, stdout);
-            }
-            // text rows: the formatting (exact "%f", gort_format_f6) is the slowest stage of the whole program, so
-            // the lines of a chunk are formatted by several threads into their own buffers and written in order
-            auto format_lines = [&](long a0, long a1, Out &dst) {
-                for (long a = a0; a < a1; ++a) {
-                    for (int q = 0; q < 4; ++q) dst.raw(ang[4 * a + q]);
-                    for (int i = 0; i < nw; ++i) {
-                        dst.num(rsurf[(size_t)a * nw + i]);
-                        if (o.prnspec) {
-                            dst.buf += "{ ";
-                            for (int q = 0; q < 4; ++q) dst.num(scomp[((size_t)a * nw + i) * 4 + q]);
-                            dst.buf += "} ";
-                        }
-                    }
-                    if (o.prnprop) {
-                        dst.buf += "[ ";
-                        for (int q = 0; q < 4; ++q) dst.num(nw > 0 ? K[4 * a + q] : 0.0);
-                        dst.buf += "] ";
-                    }
-                    if (o.energy)
-                        for (int i = 0; i < 3 * nw; ++i) dst.num(energy[(size_t)a * nw * 3 + i]);
-                    dst.buf += "\n";
-                }
-            };
-            if (!o.binary_out) {
-                const size_t per_line = 4 + (size_t)nw * (o.prnspec ? 5 : 1) + (o.prnprop ? 4 : 0) + (o.energy ? 3 * (size_t)nw : 0);
-                unsigned workers = format_threads((size_t)n * per_line);
-                if (workers <= 1) {
-                    for (long a0 = 0; a0 < n; a0 += 4096) {
-                        format_lines(a0, a0 + 4096 < n ? a0 + 4096 : n, out);
-                        out.flush();
-                    }
-                } else {
-                    std::vector<Out> parts(workers);
-                    std::vector<std::thread> pool;
-                    for (unsigned t = 0; t < workers; ++t)
-                        pool.emplace_back(format_lines, n * (long)t / workers, n * (long)(t + 1) / workers, std::ref(parts[t]));
-                    for (auto &th : pool) th.join();
-                    for (auto &part : parts) part.flush();
-                }
-            }
-            out.flush();
-            na += n;
+        t_read += since(tr);
+        const auto ts = std::chrono::steady_clock::now();
+        if (gort_pipe_submit(dv.pipe, n) != GORT_OK) producer_error = gort_last_error();
+        t_submit += since(ts);
+        na += n;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ++chunks_submitted;
         }
+        cv.notify_all();
+        ++k_chunk;
     }
-    gort_engine_destroy(eng);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        producer_done = true;
+    }
+    cv.notify_all();
+    consumer.join();
+    std::fflush(stdout);
+    if (verbose)
+        std::fprintf(stderr, "gortt: %ld lines in %ld chunks of <= %ld; setup %.3f s, total %.3f s; producer: slot wait %.3f, "
+                     "read+parse %.3f, submit %.3f; consumer: chunk wait %.3f, format+write %.3f\n", na, k_chunk, CHUNK,
+                     t_setup, since(t_start), t_acquire, t_read, t_submit, t_wait, t_write);
+    for (Dev &dv : devs) {
+        if (dv.id >= 0) gort_set_device(dv.id);
+        gort_pipe_destroy(dv.pipe);
+        gort_engine_destroy(dv.eng);
+    }
+    if (!producer_error.empty()) die("%s: %s\n", g_prog, producer_error.c_str());
+    if (!consumer_error.empty()) die("%s: %s\n", g_prog, consumer_error.c_str());
     if (bad_line) {
         std::fflush(stdout);
         std::fprintf(stderr, "%s: error on input, line %ld\n", argv[0], na + 1);

@@ -114,6 +114,11 @@ int  gort_lut_read(const char *path, gort_canopy *c);
 /* ============================== device entry points ============================== */
 
 int  gort_device_count(void);
+/* Device of the calling thread (hipSetDevice / hipGetDevice).  Engines, pipes and buffers belong to the device
+ * that was current when they were created; a thread that drives several devices selects the owner's device
+ * before calling into it (gort_pipe_* do that themselves).  gort_get_device returns the ordinal or <0. */
+int  gort_set_device(int device);
+int  gort_get_device(void);
 
 /* Plain device-memory helpers for callers that do not bring their own allocator (the `gortt`
  * host, C drivers).  New surface, not reference surface.  gort_dev_malloc returns NULL on failure. */
@@ -121,6 +126,12 @@ void *gort_dev_malloc(size_t bytes);
 void  gort_dev_free(void *p_dev);
 int   gort_memcpy_h2d(void *dst_dev, const void *src, size_t bytes);
 int   gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
+
+/* Pinned (page-locked) host memory: buffers from here travel over PCIe by DMA at the link rate, and
+ * gort_rsurf_stream / gort_energy_stream copy straight into them; results written into ordinary pageable memory
+ * are staged through pinned chunks and copied once more by the host.  gort_host_malloc returns NULL on failure. */
+void *gort_host_malloc(size_t bytes);
+void  gort_host_free(void *p);
 
 /* Pn/EPgap/KOpen for a batch of canopies (one workgroup per member).  Fills
  * p_n0/epgap/k_open/k_openep of every record in place; honours use_q08.
@@ -131,7 +142,9 @@ int  gort_gap_probabilities(gort_canopy *members, int n_members);
 int  gort_gap_probabilities_dev(gort_canopy *members_dev, int n_members, void *stream);
 
 /* Opaque engine: owns a HIP stream, the device copy of one canopy, the spectra and
- * the wavelength-only tables derived from them. */
+ * the wavelength-only tables derived from them.  NOT thread-safe: one thread at a time per engine (the
+ * reference's functions are not re-entrant on their structs either); use one engine per thread,
+ * or a gort_pipe, whose producer and consumer sides may live on two threads. */
 typedef struct gort_engine gort_engine;
 int  gort_engine_create(gort_engine **out);
 void gort_engine_destroy(gort_engine *e);
@@ -243,6 +256,34 @@ int  gort_energy_stream_dev(gort_engine *e, const double *angles_dev, long nA, d
  * the reduced per-member product (albedo, fAPAR) an ensemble driver exchanges between GPUs */
 int  gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
                              int member_end, double *energy_dev);
+
+/* ---- chunks of an angle stream in flight (what `gortt` runs on) ----
+ * Replaces the read-evaluate-print loop of main(), gortt.c:232-329, by a pipeline of `depth` slots: while the
+ * kernels of chunk i run, the angles of chunk i+1 are copied in and the results of chunk i-1 are copied out, all
+ * on streams of their own and ordered by events; the host is free to parse and format meanwhile.
+ *   gort_pipe_create   slots of max_lines lines each for the engine's current band count (set canopy and spectra
+ *                      first; do not change the band count while the pipe lives).  flags: GORT_PIPE_SCOMP (component
+ *                      spectra, -prnspec), GORT_PIPE_ENERGY (albedo/fAPAR, -energy), GORT_PIPE_ENERGY_ONLY.
+ *                      Host buffers are pinned.
+ *   gort_pipe_acquire  blocks until a slot is free; *angles = its pinned input buffer [max_lines][4] (degrees)
+ *   gort_pipe_submit   n lines of the acquired slot: copy in, kernels, copy out are queued; returns at once
+ *   gort_pipe_wait     blocks until the OLDEST submitted chunk has arrived on the host; its buffers stay valid
+ *                      until gort_pipe_release (rsurf[n][nw], scomp[n][nw][4] or NULL, K[n][4], energy[n][nw][3] or NULL)
+ *   acquire/submit belong to one thread, wait/release to one (possibly another) thread. */
+#define GORT_PIPE_SCOMP  1u
+#define GORT_PIPE_ENERGY 2u
+#define GORT_PIPE_ENERGY_ONLY 4u     /* albedo/fAPAR without rsurf and K (those pointers of a chunk are NULL) */
+typedef struct gort_pipe gort_pipe;
+typedef struct gort_pipe_chunk {
+    long n;
+    const double *angles, *rsurf, *scomp, *K, *energy;
+} gort_pipe_chunk;
+int  gort_pipe_create(gort_engine *e, long max_lines, int depth, unsigned flags, gort_pipe **out);
+int  gort_pipe_acquire(gort_pipe *p, double **angles);
+int  gort_pipe_submit(gort_pipe *p, long n);
+int  gort_pipe_wait(gort_pipe *p, gort_pipe_chunk *out);
+int  gort_pipe_release(gort_pipe *p);
+void gort_pipe_destroy(gort_pipe *p);
 
 #ifdef __cplusplus
 }

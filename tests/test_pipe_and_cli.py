@@ -1,0 +1,136 @@
+"""Chunks in flight: the gort_pipe C ABI, the pinned / staged host entry points and the three-stage pipeline of
+the `gortt` executable (parse | GPU | format).  Reference interface: the per-line loop gortt.c:232-329."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+from gort_amd import api
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+REGRESSION = 1e-9
+
+
+def _lines(rng, n, distinct=True):
+    sza = rng.uniform(0, 89, n) if distinct else rng.integers(0, 90, n).astype(float)
+    return np.stack([rng.uniform(-89, 89, n), rng.uniform(0, 360, n), sza, rng.uniform(0, 360, n)], 1)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = api.Engine()
+    e.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
+    yield e
+    e.close()
+
+
+def test_pipe_chunks_in_flight_equal_one_call(eng):
+    """10 chunks through a 3-slot pipe (producer runs ahead of the consumer) == the same lines in one call."""
+    rng = np.random.default_rng(11)
+    wl = np.linspace(400.0, 2500.0, 700)
+    eng.set_spectra(*api.spectra(wl))
+    ang = _lines(rng, 10 * 3000 - 1234, distinct=False)
+    whole, sc_whole, K_whole = eng.rsurf_stream(ang, want_scomp=True)
+    e_whole = eng.energy_stream(ang[:500])
+    pipe = api.Pipe(eng, 3000, depth=3, flags=api.PIPE_SCOMP)
+    got, got_sc, got_K = [], [], []
+    sent = collected = 0
+    k = 0
+    nchunks = (ang.shape[0] + 2999) // 3000
+    while collected < nchunks:
+        while sent < nchunks and sent - collected < 3:
+            a = pipe.acquire()
+            n = min(3000, ang.shape[0] - sent * 3000)
+            a[:n] = ang[sent * 3000: sent * 3000 + n]
+            pipe.submit(n)
+            sent += 1
+        c = pipe.wait()
+        assert np.array_equal(c["angles"], ang[collected * 3000: collected * 3000 + c["n"]])
+        got.append(c["rsurf"].copy()); got_sc.append(c["scomp"].copy()); got_K.append(c["K"].copy())
+        pipe.release()
+        collected += 1
+    pipe.close()
+    assert np.array_equal(np.concatenate(got).view(np.int64), whole.view(np.int64))
+    assert np.array_equal(np.concatenate(got_sc).view(np.int64), sc_whole.view(np.int64))
+    assert np.array_equal(np.concatenate(got_K).view(np.int64), K_whole.view(np.int64))
+    # energy through a pipe
+    pipe = api.Pipe(eng, 500, depth=1, flags=api.PIPE_ENERGY_ONLY)
+    a = pipe.acquire(); a[:500] = ang[:500]; pipe.submit(500)
+    c = pipe.wait()
+    assert c["rsurf"] is None and np.array_equal(c["energy"].view(np.int64), e_whole.view(np.int64))
+    pipe.release(); pipe.close()
+    # an empty chunk is a chunk
+    pipe = api.Pipe(eng, 16, depth=2)
+    pipe.acquire(); pipe.submit(0)
+    assert pipe.wait()["n"] == 0
+    pipe.release(); pipe.close()
+
+
+def test_host_entry_pinned_equals_staged_equals_oracle(eng):
+    """gort_rsurf_stream into pageable memory (pinned staging, 3 chunks in flight, threaded copy-out) and into a
+    pinned buffer (one DMA) give the same bits; a sample of lines against the oracle."""
+    rng = np.random.default_rng(12)
+    wl = np.arange(400.0, 2501.0)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_spectra(rs, rl, tl)
+    ang = _lines(rng, 30011)
+    staged, _, K = eng.rsurf_stream(ang)
+    pin = api.PinnedArray((ang.shape[0], wl.size))
+    pinned, _, K2 = eng.rsurf_stream(ang, out=pin.array)
+    assert pinned is pin.array
+    assert np.array_equal(staged.view(np.int64), pinned.view(np.int64)) and np.array_equal(K, K2)
+    idx = np.sort(rng.choice(ang.shape[0], 30, replace=False))
+    c = O.make_canopy(lai=4.0)
+    ref, _, _ = O.rsurf_stream(c, ang[idx], *O.spectra(wl), want_K=False)
+    assert relerr(staged[idx], ref, floor=1e-12) <= REGRESSION
+    pin.free()
+    # the energy entry point staged (3 x 2101 doubles per line)
+    e_big = eng.energy_stream(ang[:4000])
+    e_small = np.concatenate([eng.energy_stream(ang[i:i + 50]) for i in range(0, 200, 50)])
+    assert np.array_equal(e_big[:200].view(np.int64), e_small.view(np.int64))
+
+
+def _gortt(args, stdin_bytes, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    run = subprocess.run([api.GORTT_BIN] + args, input=stdin_bytes, capture_output=True, timeout=600, env=e)
+    return run.returncode, run.stdout, run.stderr
+
+
+def test_cli_pipeline_many_chunks_in_order_and_devices():
+    """A text stream of several chunks (chunk size follows the band count): rows leave in input order, and
+    --gpus 1, the default and two pipes on one device (GORTT_DEVICES=0,0: the multi-device path of a box with one
+    GPU) write identical bytes; binary output carries the same numbers."""
+    rng = np.random.default_rng(13)
+    n, wl = 9000, np.linspace(400, 2500, 1500).round(2)
+    ang = np.round(_lines(rng, n, distinct=False), 4)
+    head = ("%d %d %s\n" % (n, len(wl), " ".join("%g" % w for w in wl))).encode()
+    text = head + "".join("%.4f %.4f %.4f %.4f\n" % tuple(r) for r in ang).encode()
+    rc, out, err = _gortt(["-LAI", "4.0", "-prnprop"], text)
+    assert rc == 0 and err == b""
+    lines = out.split(b"\n")
+    assert lines[0] + b"\n" == head and len(lines) == n + 2
+    first = np.array([[float(t) for t in ln.split()[:4]] for ln in lines[1:n + 1]])
+    assert np.allclose(first, ang, atol=5.1e-7)                      # order kept
+    for env, extra in (({}, ["--gpus", "1"]), ({"GORTT_DEVICES": "0,0"}, []), ({"GORTT_THREADS": "1"}, [])):
+        rc2, out2, err2 = _gortt(["-LAI", "4.0", "-prnprop"] + extra, text, env)
+        assert rc2 == 0 and out2 == out, (env, extra)
+    rc, bout, err = _gortt(["-LAI", "4.0", "-prnprop", "--binary-out"], text, {"GORTT_DEVICES": "0,0"})
+    assert rc == 0
+    rows = np.frombuffer(bout[len(head):], dtype="<f8").reshape(n, 4 + len(wl) + 4)
+    assert np.array_equal(rows[:, :4], ang)
+    vals = np.array([[float(t) for t in ln.replace(b"[", b" ").replace(b"]", b" ").split()] for ln in lines[1:n + 1:97]])
+    assert np.allclose(vals, rows[::97], rtol=0, atol=5.0001e-7, equal_nan=True)
+    # a bad line in the third chunk: every row in front of it is written, then the reference's message
+    bad = text.split(b"\n")
+    bad[7000] = b"12 abc"
+    rc, out3, err3 = _gortt(["-LAI", "4.0", "-prnprop"], b"\n".join(bad))
+    assert rc != 0 and b"error on input, line 7000" in err3
+    assert out3 == b"\n".join(lines[:7000]) + b"\n"
+    # fewer lines than announced: all rows, then the count message (gortt.c:331-336)
+    rc, out4, err4 = _gortt(["-LAI", "4.0", "-prnprop"], b"\n".join(text.split(b"\n")[:5001]) + b"\n")
+    assert rc != 0 and out4 == b"\n".join(lines[:5001]) + b"\n"
+    assert b"expected number of angles (9000) does not match with number found (5000)" in err4
