@@ -130,6 +130,55 @@ def test_gap_probabilities_fuzz_incl_tie_hazards():
     print("gap fuzz: worst relative error over %d canopies: %.2e" % (len(kws), worst))
 
 
+def _fuzz_specs():
+    specs = json.load(open(os.path.join(GOLDEN, "fuzz_canopies.json")))
+    for sp in specs:
+        if "newstyle" in sp["kw"]:
+            sp["kw"]["newstyle"] = tuple(sp["kw"]["newstyle"])
+    return specs
+
+
+def test_gap_probabilities_230_reference_canopies(golden):
+    """The canopies of the fuzz test above against the REAL reference (tests/golden/fuzz_canopies.*, dumped by
+    tools/make_golden.py from `gortt -W` at %.17g): tie geometries, oblate crowns, LAI 0.1 and 9, 150 draws with
+    seed 4242, the first 40 C5 members, old-style flags - in ONE launch.  Two of them are NaN in the reference."""
+    specs = _fuzz_specs()
+    lut = golden("fuzz_canopies.npz")["lut"]
+    members = [api.make_canopy(**sp["kw"]) for sp in specs]
+    api.gap_probabilities(members)
+    worst, n_nan = 0.0, 0
+    for sp, m, tab in zip(specs, members, lut):
+        e = max(err(np.array(m.p_n0)[:90], tab[:90, 0]), err(np.array(m.epgap)[:90], tab[:90, 1]),
+                err(np.array([m.k_open, m.k_openep]), tab[90]))
+        assert e <= REGRESSION, (sp, e)
+        worst = max(worst, e)
+        n_nan += int(np.isnan(tab).any())
+    assert n_nan == 2
+    print("gap kernel vs reference, %d canopies: worst %.1e" % (len(specs), worst))
+
+
+def test_brdf_rows_of_reference_fuzz_canopies(eng, golden):
+    """BRDF rows of 24 of them, from the reference: hot-spot lines, table nodes, near-horizon view and sun.  The gap
+    tables are the kernel's own (so this is the whole chain); the hot spot at 89 deg is ill-conditioned in the
+    reference itself and held to 1e-6, everything else to 1e-9."""
+    specs = _fuzz_specs()
+    g = golden("fuzz_canopies.npz")
+    wl, lines = g["brdf_wl"], g["brdf_lines"]
+    rs, rl, tl = api.spectra(wl)
+    eng.set_spectra(rs, rl, tl)
+    ill = np.zeros(len(lines), bool)
+    ill[24] = True
+    ill[:8] |= np.abs(lines[:8, 0]) > 80                     # exact hot spot close to the horizon
+    for k, i in enumerate(g["brdf_pick"]):
+        eng.set_canopy(gpu_canopy(**specs[int(i)]["kw"]))
+        r, sc, K = eng.rsurf_stream(lines, want_scomp=True)
+        ok = ~ill
+        assert err(r[ok], g["brdf_rsurf"][k][ok]) <= REGRESSION, specs[int(i)]
+        assert err(sc[ok], g["brdf_scomp"][k][ok]) <= REGRESSION
+        assert err_K(K, g["brdf_K"][k]) <= REGRESSION
+        assert err(r[ill], g["brdf_rsurf"][k][ill]) <= 1e-6
+
+
 # ---------------------------------------------------------------- BRDF stream
 def test_c2_principal_plane(eng, golden):
     g = golden("c2_principal_plane.npz")

@@ -235,3 +235,58 @@ def test_cli_full_precision_rows(golden):
           prnspec=True)
     check("horizon", lai4, {}, prnprop=True)
     check("azimuth_wrap", lai4, {}, prnprop=True)
+
+
+# ------------------------------------------------------------------ fuzz canopies (230, from the real reference)
+FUZZ = json.load(open(os.path.join(GOLDEN, "fuzz_canopies.json")))
+
+
+def fuzz_kw(spec):
+    kw = dict(spec["kw"])
+    if "newstyle" in kw:
+        kw["newstyle"] = tuple(kw["newstyle"])
+    return kw
+
+
+def test_fuzz_canopies_gap_tables(golden):
+    """230 canopies dumped from the REAL reference (`gortt -W` at %.17g): exact-tie geometries (-BR 1/2/3), oblate
+    crowns, LAI 0.1 and 9, 150 draws of the GPU fuzz test, the first 40 C5 members, old-style flags.  Two of
+    them (HB = BR = 1) give NaN in the reference; relerr() demands the same NaN pattern."""
+    lut = golden("fuzz_canopies.npz")["lut"]
+    assert lut.shape == (len(FUZZ), 91, 2) and len(FUZZ) >= 200
+    worst = 0.0
+    for spec, tab in zip(FUZZ, lut):
+        c = O.make_canopy(**fuzz_kw(spec))
+        pn0, ep, ko, kep = O.gap_tables(c)
+        e = max(relerr(pn0[:90], tab[:90, 0]), relerr(ep[:90], tab[:90, 1]), relerr(np.array([ko, kep]), tab[90]))
+        assert e <= TOL, (spec, e)
+        worst = max(worst, e)
+    print("oracle vs reference, %d fuzz canopies: worst %.1e" % (len(FUZZ), worst))
+
+
+def test_fuzz_canopies_brdf_rows(golden):
+    """BRDF rows (rsurf, C/G/T/Z, K) of 24 of those canopies from the reference: exact hot-spot lines, table nodes,
+    view and sun near the horizon, the hot spot AT 89 deg."""
+    g = golden("fuzz_canopies.npz")
+    wl, lines = g["brdf_wl"], g["brdf_lines"]
+    rs, rl, tl = O.spectra(wl)
+    for k, i in enumerate(g["brdf_pick"]):
+        c = O.make_canopy(**fuzz_kw(FUZZ[int(i)]))
+        r, sc, K = O.rsurf_stream(c, lines, rs, rl, tl, want_scomp=True)
+        assert relerr(r, g["brdf_rsurf"][k]) <= TOL, FUZZ[int(i)]
+        assert relerr(sc.reshape(g["brdf_scomp"][k].shape), g["brdf_scomp"][k]) <= TOL
+        assert relerr(K, g["brdf_K"][k], floor=1.0) <= TOL
+
+
+def test_reference_branch_coverage_table_is_complete():
+    """tests/golden/ref_branch_coverage.md (tools/ref_coverage.py, gcov build of the reference): every branch outcome
+    of gortt_get_s's thresholds and of gortt_vol and its helpers is taken by at least one reference-generated canopy,
+    so the oracle is pinned on every piece of the piecewise geometry it restates."""
+    import re
+    text = open(os.path.join(GOLDEN, "ref_branch_coverage.md")).read()
+    m = re.search(r"\*\*(\d+) of (\d+) branch outcomes", text)
+    assert m and m.group(1) == m.group(2) and int(m.group(2)) >= 30
+    assert "never reached: none" in text
+    for line in (582, 589, 679, 683, 690, 697, 725, 736, 752):
+        row = re.search(r"^\| %d \| (\d+) \| (\d+) / (\d+) \|" % line, text, re.M)
+        assert row and int(row.group(2)) > 0 and int(row.group(3)) > 0, line

@@ -326,16 +326,98 @@ def c5_goldens():
     np.savez_compressed(os.path.join(GOLD, "c5_members.npz"), **store)
 
 
+# ------------------------------------------------- fuzz canopies (task 2)
+def fuzz_canopy_specs():
+    """The canopies the GPU fuzz tests draw (tests/test_gpu_parity.py), so that those tests compare with the
+    REFERENCE and not only with our restatement: the exact-tie geometries (-BR 1/2/3: s/ds + 0.5 an exact integer
+    in the path-length histogram, gortt_pn_kopen.c:134-139), oblate crowns, very sparse / very dense stands, the
+    first 150 draws of test_gap_probabilities_fuzz_incl_tie_hazards (seed 4242), the first 40 C5 members."""
+    specs = []
+
+    def ns(hb, br, pcc, lai, tag):
+        hb, br, pcc, lai = (float(np.float32(x)) for x in (hb, br, pcc, lai))
+        specs.append({"tag": tag, "flags": ["-HB", repr(hb), "-BR", repr(br), "-PCC", repr(pcc), "-LAI", repr(lai)],
+                      "kw": {"newstyle": [hb, br, pcc], "lai": lai}})
+    for br in (1.0, 2.0, 3.0):
+        for hb in (1.0, 2.0, 2.5):
+            for pcc in (0.3, 0.6):
+                ns(hb, br, pcc, 3.0, "tie")
+    rng = np.random.default_rng(4242)
+    for _ in range(150):
+        ns(rng.uniform(0.5, 4), rng.uniform(0.4, 4), rng.uniform(0.05, 0.95), rng.uniform(0.1, 9), "fuzz4242")
+    for br in (0.4, 0.5, 0.65, 0.8, 0.95):                        # oblate crowns, b/r < 1
+        for pcc in (0.2, 0.7):
+            ns(1.5, br, pcc, 2.5, "oblate")
+    for lai in (0.1, 9.0):
+        for br in (1.0, 2.5):
+            for pcc in (0.1, 0.9):
+                ns(2.0, br, pcc, lai, "lai_extreme")
+    for m in c5_members(40):
+        ns(m["hb"], m["br"], m["pcc"], m["lai"], "c5")
+    old = [dict(favd=0.3, h1=1.0, h2=4.0, lam=0.9, r=0.5, b=0.5), dict(favd=1.2, h1=6.0, h2=20.0, lam=0.05, r=2.5, b=7.0),
+           dict(favd=0.8, h1=2.0, h2=2.5, lam=0.2, r=1.0, b=3.0), dict(favd=0.05, h1=4.0, h2=12.0, lam=0.4, r=0.9, b=0.6)]
+    for kw in old:
+        specs.append({"tag": "oldstyle", "kw": kw,
+                      "flags": ["-favd", repr(kw["favd"]), "-h1", repr(kw["h1"]), "-h2", repr(kw["h2"]), "-lambda", repr(kw["lam"]),
+                                "-r", repr(kw["r"]), "-b", repr(kw["b"])]})
+    return specs
+
+
+def fuzz_goldens():
+    pool = ThreadPoolExecutor(8)
+    specs = fuzz_canopy_specs()
+
+    def lut(spec):
+        rc, out, err = run(GORTT_FP, spec["flags"] + ["-W"], "")
+        if rc != 0:
+            return None
+        rows = [ln.split() for ln in out.strip().split("\n")]
+        if len(rows) != 91 or rows[90][0] != "-1":
+            return None
+        # NaN rows are kept: HB = BR = 1 gives `-nan` in epgap(30 deg) and KOpenEP in the reference itself, and
+        # the NaN pattern is part of what the restatement and the kernel have to reproduce
+        return np.array([[float(r[1]), float(r[2])] for r in rows])
+    tabs = list(pool.map(lut, specs))
+    keep = [i for i, t in enumerate(tabs) if t is not None]
+    print("fuzz canopies: %d of %d gave a 91-row -W table, %d of them with NaN entries"
+          % (len(keep), len(specs), sum(int(np.isnan(tabs[i]).any()) for i in keep)))
+    specs = [specs[i] for i in keep]
+    tab = np.array([tabs[i] for i in keep])                         # [n][91][2]: rows 0..89 p_n0, epgap; row 90 k_open, k_openep
+    json.dump(specs, open(os.path.join(GOLD, "fuzz_canopies.json"), "w"), indent=0)
+
+    # BRDF rows of 24 of them (every tag represented): random lines, exact hot-spot lines, table nodes, near-horizon
+    rng = np.random.default_rng(2024)
+    pick = sorted(set([0, 5, 11, 17] + list(range(18, len(specs), max(1, (len(specs) - 18) // 20)))))[:24]
+    wl = [450.0, 555.5, 670.0, 865.0, 1240.25, 1650.0, 2130.0]
+    lines = np.stack([rng.uniform(-89.9, 89.9, 48), rng.uniform(-400, 400, 48), rng.uniform(-89.9, 89.9, 48),
+                      rng.uniform(-400, 400, 48)], 1)
+    lines[:8, 0] = lines[:8, 2]; lines[:8, 1] = lines[:8, 3]           # exact hot spot
+    lines[8:14, [0, 2]] = np.round(lines[8:14, [0, 2]])                # integer zeniths (table nodes)
+    lines[14:20, 0] = rng.uniform(88.5, 89.99, 6)                     # view near the horizon
+    lines[20:24, 2] = rng.uniform(88.0, 89.9, 4)                      # sun near the horizon
+    lines[24] = [89.0, 10.0, 89.0, 10.0]                              # hot spot at the horizon (ill-conditioned in the reference)
+    lines[25] = [0.0, 0.0, 0.0, 0.0]
+
+    def rows(i):
+        return fp_stream(specs[i]["flags"], lines.tolist(), wl, prnprop=True, prnspec=True)
+    res = list(pool.map(rows, pick))
+    np.savez_compressed(os.path.join(GOLD, "fuzz_canopies.npz"), lut=tab, brdf_pick=np.array(pick), brdf_lines=lines,
+                        brdf_wl=np.array(wl), brdf_rsurf=np.array([r["rsurf"] for r in res]),
+                        brdf_K=np.array([r["K"] for r in res]), brdf_scomp=np.array([r["scomp"] for r in res]))
+    print("fuzz goldens done: %d canopies, %d with BRDF rows" % (len(specs), len(pick)))
+
+
 def main():
     for b in (GORTT, GORTT_FP):
         if not os.path.exists(b):
             sys.exit("missing %s: run `make -C oracle ref` first" % b)
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["cli", "func", "config", "c5"]
+    what = sys.argv[1:] or ["cli", "func", "config", "c5", "fuzz"]
     if "cli" in what: cli_cases()
     if "func" in what: canopies_and_spectra()
     if "config" in what: config_goldens()
     if "c5" in what: c5_goldens()
+    if "fuzz" in what: fuzz_goldens()
 
 
 if __name__ == "__main__":
