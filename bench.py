@@ -85,6 +85,7 @@ def cpu_baseline(wl, budget_s=20.0, force_port=False, procs=1):
         except Exception as ex:                      # fall through to the port
             print("cpu_baseline: reference run failed (%s); using the oracle port" % ex, file=sys.stderr)
     from oracle import oracle as O
+    O.AUTO_BUILD = False
     c = O.make_canopy(lai=4.0)
     rs, rl, tl = O.spectra(wl)
     rng = np.random.default_rng(1)
@@ -99,6 +100,69 @@ def cpu_baseline(wl, budget_s=20.0, force_port=False, procs=1):
                       % (n, len(wl), dt, model)}
 
 
+def _ref_grid_worker(args):
+    """One process of cpu_baseline_grid: the reference's gortt_rsurf (oracle/_ref/libgortt_ref.so, built from
+    /root/reference by oracle/Makefile) on a share of the metric grid's nodes, all 2101 bands, no text I/O."""
+    so, nodes, wl = args
+    import ctypes as C
+    L = C.CDLL(so)
+    D = C.c_double
+    argv = (C.c_char_p * 3)(b"gortt", b"-LAI", b"4.0")
+    L.refshim_canopy(3, argv)
+    nw = len(wl)
+    w = np.ascontiguousarray(wl, dtype=np.float64)
+    rs, rl, tl = np.zeros(nw), np.zeros(nw), np.zeros(nw)
+    pd = lambda a: a.ctypes.data_as(C.POINTER(D))
+    L.refshim_spectra(pd(w), nw, pd(rs), pd(rl), pd(tl))
+    L.refshim_rsurf.argtypes = [D] * 5 + [C.POINTER(D)] * 4
+    out, sc, K, pr = np.zeros(nw), np.zeros(4 * nw), np.zeros(4), np.zeros(4)
+    po, ps, pk, pp = pd(out), pd(sc), pd(K), pd(pr)
+    rad = np.pi / 180.0
+    t0 = time.perf_counter()
+    acc = 0.0
+    for isza, ivza, iphi in nodes:
+        # the normalisation of main() for the line "vza phi sza 0" (gortt.c:240-279)
+        vza, vaa, sza, saa = ivza * rad, iphi * rad, isza * rad, 0.0
+        raa = saa - vaa
+        raa = abs(raa - 2 * np.pi * int(0.5 + raa / (2 * np.pi)))
+        L.refshim_rsurf(vza, vaa, sza, saa, raa, po, ps, pk, pp)
+        acc += out[0]
+    return time.perf_counter() - t0, len(nodes), acc
+
+
+def cpu_baseline_grid(wl, procs, budget_s=12.0):
+    """The SAME workload shape as the GPU line, on the host CPU, through the reference itself: random nodes of the
+    metric grid x all 2101 bands via gortt_rsurf (no LUT file, no text), one process per core.  None where the
+    reference build did not travel (oracle/_ref is built in the build container only)."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libgortt_ref.so")
+    if not os.path.exists(so):
+        return None
+    import multiprocessing as mp
+    rng = np.random.default_rng(2)
+    try:
+        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+
+    def draw(n):
+        return [tuple(int(x) for x in r) for r in np.stack([rng.integers(0, 90, n), rng.integers(0, 90, n), rng.integers(0, 361, n)], 1)]
+    ctx = mp.get_context("spawn")                      # never fork a process that has initialised the GPU
+    with ctx.Pool(procs) as pool:
+        dt, n, _ = pool.apply(_ref_grid_worker, ((so, draw(60), wl),))
+        per_node = dt / n
+        n_each = int(min(max(budget_s / per_node, 100), 20000))
+        t0 = time.perf_counter()
+        res = pool.map(_ref_grid_worker, [(so, draw(n_each), wl) for _ in range(procs)])
+        wall = time.perf_counter() - t0
+    total = sum(r[1] for r in res) * len(wl)
+    busy = max(r[0] for r in res)
+    return {"value": total / busy, "unit": "samples/s", "cores": procs, "kind": "reference",
+            "sample": "reference gortt_rsurf (oracle/_ref/libgortt_ref.so = /root/reference compiled -O3; direct gap "
+                      "probabilities, no text I/O): %d processes x %d random nodes of the metric grid x %d bands, slowest "
+                      "process %.1f s (wall %.1f s incl. each process's 0.4 s gap-probability setup); cpu: %s"
+                      % (procs, n_each, len(wl), busy, wall, model)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +171,9 @@ def main():
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")
+    ap.add_argument("--sustain-s", type=float, default=3.0,
+                    help="after the timed region, keep stepping for this many seconds and report the mean step ('sustained'); 0 = off")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: every rank uses cuda:0, process group gloo (not a measurement)")
     ap.add_argument("--gather", action="store_true",
@@ -149,14 +216,21 @@ def main():
     eng.set_spectra(rs, rl, tl)
     grid = api.hemisphere_grid(nsza=args.nsza)
     rows = grid.nsza * grid.nvza
-    from gort_amd.shard import all_gather_lut, row_slab
+    from gort_amd.shard import all_gather_in_place, empty_gatherable, my_window, row_slab
     r0, r1 = row_slab(rank, world, rows)
     my_samples = (r1 - r0) * grid.nphi * nw
     total_samples = rows * grid.nphi * nw
-    lut = torch.empty(((r1 - r0) * grid.nphi, nw), dtype=torch.float64, device="cuda")
+    if args.gather and world > 1:
+        # the whole LUT once (+ < world rows of padding): this rank computes straight into its window of it and
+        # the all-gather lands in place - no receive buffer, no second copy (gort_amd/shard.py)
+        full_padded = empty_gatherable(rows, grid.nphi * nw, world, torch.float64, "cuda")
+        lut = my_window(full_padded, rank, world, rows).view((r1 - r0) * grid.nphi, nw)
+    else:
+        lut = torch.empty(((r1 - r0) * grid.nphi, nw), dtype=torch.float64, device="cuda")
 
     def step():
-        eng.rsurf_grid_dev(grid, r0, r1, lut)
+        if r1 > r0:
+            eng.rsurf_grid_dev(grid, r0, r1, lut)
 
     for _ in range(args.warmup):
         step()
@@ -172,6 +246,28 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = eng.last_expand_ms()          # mean duration of the LUT expansion kernel, HIP events on its stream
+    if kernel_ms < 0:
+        kernel_ms = 0.0                       # a rank without rows
+
+    # ---- sustained rate: the same step back to back for >= --sustain-s seconds (clocks and power settled) ----
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-4)) + 1)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        eng.synchronize()
+        torch.cuda.synchronize()
+        barrier()
+        sus_dt = time.perf_counter() - ts
+        sus_kernel = eng.last_expand_ms()
+        if world > 1:
+            t = torch.tensor([sus_dt, max(sus_kernel, 0.0)], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sus_dt, sus_kernel = float(t[0]), float(t[1])
+        sustained = {"seconds": sus_dt, "steps": n_sus, "ms_per_step": sus_dt / n_sus * 1e3,
+                     "value": total_samples * n_sus / sus_dt, "kernel_ms": sus_kernel}
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -186,16 +282,17 @@ def main():
     if args.gather and world > 1:
         torch.cuda.synchronize(); barrier()
         tg = time.perf_counter()
-        full = all_gather_lut(lut.view(r1 - r0, grid.nphi * nw), rows)
+        full = all_gather_in_place(full_padded, rows)
         torch.cuda.synchronize(); barrier()
         allgather_ms = (time.perf_counter() - tg) * 1e3
         del full
 
     # ---- parity spot check (outside the timed region): sampled rows vs the CPU oracle ----
     parity = None
-    if rank == 0:
+    if rank == 0 and not args.no_parity:
         try:
             from oracle import oracle as O
+            O.AUTO_BUILD = False                  # the prebuilt checker or nothing: no compiler runs in a bench process
             oc = O.make_canopy(lai=4.0)
             ors, orl, otl = O.spectra(wl)
             rng = np.random.default_rng(5)
@@ -216,15 +313,19 @@ def main():
         value = total_samples * args.steps / dt
         per_launch_bytes = my_samples * BYTES_PER_SAMPLE
         achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else None
-        # HBM bytes per launch of the dominant kernel from the PMC counters: a live bench run cannot collect
-        # them (rocprofv3 --pmc needs its own passes), so the number of the last committed PMC run is quoted
-        # when it was taken on this very workload; otherwise null.
-        traffic, traffic_src = (args.traffic_gb * 1e9, "--traffic-gb") if args.traffic_gb else (None, None)
+        # HBM bytes per launch of the dominant kernel come from PMC counters, which a live bench run cannot collect
+        # (rocprofv3 --pmc needs passes of its own): `traffic` is a measurement of THIS code only when it is handed in
+        # with --traffic-gb by the profiling script; otherwise it is null and the last committed PMC figure is quoted
+        # separately, labelled as replayed, with the commit it was taken at.
+        traffic, traffic_src = (args.traffic_gb * 1e9, "measured: --traffic-gb from a rocprofv3 --pmc pass of this commit") \
+            if args.traffic_gb else (None, None)
+        replayed = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if traffic is None and os.path.exists(pmc_file):
+        if os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             if pmc.get("workload") == "%dx%dx%dx%d" % (grid.nsza, grid.nvza, grid.nphi, nw) and pmc.get("n_gpus") == world:
-                traffic, traffic_src = pmc["traffic_bytes"], "profiles/pmc_latest.json: " + pmc["note"]
+                replayed = {"traffic": pmc["traffic_bytes"], "label": "replayed", "commit": pmc.get("commit"),
+                            "note": pmc["note"]}
         out = {
             "metric": "BRDF samples/sec ((theta_v,theta_s,dphi,lambda) tuples)",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -239,7 +340,8 @@ def main():
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
                          "xcd_mapping": eng.xcd_mapping(), "xcd_weights_32nds": eng.xcd_weights()[0],
                          "bare_store_pattern_gbs_equal_xcd_shares": eng.store_pattern_gbs(),
-                         "traffic": traffic, "traffic_source": traffic_src},
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_replayed": replayed},
+            "sustained": sustained,
             "parity": parity,
         }
         if allgather_ms is not None:
@@ -247,16 +349,27 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # all host cores of the box's share (16 per GPU on this pool), one reference process per core
             ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
-            out["cpu_baseline"] = cpu_baseline(wl, budget_s=15.0, procs=ncores)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-            if out["cpu_baseline"]["kind"] == "reference":
-                out["cpu_baseline_1core"] = cpu_baseline(wl, budget_s=8.0, procs=1)
-                # additionally: our own hoisted scalar-C restatement (no text I/O), the strongest 1-core CPU number we have
-                out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
+            # (1) the SAME workload shape through the reference's own gortt_rsurf (grid nodes x 2101 bands, no text)
+            same = cpu_baseline_grid(wl, ncores, budget_s=12.0)
+            # (2) the reference as a user runs it: the CLI with a -P LUT, random lines x 180 bands, text to /dev/null
+            cli = cpu_baseline(wl, budget_s=10.0, procs=ncores)
+            out["cpu_baseline"] = same if same is not None else cli
+            if same is not None:
+                out["cpu_baseline_cli"] = cli
+            # (3) our own hoisted scalar-C restatement (no text I/O), one core: the strongest per-core CPU number we have
+            out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
+            out["gpu_over_cpu"] = {"vs_cpu_baseline_same_shape_all_cores": value / out["cpu_baseline"]["value"],
+                                   "vs_port_one_core": value / out["cpu_baseline_port"]["value"]}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+    # a headline number without its parity check is not a result: fail the run
+    if rank == 0 and not args.no_parity:
+        bad = parity is None or "error" in parity or not parity["nan_pattern_equal"] or not parity["max_rel_err"] <= parity["tolerance"]
+        if bad:
+            print("bench.py: parity check failed or missing: %r" % (parity,), file=sys.stderr)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

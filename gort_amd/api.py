@@ -480,7 +480,7 @@ class Engine:
         """'static' where workgroup dispatch was probed to be round-robin over the XCDs, else 'slots'."""
         m = lib().gort_engine_xcd_mapping(self.h)
         if m < 0:
-            _check(-m)
+            _check(m)
         return {1: "static", 2: "slots"}[m]
 
     def energy_stream(self, angles_deg):

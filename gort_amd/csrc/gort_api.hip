@@ -34,7 +34,13 @@ struct DevBuf {
         if (p) GORT_HIP(hipFree(p));
         p = nullptr;
         cap = 0;
-        GORT_HIP(hipMalloc(&p, bytes));
+        const hipError_t err = hipMalloc(&p, bytes);
+        if (err != hipSuccess) {
+            p = nullptr;
+            (void)hipGetLastError();
+            return fail(err == hipErrorOutOfMemory ? GORT_ENOMEM : GORT_ENODEVICE, "hipMalloc of %zu bytes: %s", bytes,
+                        hipGetErrorString(err));
+        }
         cap = bytes;
         return GORT_OK;
     }
@@ -68,6 +74,10 @@ struct gort_engine {
     hipEvent_t ev_verdict = nullptr;
     bool group_verdict_pending = false;
     int group_skip = 0;                  // calls left before the grouped form is tried again
+    char *stage = nullptr;               // pinned staging of the setters' small uploads (stage_begin / stage_h2d)
+    size_t stage_cap = 0, stage_off = 0;
+    hipEvent_t ev_stage = nullptr;
+    bool stage_busy = false;
     gort_pipe *hpipe = nullptr;          // pinned staging of the host-buffer entry points, created on first use
     int hpipe_nw = 0;
     unsigned hpipe_flags = 0;
@@ -192,7 +202,8 @@ extern "C" int gort_engine_create(gort_engine **out)
     if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
         int w[8];
         if (sscanf(v, "%d,%d,%d,%d,%d,%d,%d,%d", w, w + 1, w + 2, w + 3, w + 4, w + 5, w + 6, w + 7) == 8) {
-            for (int x = 0; x < 8; ++x) e->xcd_weights[x] = w[x];
+            // the range gort_engine_set_xcd_weights accepts: what gort_engine_xcd_weights reports is what is used
+            for (int x = 0; x < 8; ++x) e->xcd_weights[x] = w[x] < 8 ? 8 : (w[x] > 32 ? 32 : w[x]);
             e->xcd_calibrated = true;
         }
     }
@@ -219,6 +230,8 @@ extern "C" void gort_engine_destroy(gort_engine *e)
     for (hipEvent_t ev : e->ev_stream) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_sgeo) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_verdict) (void)hipEventDestroy(e->ev_verdict);
+    if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
+    if (e->stage) (void)hipHostFree(e->stage);
     if (e->group_verdict) (void)hipHostFree(e->group_verdict);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -248,7 +261,7 @@ extern "C" int gort_engine_xcd_mapping(gort_engine *e)
     if (!e) return fail(GORT_EINVAL, "gort_engine_xcd_mapping: null engine");
     int *slots = nullptr;
     const int rc = xcd_slots_for_launch(e, &slots);
-    if (rc) return -rc;
+    if (rc) return rc;                       // GORT_E* codes are negative already
     return slots ? 2 : 1;
 }
 
@@ -306,12 +319,53 @@ static int refresh_lambda_table(gort_engine *e)
     return rc;
 }
 
+// Small host -> device uploads of the setters go through a pinned staging buffer and the engine's stream: ordered
+// behind whatever still reads the previous contents, no host wait, and none of the stalls of pageable hipMemcpy
+// (15-25 ms now and then for the 3 MB of a 1000-member ensemble).  stage_begin() once per setter call (waits only
+// if the previous call's uploads are still in flight), stage_h2d() per piece, stage_end() at the end.
+static int stage_begin(gort_engine *e, size_t total_bytes)
+{
+    if (!e->ev_stage) GORT_HIP(hipEventCreateWithFlags(&e->ev_stage, hipEventDisableTiming));
+    if (e->stage_busy) {
+        GORT_HIP(hipEventSynchronize(e->ev_stage));
+        e->stage_busy = false;
+    }
+    total_bytes += 4096;
+    if (total_bytes > e->stage_cap) {
+        if (e->stage) GORT_HIP(hipHostFree(e->stage));
+        e->stage = nullptr;
+        e->stage_cap = 0;
+        if (hipHostMalloc((void **)&e->stage, total_bytes, hipHostMallocDefault) != hipSuccess)
+            return fail(GORT_ENOMEM, "cannot pin %zu bytes of staging memory", total_bytes);
+        e->stage_cap = total_bytes;
+    }
+    e->stage_off = 0;
+    return GORT_OK;
+}
+
+static int stage_h2d(gort_engine *e, void *dst_dev, const void *src, size_t bytes)
+{
+    if (e->stage_off + bytes > e->stage_cap) return fail(GORT_EINVAL, "staging buffer overrun");
+    char *h = e->stage + e->stage_off;
+    std::memcpy(h, src, bytes);
+    e->stage_off += (bytes + 255) & ~(size_t)255;
+    GORT_HIP(hipMemcpyAsync(dst_dev, h, bytes, hipMemcpyHostToDevice, e->stream));
+    return GORT_OK;
+}
+
+static int stage_end(gort_engine *e)
+{
+    GORT_HIP(hipEventRecord(e->ev_stage, e->stream));
+    e->stage_busy = true;
+    return GORT_OK;
+}
+
+// caller: stage_begin() with room for n canopies, stage_end() afterwards
 static int upload_canopies(gort_engine *e, const gort_canopy *members, int n, int compute_gaps)
 {
     int rc = e->canopy.reserve(sizeof(gort_canopy) * (size_t)n);
     if (rc) return rc;
-    GORT_HIP(hipStreamSynchronize(e->stream));         // the stream may still be reading the previous records
-    GORT_HIP(hipMemcpy(e->canopy.p, members, sizeof(gort_canopy) * (size_t)n, hipMemcpyHostToDevice));
+    if ((rc = stage_h2d(e, e->canopy.p, members, sizeof(gort_canopy) * (size_t)n))) return rc;
     if (compute_gaps && (rc = launch_gap_probabilities(e->canopy.as<gort_canopy>(), n, e->stream))) return rc;
     if (n != e->n_members) e->have_spectra = false;    // spectra are per member
     e->n_members = n;
@@ -322,8 +376,10 @@ static int upload_canopies(gort_engine *e, const gort_canopy *members, int n, in
 extern "C" int gort_engine_set_canopy(gort_engine *e, const gort_canopy *c)
 {
     if (!e || !c) return fail(GORT_EINVAL, "gort_engine_set_canopy: bad argument");
-    int rc = upload_canopies(e, c, 1, 0);
+    int rc = stage_begin(e, sizeof(gort_canopy));
     if (rc) return rc;
+    if ((rc = upload_canopies(e, c, 1, 0))) return rc;
+    if ((rc = stage_end(e))) return rc;
     return refresh_lambda_table(e);
 }
 
@@ -335,12 +391,12 @@ extern "C" int gort_engine_set_spectra(gort_engine *e, int nw, const double *rso
         return fail(GORT_EINVAL, "gort_engine_set_spectra: engine holds %d members; use gort_engine_set_members", e->n_members);
     int rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw);
     if (rc) return rc;
-    GORT_HIP(hipStreamSynchronize(e->stream));
     double *sp = e->spectra.as<double>();
     const size_t b = sizeof(double) * (size_t)nw;
-    GORT_HIP(hipMemcpy(sp, rsoil, b, hipMemcpyHostToDevice));
-    GORT_HIP(hipMemcpy(sp + nw, rleaf, b, hipMemcpyHostToDevice));
-    GORT_HIP(hipMemcpy(sp + 2 * nw, tleaf, b, hipMemcpyHostToDevice));
+    if ((rc = stage_begin(e, 3 * (b + 256)))) return rc;
+    if ((rc = stage_h2d(e, sp, rsoil, b)) || (rc = stage_h2d(e, sp + nw, rleaf, b)) || (rc = stage_h2d(e, sp + 2 * nw, tleaf, b)))
+        return rc;
+    if ((rc = stage_end(e))) return rc;
     e->nw = nw;
     e->have_spectra = true;
     return refresh_lambda_table(e);
@@ -353,10 +409,13 @@ extern "C" int gort_engine_set_members(gort_engine *e, const gort_canopy *member
 {
     if (!e || !members || n_members <= 0 || n_members > 65535 || nw <= 0 || !spectra)
         return fail(GORT_EINVAL, "gort_engine_set_members: bad argument");
-    int rc = upload_canopies(e, members, n_members, compute_gaps);
+    int rc = stage_begin(e, sizeof(gort_canopy) * (size_t)n_members);
     if (rc) return rc;
+    if ((rc = upload_canopies(e, members, n_members, compute_gaps))) return rc;
+    if ((rc = stage_end(e))) return rc;
     const size_t bytes = sizeof(double) * 3 * (size_t)nw * (size_t)n_members;
     if ((rc = e->spectra.reserve(bytes))) return rc;
+    GORT_HIP(hipStreamSynchronize(e->stream));         // large and pageable: a plain copy, behind everything queued
     GORT_HIP(hipMemcpy(e->spectra.p, spectra, bytes, hipMemcpyHostToDevice));
     e->nw = nw;
     e->have_spectra = true;
@@ -389,14 +448,16 @@ extern "C" int gort_engine_set_members_leaf(gort_engine *e, const gort_canopy *m
     for (int i = 0; i < nw; ++i)
         if (!(wl_nm[i] >= 400 && wl_nm[i] <= 2500))
             return fail(GORT_ERANGE, "gortt_price_soil: wavlength out of range (400-2500)");
-    int rc = upload_canopies(e, members, n_members, compute_gaps);
+    int rc = stage_begin(e, (sizeof(gort_canopy) + sizeof(gort_leaf_soil)) * (size_t)n_members + sizeof(double) * (size_t)nw + 1024);
     if (rc) return rc;
+    if ((rc = upload_canopies(e, members, n_members, compute_gaps))) return rc;
     if ((rc = ensure_spectral_tables(e))) return rc;
     if ((rc = e->leaf.reserve(sizeof(gort_leaf_soil) * (size_t)n_members))) return rc;
     if ((rc = e->wl.reserve(sizeof(double) * (size_t)nw))) return rc;
     if ((rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw * (size_t)n_members))) return rc;
-    GORT_HIP(hipMemcpy(e->leaf.p, leaf, sizeof(gort_leaf_soil) * (size_t)n_members, hipMemcpyHostToDevice));
-    GORT_HIP(hipMemcpy(e->wl.p, wl_nm, sizeof(double) * (size_t)nw, hipMemcpyHostToDevice));
+    if ((rc = stage_h2d(e, e->leaf.p, leaf, sizeof(gort_leaf_soil) * (size_t)n_members))) return rc;
+    if ((rc = stage_h2d(e, e->wl.p, wl_nm, sizeof(double) * (size_t)nw))) return rc;
+    if ((rc = stage_end(e))) return rc;
     rc = launch_member_spectra(e->leaf.as<gort_leaf_soil>(), n_members, nw, e->wl.as<double>(),
                                e->tab_coef.as<float>(), e->tab_t12.as<double>(), e->tab_talf.as<double>(),
                                e->tab_eof.as<double>(), e->spectra.as<double>(), e->stream);

@@ -1250,8 +1250,9 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
             // the rate of the bare store pattern with equal shares, first start to last end (wall clock ticks)
             unsigned long long t1 = 0;
             for (int x = 0; x < 8; ++x) if (host[8 + x] > t1) t1 = host[8 + x];
-            int khz = 0;
-            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, 0) == hipSuccess && khz > 0 && t1 > t0)
+            int khz = 0, dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0 && t1 > t0)
                 *pattern_gbs = (double)chunks * 1024.0 / ((double)(t1 - t0) / khz * 1e-3) / 1e9;
         }
         for (int x = 0; x < 8; ++x) {

@@ -10,9 +10,11 @@ an ensemble of perturbed members.  Parity is parity of the forward runs (tests/t
 import numpy as np
 
 from . import api
+from .shard import all_gather_lut, row_slab
 
 #: state vector layout; the first four are the `gortt` new-style crown flags (gortt.c:1086-1131), the rest
-#: PROSPECT-D leaf parameters (prospect_DB.f90) and the first Price soil coefficient (price_soil.c)
+#: PROSPECT-D leaf parameters (PROSPECT-D/prospect_DB.f90:72-191) and the first Price soil coefficient
+#: (gortt_price_soil, gortt.c:1286-1328)
 STATE = ("HB", "BR", "PCC", "LAI", "N", "Cab", "Car", "Cw", "Cm", "rsl1")
 DEFAULT = dict(HB=2.0, BR=2.0, PCC=0.6, LAI=4.0, N=1.2, Cab=30.0, Car=10.0, Cw=0.015, Cm=0.009, rsl1=0.2)
 
@@ -88,3 +90,87 @@ def jacobian(wavelengths, state, angles_deg, rel_step=1e-3, params=STATE, engine
         ens.close()
     J = np.stack([(r[2 + 2 * k] - r[1 + 2 * k]) / (2.0 * steps[k]) for k in range(len(params))])
     return r[0], J, np.array(steps)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5
+def draw_c5_members(n, seed=12345):
+    """The ensemble of BASELINE.json config 5 as SURVEY.md 8(d) fixes it: numpy default_rng(seed); per member
+    HB~U(1,3), BR~U(1,3.5), PCC~U(0.2,0.8), LAI~U(0.5,6) (through float32, as the CLI parses them), Cab~U(10,60),
+    Cw~U(0.005,0.03), Cm~U(0.002,0.015), N~U(1,2.5), rsl1~U(0.05,0.4).  Returns (canopies, leaf_soil records)."""
+    rng = np.random.default_rng(seed)
+    canopies, leaf = [], []
+    for _ in range(n):
+        hb, br, pcc, lai = rng.uniform(1, 3), rng.uniform(1, 3.5), rng.uniform(0.2, 0.8), rng.uniform(0.5, 6)
+        cab, cw, cm = rng.uniform(10, 60), rng.uniform(0.005, 0.03), rng.uniform(0.002, 0.015)
+        N, rsl1 = rng.uniform(1, 2.5), rng.uniform(0.05, 0.4)
+        canopies.append(api.make_canopy(newstyle=(f32(hb), f32(br), f32(pcc)), lai=f32(lai)))
+        leaf.append(api.leaf_soil(prospect=dict(N=N, Cab=cab, Cw=cw, Cm=cm), rsl=(rsl1, 0.1, 0.03726, -0.002426)))
+    return canopies, leaf
+
+
+def c5_grid():
+    """Per member: sun zenith 30 deg, view zenith 0..90, relative azimuth 0..360 in integer degrees (32 851 tuples)."""
+    g = api.Grid()
+    g.sza0, g.dsza, g.nsza = 30.0, 1.0, 1
+    g.vza0, g.dvza, g.nvza = 0.0, 1.0, 91
+    g.phi0, g.dphi, g.nphi = 0.0, 1.0, 361
+    return g
+
+
+def gather_member_tables(local, n_members, group=None):
+    """The one exchange step of a member-sharded ensemble: every rank holds the reduced product of ITS members
+    (members in gort_amd.shard.row_slab order), local[members_local][...]; returns table[n_members][...] on every
+    rank by one all-gather (RCCL over xGMI with the `nccl` backend; 50 KB per member for the albedo table, while
+    each member's 552 MB LUT stays on the GPU that made it)."""
+    tail = tuple(local.shape[1:])
+    flat = local.reshape(local.shape[0], int(np.prod(tail)) if tail else 1)      # explicit: a rank may hold no member
+    return all_gather_lut(flat, n_members, group).reshape((n_members,) + tail)
+
+
+def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, group=None, lut_chunk=0, seed=12345,
+                         gather_on_cpu=False):
+    """Config 5 on `world` ranks, one GPU each: rank r draws the whole ensemble (same seed everywhere), keeps the
+    members row_slab(r, world, n) on its GPU - gap probabilities, PROSPECT-D/Price, band tables on the device,
+    optionally every member's hemisphere LUT in chunks of `lut_chunk` members - and all ranks end with the
+    ensemble's albedo/fAPAR table energy[n_members][nw][3].  Returns (table as numpy, timings dict).
+    gather_on_cpu: exchange through host memory (gloo rehearsals on one GPU)."""
+    import time
+    import torch
+    wl = np.ascontiguousarray(wavelengths, dtype=np.float64)
+    canopies, leaf = draw_c5_members(n_members, seed)
+    m0, m1 = row_slab(rank, world, n_members)
+    eng = api.Engine()
+    t = {}
+    t0 = time.perf_counter()
+    if m1 > m0:
+        eng.set_members_leaf(canopies[m0:m1], leaf[m0:m1], wl, compute_gaps=True)
+        eng.synchronize()
+    t["setup_s"] = time.perf_counter() - t0
+    t["lut_s"] = 0.0
+    if lut_chunk and m1 > m0:
+        g = c5_grid()
+        chunk = min(lut_chunk, m1 - m0)
+        lut = torch.empty((chunk, g.nvza * g.nphi, wl.size), dtype=torch.float64, device="cuda")
+        t0 = time.perf_counter()
+        for a in range(0, m1 - m0, chunk):
+            eng.rsurf_members_grid_dev(g, a, min(m1 - m0, a + chunk), lut)
+        eng.synchronize()
+        t["lut_s"] = time.perf_counter() - t0
+        del lut
+    energy = torch.empty((m1 - m0, 1, wl.size, 3), dtype=torch.float64, device="cuda")
+    if m1 > m0:
+        sun = torch.tensor([[0.0, 0.0, float(sun_zenith), 0.0]], dtype=torch.float64, device="cuda")
+        eng.energy_members_dev(sun, 0, m1 - m0, energy)
+        eng.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    local = energy.view(m1 - m0, wl.size, 3)
+    if world > 1:
+        full = gather_member_tables(local.cpu() if gather_on_cpu else local, n_members, group)
+    else:
+        full = local
+    torch.cuda.synchronize()
+    t["gather_s"] = time.perf_counter() - t0
+    out = full.cpu().numpy()
+    eng.close()
+    return out, t

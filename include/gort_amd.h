@@ -232,7 +232,7 @@ int  gort_rsurf_members_stream_dev(gort_engine *e, const double *angles_dev, lon
  * engine's stream; returns <0 if none. */
 double gort_engine_last_expand_ms(gort_engine *e);
 /* how the flat expansion kernels map workgroups to XCD-contiguous output ranges on this device: 1 = static
- * (workgroup dispatch probed to be round-robin over the XCDs), 2 = per-XCD slot counters; <0 = -error */
+ * (workgroup dispatch probed to be round-robin over the XCDs), 2 = per-XCD slot counters; <0 = a GORT_E* code */
 int  gort_engine_xcd_mapping(gort_engine *e);
 /* duty weights of the eight XCDs in 32nds (static mapping): the XCDs of a part do not write equally fast, and
  * the slower ones get a smaller share of the LUT slab.  Calibrated on the first LUT slab of >= 1 GiB

@@ -45,12 +45,18 @@ def build(force=False):
 
 
 _lib = None
+#: bench.py sets this to False: a benchmark process (GPU initialised, possibly under rocprofv3) must never start a
+#: compiler; it loads the prebuilt library or fails.  Tests keep the convenience of an automatic build.
+AUTO_BUILD = True
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if AUTO_BUILD:
+            build()
+        elif not os.path.exists(LIB):
+            raise ImportError("%s missing: build it with `make -C oracle` (or __graft_entry__.build())" % LIB)
         _lib = C.CDLL(LIB)
         _lib.gort_o_crown_proj_volume.restype = D
         _lib.gort_o_get_es.restype = D

@@ -190,3 +190,28 @@ def test_index_math_selftest():
     """Host-side self-test of the LUT kernel's index arithmetic: the multiply-shift divisions equal '/', and the
     XCD duty mapping sends the workgroups of a launch onto every logical block exactly once (300 weightings)."""
     assert api.lib().gort_selftest_index_math() == 0
+
+
+def test_error_codes_are_negative_and_null_handles_fail_cleanly():
+    """gort_engine_xcd_mapping returned +3/+5 for device errors (it negated an already negative code).
+    Every entry point that reports through its return value gives a NEGATIVE GORT_E* code for a null handle,
+    without touching a device; the new pipe / pinned-memory surface included."""
+    import ctypes as C
+    L = api.lib()
+    assert L.gort_engine_xcd_mapping(None) == api.EINVAL
+    assert L.gort_engine_stream_form(None) == api.EINVAL
+    assert L.gort_engine_set_stream_grouping(None, 1) == api.EINVAL
+    assert L.gort_engine_last_stream_ms(None) < 0
+    assert L.gort_engine_synchronize(None) == api.EINVAL
+    w = (C.c_int * 8)()
+    assert L.gort_engine_xcd_weights(None, w) == api.EINVAL
+    assert L.gort_pipe_submit(None, 1) == api.EINVAL and L.gort_pipe_release(None) == api.EINVAL
+    chunk = api.PipeChunk()
+    assert L.gort_pipe_wait(None, C.byref(chunk)) == api.EINVAL
+    h = C.c_void_p()
+    assert L.gort_pipe_create(None, 10, 2, 0, C.byref(h)) == api.EINVAL and not h.value
+    L.gort_pipe_destroy(None)
+    L.gort_host_free(None)
+    if api.device_count() == 0:
+        assert L.gort_set_device(0) == api.ENODEVICE
+        assert L.gort_get_device() < 0
