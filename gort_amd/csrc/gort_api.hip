@@ -782,6 +782,9 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     if (few_bands) {
         // few bands: one thread per sample straight from the full angle records (single canopy only)
         if (e->n_members != 1) return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: needs nw >= 128 bands");
+        // up to 8 bands (config 3 has one): no records at all, the geometry kernel writes the samples itself
+        static const bool fuse = !(getenv("GORT_GRID_FUSE") && atoi(getenv("GORT_GRID_FUSE")) == 0);
+        if (nw <= 8 && fuse) return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream);
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
         return launch_expand_stream(c, e->L.as<double>(), nw, nullptr, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr,

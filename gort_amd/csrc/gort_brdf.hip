@@ -236,9 +236,15 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 // per-tuple form.
 constexpr int GEOM_ROW_THREADS = 128;
 constexpr int GEOM_ROWS = 4;
+// mode 0: full stream records (GORT_COEF_STRIDE doubles per node); 1: compact 64-B records for the LUT kernel;
+// 2: FUSED for grids of a few bands (BASELINE config 3 is one band): the node's samples are formed right here from
+// its coefficients - no 128-B record per node written and read back (383 MB each way for the hemisphere grid,
+// more than the arithmetic costs) - with the same sun_terms()/dot5() as the two-kernel path: same bits.
 __global__ __launch_bounds__(GEOM_ROW_THREADS) void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
-                                                                          double *__restrict__ coef, int compact)
+                                                                          double *__restrict__ coef, int compact,
+                                                                          const double *__restrict__ Lall, int nw,
+                                                                          double *__restrict__ rsurf)
 {
     __shared__ RowTerms s_row[GEOM_ROWS];
     __shared__ int s_member[GEOM_ROWS];
@@ -269,7 +275,16 @@ __global__ __launch_bounds__(GEOM_ROW_THREADS) void geometry_grid_kernel(const g
         GeomOut o;
         finish_angle(c, s_row[r], raa, o);
         const long i = first * g.nphi + n;
-        if (compact) {
+        if (compact == 2) {
+            double rec[GORT_COEF_STRIDE];
+            store_coef(rec, c, o);
+            const double *__restrict__ L = Lall + (long)s_member[r] * L_NSLOT * nw;
+            const SunScalars sun = load_sun(rec);
+            for (int b = 0; b < nw; ++b) {
+                const SunTerms t = sun_terms(L, nw, b, sun, c.k_open, c.k_openep);
+                rsurf[i * nw + b] = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t.C0, t.B, t.Z, t.G, t.T);
+            }
+        } else if (compact) {
             // LUT path: only the five expansion coefficients, one 64-B record per node
             double rec[GORT_COEF_STRIDE];
             store_coef(rec, c, o);
@@ -922,8 +937,19 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
     const long rows = row_end - row_begin;
     if (rows <= 0) return GORT_OK;
     hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
-                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, coef_dev, compact ? 1 : 0);
+                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, coef_dev, compact ? 1 : 0,
+                       (const double *)nullptr, 0, (double *)nullptr);
     return check_launch("geometry_grid_kernel");
+}
+
+int launch_geometry_grid_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g, long row_begin,
+                               long row_end, double *rsurf_dev, void *stream)
+{
+    const long rows = row_end - row_begin;
+    if (rows <= 0 || nw <= 0) return GORT_OK;
+    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
+                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, (double *)nullptr, 2, L_dev, nw, rsurf_dev);
+    return check_launch("geometry_grid_kernel (fused)");
 }
 
 // nA angle lines for each of n_members members (member-major records and outputs); one thread per sample

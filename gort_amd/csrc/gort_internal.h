@@ -64,6 +64,9 @@ int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_d
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream);
+// grids of a few bands: samples formed in the geometry kernel itself, rsurf_dev[rows][nphi][nw], no records
+int launch_geometry_grid_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g,
+                               long row_begin, long row_end, double *rsurf_dev, void *stream);
 // per-XCD slot counters of the flat expansion kernels: 8 ints, one per 128-B line (XCD_SLOT_PITCH ints apart) so
 // that the eight XCDs' atomics do not serialise on one line; the caller zeroes XCD_SLOT_BYTES on the stream
 constexpr int XCD_SLOT_PITCH = 32;

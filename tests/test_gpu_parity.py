@@ -344,6 +344,34 @@ def test_grid_equals_stream_and_oracle(eng, nw):
     assert err(got, ref) <= REGRESSION
 
 
+@pytest.mark.parametrize("nw", [1, 3, 8])
+def test_few_band_grid_fused_equals_two_kernel_path(nw):
+    """Grids of up to 8 bands (BASELINE config 3 has one) form their samples inside the geometry kernel; the
+    two-kernel path (records + per-sample expansion, GORT_GRID_FUSE=0) must give the same bits."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+from gort_amd import api
+nw = %d
+c = api.gap_probabilities(api.make_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3))
+e = api.Engine(); e.set_canopy(c); e.set_spectra(*api.spectra(np.linspace(450.0, 2300.0, nw)))
+g = api.hemisphere_grid(13, 91, 361)
+lut = torch.empty((13 * 91 * 361, nw), dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+e.rsurf_grid_dev(g, 5, 13 * 91 - 7, lut)
+e.synchronize()
+print(hashlib.sha256(lut[: (13 * 91 - 12) * 361].cpu().numpy().tobytes()).hexdigest())
+""" % (root, nw)
+    digests = []
+    for fuse in ("1", "0"):
+        run = subprocess.run(["python3", "-c", script], capture_output=True, timeout=300, env=dict(os.environ, GORT_GRID_FUSE=fuse))
+        assert run.returncode == 0, run.stderr.decode()[-2000:]
+        digests.append(run.stdout.decode().strip().split("\n")[-1])
+    assert digests[0] == digests[1] and len(digests[0]) == 64
+
+
 # --------------------------------------------------------------------- energy
 def test_c4_albedo_all_sun_zeniths(eng, golden):
     g = golden("c4_albedo.npz")

@@ -42,14 +42,23 @@ t = best(lambda: eng.energy_stream_dev(sza, en), eng)
 print("C4  91 sun zeniths x 2101 bands  : %8.1f us  = %.3e BRDF evaluations/s equivalent (91 x 512 nodes x 2101 bands); "
       "the reference needs 512 rsurf calls per (sun zenith, band)" % (t * 1e6, 91 * 512 * wl.size / t))
 
-# stream entry point at full spectrum: 65 536 random lines x 2101 bands (every line its own sun zenith)
+# stream entry point at full spectrum: 65 536 random lines x 2101 bands, (a) 91 distinct sun zeniths (lines grouped by
+# sun zenith on the device), (b) every line its own sun zenith (per-line sun terms)
 rng = np.random.default_rng(0)
 n = 65536
-a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), np.zeros(n)], 1), device="cuda")
 o2 = torch.empty((n, wl.size), dtype=torch.float64, device="cuda")
-t = best(lambda: eng.rsurf_stream_dev(a, o2), eng)
-print("stream 65 536 random lines x 2101: %8.1f us  %.3e samples/s  %.0f GB/s written" % (t * 1e6, n * wl.size / t, n * wl.size * 8 / t / 1e9))
-# host in / host out (PCIe inclusive), what the CLI pays before formatting
+for label, sza in (("91 sun zeniths", rng.integers(0, 90, n).astype(float)), ("all distinct  ", rng.uniform(0, 89, n))):
+    a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), sza, np.zeros(n)], 1), device="cuda")
+    torch.cuda.synchronize()
+    t = best(lambda: eng.rsurf_stream_dev(a, o2), eng)
+    print("stream 65 536 lines x 2101, %s: %8.1f us  %.3e samples/s  %.0f GB/s written  (%s form)"
+          % (label, t * 1e6, n * wl.size / t, n * wl.size * 8 / t / 1e9, eng.stream_form()))
+# host in / host out (PCIe inclusive), what the CLI pays before formatting: into a pinned buffer (one DMA) and into an
+# ordinary, already touched numpy array (pinned staging + threaded copy-out); tools/bench_host_path.py has the copy rate
 ah = a.cpu().numpy()
-t0 = time.perf_counter(); eng.rsurf_stream(ah, want_K=True); t = time.perf_counter() - t0
-print("same through host buffers (PCIe) : %8.1f ms  %.3e samples/s" % (t * 1e3, n * wl.size / t))
+pin = api.PinnedArray((n, wl.size))
+t = best(lambda: eng.rsurf_stream(ah, want_K=True, out=pin.array), eng, reps=3)
+print("same through host buffers, pinned output   : %8.1f ms  %.3e samples/s" % (t * 1e3, n * wl.size / t))
+out = np.zeros((n, wl.size))
+t = best(lambda: eng.rsurf_stream(ah, want_K=True, out=out), eng, reps=3)
+print("same through host buffers, pageable output : %8.1f ms  %.3e samples/s" % (t * 1e3, n * wl.size / t))
