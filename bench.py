@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab-candidates", type=int, default=3,
+                    help="untimed setup: allocate this many LUT slabs, keep the one the expansion kernel writes fastest, "
+                         "verify it, redraw up to 3 times if it is a slow placement (1 = off)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")
     ap.add_argument("--sustain-s", type=float, default=3.0,
                     help="after the timed region, keep stepping for this many seconds and report the mean step ('sustained'); 0 = off")
@@ -220,13 +223,17 @@ def main():
     r0, r1 = row_slab(rank, world, rows)
     my_samples = (r1 - r0) * grid.nphi * nw
     total_samples = rows * grid.nphi * nw
+    slab_ms = []
     if args.gather and world > 1:
         # the whole LUT once (+ < world rows of padding): this rank computes straight into its window of it and
         # the all-gather lands in place - no receive buffer, no second copy (gort_amd/shard.py)
         full_padded = empty_gatherable(rows, grid.nphi * nw, world, torch.float64, "cuda")
         lut = my_window(full_padded, rank, world, rows).view((r1 - r0) * grid.nphi, nw)
     else:
-        lut = torch.empty(((r1 - r0) * grid.nphi, nw), dtype=torch.float64, device="cuda")
+        # untimed setup: the slab is the fastest of a few allocations (physical placement decides +-5 % of the
+        # expansion kernel's write rate and a multi-GPU step ends with its slowest rank)
+        from gort_amd.shard import pick_fastest_slab
+        lut, slab_ms = pick_fastest_slab(eng, grid, r0, r1, nw, candidates=args.slab_candidates)
 
     def step():
         if r1 > r0:
@@ -340,6 +347,7 @@ def main():
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
                          "xcd_mapping": eng.xcd_mapping(), "xcd_weights_32nds": eng.xcd_weights()[0],
                          "bare_store_pattern_gbs_equal_xcd_shares": eng.store_pattern_gbs(),
+                         "slab_selection_rank0": slab_ms,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_replayed": replayed},
             "sustained": sustained,
             "parity": parity,

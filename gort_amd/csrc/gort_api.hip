@@ -87,6 +87,8 @@ struct gort_engine {
     // duty weights of the XCDs (32nds) for the static mapping; calibrated on the first LUT slab big enough
     int xcd_weights[8] = {32, 32, 32, 32, 32, 32, 32, 32};
     bool xcd_calibrated = false;
+    bool xcd_weights_fixed = false;      // set by hand: never recalibrated
+    int xcd_cal_class = -1;              // log2 size class of the slab the weights were measured on
     double xcd_pattern_gbs = 0.0;        // rate of the bare store pattern during the calibration pass
     // Small LUT slabs (the per-rank slabs of a multi-GPU run) are pipelined over two streams: geometry and sun
     // table of call i+1 run on `aux` into the other half of a double buffer while the expansion of call i is
@@ -198,13 +200,13 @@ extern "C" int gort_engine_create(gort_engine **out)
     }
     if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
     e->stream_grouping = stream_group_enabled();
-    if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = atoi(v) == 0;        // 0: equal weights
+    if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
     if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
         int w[8];
         if (sscanf(v, "%d,%d,%d,%d,%d,%d,%d,%d", w, w + 1, w + 2, w + 3, w + 4, w + 5, w + 6, w + 7) == 8) {
             // the range gort_engine_set_xcd_weights accepts: what gort_engine_xcd_weights reports is what is used
             for (int x = 0; x < 8; ++x) e->xcd_weights[x] = w[x] < 8 ? 8 : (w[x] > 32 ? 32 : w[x]);
-            e->xcd_calibrated = true;
+            e->xcd_calibrated = e->xcd_weights_fixed = true;
         }
     }
     *out = e;
@@ -281,13 +283,13 @@ extern "C" int gort_engine_set_xcd_weights(gort_engine *e, const int weights[8])
     if (!e) return fail(GORT_EINVAL, "gort_engine_set_xcd_weights: null engine");
     if (!weights) {                          // back to automatic: calibrate on the next big LUT slab
         for (int x = 0; x < 8; ++x) e->xcd_weights[x] = 32;
-        e->xcd_calibrated = false;
+        e->xcd_calibrated = e->xcd_weights_fixed = false;
         return GORT_OK;
     }
     for (int x = 0; x < 8; ++x)
         if (weights[x] < 8 || weights[x] > 32) return fail(GORT_ERANGE, "gort_engine_set_xcd_weights: weight %d outside 8..32", weights[x]);
     for (int x = 0; x < 8; ++x) e->xcd_weights[x] = weights[x];
-    e->xcd_calibrated = true;
+    e->xcd_calibrated = e->xcd_weights_fixed = true;
     return GORT_OK;
 }
 
@@ -823,10 +825,17 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     }
     int *xcd_slots = nullptr;
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
-    if (!xcd_slots && !e->xcd_calibrated && nA * (long)nw >= (1L << 27)) {
-        // first slab of 1 GiB or more: time the XCDs' write rates on it (it is overwritten right after)
-        if ((rc = calibrate_xcd_weights(e->stream, lut_dev, nA * (long)nw, e->xcd_weights, &e->xcd_pattern_gbs))) return rc;
-        e->xcd_calibrated = true;
+    // slabs of 1 GiB or more: time the XCDs' write rates on the slab itself (it is overwritten right after) - once per
+    // size class (power of two of the slab's size), since how unevenly the XCDs write depends on how far apart their
+    // windows lie; weights set by hand (GORT_XCD_WEIGHTS, gort_engine_set_xcd_weights) are left alone
+    if (!xcd_slots && !e->xcd_weights_fixed && nA * (long)nw >= (1L << 27)) {
+        int cls = 0;
+        for (long v = nA * (long)nw; v > 1; v >>= 1) ++cls;
+        if (!e->xcd_calibrated || cls != e->xcd_cal_class) {
+            if ((rc = calibrate_xcd_weights(e->stream, lut_dev, nA * (long)nw, e->xcd_weights, &e->xcd_pattern_gbs))) return rc;
+            e->xcd_calibrated = true;
+            e->xcd_cal_class = cls;
+        }
     }
     // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to
     // 512 launches are kept between two gort_engine_last_expand_ms() calls

@@ -12,7 +12,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from gort_amd import api  # noqa: E402
-from gort_amd.shard import row_slab  # noqa: E402
+from gort_amd.shard import pick_fastest_slab, row_slab  # noqa: E402
 
 
 def main():
@@ -30,7 +30,8 @@ def main():
         worst = 0.0
         for rank in sorted({0, world // 2, world - 1}):
             r0, r1 = row_slab(rank, world, rows)
-            lut = torch.empty(((r1 - r0) * grid.nphi, wl.size), dtype=torch.float64, device="cuda")
+            cands = int(os.environ.get("CANDIDATES", "3"))
+            lut, cand_ms = pick_fastest_slab(eng, grid, r0, r1, wl.size, candidates=cands)
             for _ in range(5):
                 eng.rsurf_grid_dev(grid, r0, r1, lut)
             eng.synchronize()
@@ -42,8 +43,8 @@ def main():
             ms = (time.perf_counter() - t0) * 1e3 / steps
             k = eng.last_expand_ms()
             gb = (r1 - r0) * grid.nphi * wl.size * 8 / 1e9
-            print("N=%d rank %d rows [%d,%d) %.2f GB: %.3f ms/step, expand kernel %.3f ms (%.0f GB/s), other %.3f ms"
-                  % (world, rank, r0, r1, gb, ms, k, gb / k * 1e3, ms - k), flush=True)
+            print("N=%d rank %d rows [%d,%d) %.2f GB: %.3f ms/step, expand kernel %.3f ms (%.0f GB/s), other %.3f ms; candidates %s"
+                  % (world, rank, r0, r1, gb, ms, k, gb / k * 1e3, ms - k, " | ".join("%s -> %.3f" % (" ".join("%.3f" % x for x in a["probe_ms"]), a["verified_ms"]) for a in cand_ms)), flush=True)
             worst = max(worst, ms)
             del lut
             torch.cuda.empty_cache()

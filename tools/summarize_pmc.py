@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, "**", "*_counter_collection.csv"), recursi
             agg[k][c].append(v)
 out = {}
 for k, ctrs in agg.items():
-    name = k.split("(")[0].replace("void ", "").replace("gort::(anonymous namespace)::", "")
+    name = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("gort::", "").split("(")[0]
     d = {"launches": max(len(v) for v in ctrs.values())}
     for c, v in ctrs.items():
         d[c] = sum(v) / len(v)
