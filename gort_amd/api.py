@@ -450,7 +450,8 @@ class Engine:
         return {0: "narrow", 1: "grouped", 2: "per-line"}[m]
 
     def set_stream_grouping(self, on):
-        _check(lib().gort_engine_set_stream_grouping(self.h, int(bool(on))))
+        """False/0 never, True/1 automatic (size threshold), 2 whenever the stream allows it."""
+        _check(lib().gort_engine_set_stream_grouping(self.h, int(on)))
 
     def last_stream_ms(self):
         return lib().gort_engine_last_stream_ms(self.h)

@@ -66,7 +66,8 @@ struct gort_engine {
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
     DevBuf sgroup, ssun;                 // workspace of the grouped stream expansion (gort_stream.hip)
-    bool stream_grouping = true;         // GORT_STREAM_GROUP=0 / gort_engine_set_stream_grouping
+    int stream_grouping = 0;             // 0 per line (default), 1 group large streams (size threshold, verdict memory), 2 group whenever possible
+    long group_min_lines = 200000;       // GORT_STREAM_GROUP_MIN: automatic mode groups streams of at least this many lines
     int stream_form = 0;                 // form of the last stream call: 0 narrow, 1 grouped, 2 per line, -1 ask the device
     hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call
     hipEvent_t ev_sgeo[2] = {nullptr, nullptr};       // stream call: inputs ready / geometry done (second stream)
@@ -199,7 +200,8 @@ extern "C" int gort_engine_create(gort_engine **out)
         return fail(GORT_ENODEVICE, "gort_engine_create: cannot create streams/events");
     }
     if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
-    e->stream_grouping = stream_group_enabled();
+    if (const char *v = getenv("GORT_STREAM_GROUP")) { const int m = atoi(v); e->stream_grouping = m < 0 ? 0 : (m > 2 ? 2 : m); }
+    if (const char *v = getenv("GORT_STREAM_GROUP_MIN")) e->group_min_lines = atol(v);
     if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
     if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
         int w[8];
@@ -518,7 +520,10 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
     size_t ws_bytes = 0, sun_bytes = 0;
     const bool wide = expand_stream_workspace(e->nw, nA, scomp_dev != nullptr, &ws_bytes, &sun_bytes);
-    if (!e->stream_grouping) ws_bytes = 0;
+    // Since the stream family's regrouped sample (gort_device.h) the per-line kernel is as fast as the grouped form or
+    // faster (1 048 576 lines: 3.35 ms per line, 3.43 grouped; 65 536: 232 against 252 us, it has no grouping pass), so
+    // per line is the default; mode 1 groups streams of at least group_min_lines, mode 2 whenever the stream allows it
+    if (e->stream_grouping == 0 || (e->stream_grouping == 1 && nA < e->group_min_lines)) ws_bytes = 0;
     // Whether the grouped form applies is decided on the device, call by call; giving a stream up costs ~40 us of
     // grouping and of launches that return at once.  Streams are mostly of one kind, so the verdict of the last
     // attempt (copied back asynchronously, looked at only once it has arrived) suspends further attempts for the
@@ -546,15 +551,15 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
             if (!e->ev_sgeo[i]) GORT_HIP(hipEventCreateWithFlags(&e->ev_sgeo[i], hipEventDisableTiming));
         GORT_HIP(hipEventRecord(e->ev_sgeo[0], e->stream));            // inputs ready, previous readers of coef done
         GORT_HIP(hipStreamWaitEvent(e->aux, e->ev_sgeo[0], 0));
-        if ((rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, e->aux))) return rc;
+        if ((rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, 1, e->aux))) return rc;
         GORT_HIP(hipEventRecord(e->ev_sgeo[1], e->aux));
-    } else if ((rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, e->stream))) {
+    } else if ((rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, wide ? 1 : 0, e->stream))) {
         return rc;
     }
     GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
     rc = launch_expand_stream(c, e->L.as<double>(), e->nw, angles_dev, coef, nA, rsurf_dev, scomp_dev, xcd_slots,
                               ws_bytes ? e->sgroup.p : nullptr, ws_bytes ? e->ssun.as<double>() : nullptr, e->stream,
-                              beside ? (void *)e->ev_sgeo[1] : nullptr);
+                              beside ? (void *)e->ev_sgeo[1] : nullptr, false);
     GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
     if (rc == GORT_OK && ws_bytes && !e->group_verdict_pending) {
         if (!e->group_verdict) {
@@ -706,7 +711,7 @@ extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, 
 extern "C" int gort_engine_set_stream_grouping(gort_engine *e, int on)
 {
     if (!e) return fail(GORT_EINVAL, "gort_engine_set_stream_grouping: null engine");
-    e->stream_grouping = on != 0;
+    e->stream_grouping = on < 0 ? 0 : (on > 2 ? 2 : on);
     e->group_skip = 0;                       // forget what earlier streams were like
     e->group_verdict_pending = false;
     return GORT_OK;
@@ -790,7 +795,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
         return launch_expand_stream(c, e->L.as<double>(), nw, nullptr, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr,
-                                    nullptr, nullptr, e->stream, nullptr);
+                                    nullptr, nullptr, e->stream, nullptr, true);
     }
     // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).
     // Full-size slabs: ONE buffer, reused by every call - the 191 MB of records the geometry kernel writes are

@@ -208,9 +208,13 @@ __device__ inline void store_coef(double *rec, const gort_canopy &c, const GeomO
     rec[C_PAD0] = 0.0;  rec[C_PAD1] = 0.0;
 }
 
+// layout 0: the classic record (five coefficients, sun scalars, component-spectra extras: CoefSlot);
+// layout 1: the LineTerms of the stream family's regrouped sample (gort_device.h) for the wide stream kernels, which
+//           read them through the scalar cache once per 128 samples and must not spend VALU work on deriving them
 __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy *__restrict__ canopy,
                                                                const double *__restrict__ angles, long nA,
-                                                               double *__restrict__ coef, double *__restrict__ K)
+                                                               double *__restrict__ coef, double *__restrict__ K,
+                                                               int layout)
 {
     const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nA) return;
@@ -221,7 +225,16 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
     GeomOut g;
     geometry_core(c, vza, sza, raa, g);
-    store_coef(coef + (member * nA + a) * GORT_COEF_STRIDE, c, g);
+    if (layout == 0) {
+        store_coef(coef + (member * nA + a) * GORT_COEF_STRIDE, c, g);
+    } else {
+        double rec[GORT_COEF_STRIDE];
+        store_coef(rec, c, g);
+        const LineTerms l = line_terms_of_record(rec, c.k_openep, c.k_open);
+        double *o = coef + (member * nA + a) * GORT_COEF_STRIDE;
+        o[0] = l.alpha;  o[1] = l.P1;  o[2] = l.P2;  o[3] = l.Q1;  o[4] = l.Q2;  o[5] = l.Q3;  o[6] = l.Q4;  o[7] = l.Q5;
+        o[8] = l.Q6;  o[9] = l.mu;  o[10] = l.t0;  o[11] = l.omtp0;  o[12] = l.m2;  o[13] = 0.0;  o[14] = 0.0;  o[15] = 0.0;
+    }
     if (K) {
         double *k = K + 4 * (member * nA + a);
         k[0] = g.Kc;  k[1] = g.Kg;  k[2] = g.Kt;  k[3] = g.Kz;
@@ -346,7 +359,8 @@ template <bool WITH_SCOMP>
 __global__ __launch_bounds__(256) void expand_stream_kernel(const gort_canopy *__restrict__ canopy,
                                                              const double *__restrict__ L, int nw,
                                                              const double *__restrict__ coef, long n_samples,
-                                                             double *__restrict__ rsurf, double *__restrict__ scomp)
+                                                             double *__restrict__ rsurf, double *__restrict__ scomp,
+                                                             int grid_form)
 {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_samples) return;
@@ -362,8 +376,13 @@ __global__ __launch_bounds__(256) void expand_stream_kernel(const gort_canopy *_
         idx += member * n_samples;
     }
     const SunScalars s = load_sun(rec);
-    const SunTerms b = sun_terms(L, nw, i, s, canopy->k_open, canopy->k_openep);
-    rsurf[idx] = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], b.C0, b.B, b.Z, b.G, b.T);
+    const BandTerms t = load_band(L, nw, i);
+    SunTerms b;
+    if (WITH_SCOMP || grid_form) b = sun_terms(t, s, canopy->k_open, canopy->k_openep);
+    // grid_form: a few-band LUT through this kernel belongs to the LUT family (five terms, dot5); streams use the
+    // stream family's regrouped sample, like every other stream kernel
+    if (grid_form) rsurf[idx] = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], b.C0, b.B, b.Z, b.G, b.T);
+    else rsurf[idx] = stream_sample(line_terms_of_record(rec, canopy->k_openep, canopy->k_open), stream_band(t));
     if (WITH_SCOMP) {
         double4 o;
         o.x = b.C0 + rec[C_FDA] * b.B + rec[C_KPZ] * b.Z + rec[C_KPG] * b.G;    // C
@@ -383,19 +402,22 @@ __global__ __launch_bounds__(256) void expand_stream_bands_kernel(const gort_can
                                                                    const double *__restrict__ L, int nw,
                                                                    const double *__restrict__ coef, long nA,
                                                                    double *__restrict__ rsurf,
-                                                                   double *__restrict__ scomp)
+                                                                   double *__restrict__ scomp, int grid_form)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const long a0 = (long)blockIdx.y * STREAM_LINES;
     const long a1 = a0 + STREAM_LINES < nA ? a0 + STREAM_LINES : nA;
     const bool live = i < nw;
     const BandTerms t = load_band(L, nw, live ? i : 0);
+    const StreamBand sb = stream_band(t);
     const double ko = canopy->k_open, kep = canopy->k_openep;
     for (long a = a0; a < a1; ++a) {
         const double *__restrict__ rec = coef + a * GORT_COEF_STRIDE;
         const SunScalars s = load_sun(rec);
-        const SunTerms b = sun_terms(t, s, ko, kep);
-        const double v = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], b.C0, b.B, b.Z, b.G, b.T);
+        SunTerms b;
+        if (WITH_SCOMP || grid_form) b = sun_terms(t, s, ko, kep);
+        const double v = grid_form ? dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], b.C0, b.B, b.Z, b.G, b.T)
+                                   : stream_sample(line_terms_of_record(rec, kep, ko), sb);
         if (live) {
             rsurf[a * nw + i] = v;
             if (WITH_SCOMP) {
@@ -709,75 +731,82 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
                                     angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
 }
 
-// The aligned flat form for ARBITRARY angle lines (every line has its own sun zenith): same chunking and
-// band-preserving stride as expand_flat_kernel, but a lane keeps the 11 BAND terms of its two bands in
-// registers and forms the five (sun, band) terms per step from the line's sun scalars, which travel in the
-// same 128-B record as the five coefficients (scalar loads).  Per sample ~45 flops + half an fp64 division on
-// top of the store; rows of nw doubles are never 128-B aligned in the band-major kernels above.
+// The aligned flat form for ARBITRARY angle lines (every line has its own sun zenith): the chunking, the
+// band-preserving stride, the PANELS (K steps x W waves, each XCD one contiguous run of panels) and the slab-edge
+// handling of expand_flat_kernel; but a lane keeps the 12 band constants of its two bands in registers and forms
+// p_df, t'_df and the sample per step from the line's 13 LineTerms (records in layout 1, scalar loads, one step
+// ahead): ~24 instructions + one fp64 division per sample (gort_device.h, stream family).
 // coef: stream records (GORT_COEF_STRIDE doubles), one pad record in front, tail pad behind.
+// one step of a wave: the samples of the chunk from the record(s) `rec`, stored with the slab-edge handling
 template <bool NT, bool WRAP>
-__device__ __forceinline__ void flat_stream_loop(const BandTerms (&t)[EPL], const int (&wrapped)[EPL],
-                                                 const int (&k_begin)[EPL], const int (&k_end)[EPL], double ko,
-                                                 double kep, int da, long step, int k_wave,
-                                                 const double *__restrict__ rec_w, double *__restrict__ out_w,
-                                                 int lane)
+__device__ __forceinline__ void flat_stream_step(const StreamBand (&t)[EPL], const bool (&second)[EPL],
+                                                 const double (&rec)[WRAP ? 2 : 1][LINE_NTERMS], bool front, bool back,
+                                                 int first_off, int last_off, double *__restrict__ o, int lane)
 {
-    const long rec_step = (long)da * GORT_COEF_STRIDE;
-    const int kb_all = k_begin[0] > k_begin[1] ? k_begin[0] : k_begin[1];
-    const int ke_all = k_end[0] < k_end[1] ? k_end[0] : k_end[1];
-    // current record(s) in registers, the next one in flight
-    double cur[2][10], nxt[2][10];
-    constexpr int slots[10] = {A_C, A_B, A_Z, A_G, A_T, S_FD, S_MU, S_T0, S_TP0, S_EPS};
+    double v[EPL];
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
-        cur[0][q] = rec_w[slots[q]];
-        cur[1][q] = WRAP ? rec_w[GORT_COEF_STRIDE + slots[q]] : 0.0;
-    }
-    rec_w += rec_step;
-    for (int kk = 0; kk < k_wave; ++kk) {
+    for (int j = 0; j < EPL; ++j) {
+        double vv[2];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) {
-            nxt[0][q] = rec_w[slots[q]];
-            nxt[1][q] = WRAP ? rec_w[GORT_COEF_STRIDE + slots[q]] : 0.0;
+        for (int w = 0; w < (WRAP ? 2 : 1); ++w) {
+            double pdf, tpdf;
+            sun_pair(t[j], rec[w][9], rec[w][10], rec[w][11], rec[w][12], pdf, tpdf);
+            vv[w] = stream_sample(rec[w][0], rec[w][1], rec[w][2], rec[w][3], rec[w][4], rec[w][5], rec[w][6], rec[w][7],
+                                  rec[w][8], t[j], pdf, tpdf);
         }
-        rec_w += rec_step;
-        double v[EPL];
+        v[j] = (WRAP && second[j]) ? vv[1] : vv[0];
+    }
+    if (!front && !back) {
+        dbl2 x;
+        x.x = v[0];
+        x.y = v[1];
+        if (NT) __builtin_nontemporal_store(x, reinterpret_cast<dbl2 *>(o));
+        else *reinterpret_cast<dbl2 *>(o) = x;
+    } else {
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            double vv[2];
-#pragma unroll
-            for (int w = 0; w < (WRAP ? 2 : 1); ++w) {
-                SunScalars s;
-                s.fd = cur[w][5];  s.mu = cur[w][6];  s.t0 = cur[w][7];  s.tp0 = cur[w][8];  s.eps = cur[w][9];
-                s.pn0 = 0.0;
-                const SunTerms b = sun_terms(t[j], s, ko, kep);
-                vv[w] = dot5(cur[w][0], cur[w][1], cur[w][2], cur[w][3], cur[w][4], b.C0, b.B, b.Z, b.G, b.T);
-            }
-            v[j] = (WRAP && wrapped[j]) ? vv[1] : vv[0];
+            const int off = EPL * lane + j;
+            if (!(front && off < first_off) && !(back && off > last_off)) o[j] = v[j];
         }
-        double *o = out_w + EPL * lane;
-        if (kk >= kb_all && kk < ke_all) {
-            dbl2 x;
-            x.x = v[0];
-            x.y = v[1];
-            if (NT) __builtin_nontemporal_store(x, reinterpret_cast<dbl2 *>(o));
-            else *reinterpret_cast<dbl2 *>(o) = x;
-        } else {
+    }
+}
+
+template <bool WRAP>
+__device__ __forceinline__ void load_line_terms(double (&rec)[WRAP ? 2 : 1][LINE_NTERMS], const double *__restrict__ p)
+{
 #pragma unroll
-            for (int j = 0; j < EPL; ++j)
-                if (kk >= k_begin[j] && kk < k_end[j]) o[j] = v[j];
-        }
-        out_w += step;
-#pragma unroll
-        for (int q = 0; q < 10; ++q) { cur[0][q] = nxt[0][q];  cur[1][q] = nxt[1][q]; }
+    for (int q = 0; q < LINE_NTERMS; ++q) {
+        rec[0][q] = p[q];
+        if (WRAP) rec[WRAP ? 1 : 0][q] = p[GORT_COEF_STRIDE + q];
+    }
+}
+
+// The steps of a wave.  One record set: the compiler issues the scalar loads of step k+1 behind the arithmetic of step
+// k and the wave waits for them at the top of the next step; the other waves of the SIMD (6 at 78 VGPRs) fill that
+// gap.  A hand-made double buffer (loads of step k+1 in front of the arithmetic of step k, two SGPR sets) cost a wave
+// of occupancy and ran 30 % SLOWER (4.54 against 3.44 ms for 1 048 576 lines): this kernel lives on thread-level
+// parallelism.
+template <bool NT, bool WRAP>
+__device__ __forceinline__ void flat_stream_loop(const StreamBand (&t)[EPL], const bool (&second)[EPL], int first_off,
+                                                 int last_step, int last_off, int da, long step, int k_wave,
+                                                 const double *__restrict__ rec_w, double *__restrict__ out_w, int lane)
+{
+    const long rec_step = (long)da * GORT_COEF_STRIDE;
+    double *o = out_w + EPL * lane;
+    double r[WRAP ? 2 : 1][LINE_NTERMS];
+    for (int kk = 0; kk < k_wave; ++kk) {
+        load_line_terms<WRAP>(r, rec_w);
+        rec_w += rec_step;
+        flat_stream_step<NT, WRAP>(t, second, r, kk == 0 && first_off > 0, kk == last_step, first_off, last_off, o, lane);
+        o += step;
     }
 }
 
 template <bool NT>
-__global__ __launch_bounds__(256) void expand_flat_stream_kernel(const gort_canopy *__restrict__ canopy,
-                                                                  const double *__restrict__ L, int nw,
+__global__ __launch_bounds__(256) void expand_flat_stream_kernel(const double *__restrict__ L, int nw,
                                                                   const double *__restrict__ coef, long n_total,
-                                                                  int shift, long stride_chunks,
+                                                                  int shift, long stride_chunks, int da,
+                                                                  int steps_per_wave, FastDiv div_stride, FastDiv div_nw,
                                                                   double *__restrict__ out, int xcd_mode,
                                                                   XcdDuty duty, long useful_blocks,
                                                                   int *__restrict__ xcd_slots,
@@ -788,35 +817,47 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const gort_cano
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long block = xcd_logical_block(xcd_mode, duty, useful_blocks, xcd_slots);
     if (block < 0) return;
-    const long wave = block * 4 + wave_in_block;
-    if (wave >= stride_chunks) return;
+    // panels of steps_per_wave x stride chunks: wave (panel, w) takes chunks panel*K*stride + w + k*stride, k < K
+    // (index arithmetic as in expand_flat_kernel: wave-uniform, 32-bit, divisions by multiply-shift)
+    const unsigned wave = (unsigned)(block * 4 + wave_in_block);
+    const unsigned stride = (unsigned)stride_chunks;
+    const unsigned panel = fast_div(wave, div_stride);
+    const unsigned w_in_panel = wave - panel * stride;
     const int lane = threadIdx.x & 63;
-    const long step = stride_chunks * CHUNK;       // a multiple of nw
-    const int da = (int)(step / nw);               // angle lines per step
-    const long e0 = wave * CHUNK - shift;
-    if (e0 >= n_total) return;
-    const long a_w = (e0 + step) / nw - da;        // >= -1
-    const int band_w = (int)((e0 + step) % nw);
-    const int k_wave = (int)((n_total - 1 - (e0 < 0 ? 0 : e0)) / step) + 1;
-    BandTerms t[EPL];
-    int wrapped[EPL], k_begin[EPL], k_end[EPL];
+    const long step = stride_chunks * CHUNK;                 // elements per step = da * nw
+    const long c0 = (long)panel * steps_per_wave * stride_chunks + w_in_panel;
+    const long last = n_total - 1 + shift;
+    const long last_chunk = last / CHUNK;
+    const int last_off = (int)(last % CHUNK);
+    if (c0 > last_chunk) return;
+    const long e0 = c0 * CHUNK - shift;                      // element index of the chunk start at step 0 (< 0 only for chunk 0)
+    const unsigned local = w_in_panel * CHUNK + (unsigned)step - (unsigned)shift;
+    const unsigned a_loc = fast_div(local, div_nw);
+    const int band_w = (int)(local - a_loc * (unsigned)nw);
+    const long a_w = (long)panel * steps_per_wave * da + a_loc - da;          // line of the chunk start, >= -1
+    const long rel = last_chunk - c0;
+    int k_wave = steps_per_wave, last_step = -1;
+    if (rel < (long)steps_per_wave * stride_chunks) {       // only the last panel's waves run out of slab
+        const unsigned k_last = fast_div((unsigned)rel, div_stride);
+        k_wave = (int)k_last + 1;
+        if ((unsigned)rel == k_last * stride) last_step = (int)k_last;        // ends in the slab's last chunk
+    }
+    const int first_off = c0 == 0 ? shift : 0;
+    StreamBand t[EPL];
+    bool second[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         int band = band_w + EPL * lane + j;
-        wrapped[j] = 0;
-        if (band >= nw) { band -= nw; wrapped[j] = 1; }
-        const long n_el = e0 + EPL * lane + j;
-        k_begin[j] = n_el < 0 ? 1 : 0;
-        k_end[j] = n_el < n_total ? (int)((n_total - 1 - n_el) / step) + 1 : 0;
-        t[j] = load_band(L, nw, band);
+        second[j] = band >= nw;                              // nw >= CHUNK on this path: one wrap at most
+        if (second[j]) band -= nw;
+        t[j] = stream_band(load_band(L, nw, band));
     }
-    const double *rec_w = coef + a_w * GORT_COEF_STRIDE;
+    const double *rec_w = coef + a_w * GORT_COEF_STRIDE;     // may point at the front pad record
     double *out_w = out + e0;
-    const double ko = canopy->k_open, kep = canopy->k_openep;
     if (band_w + CHUNK - 1 >= nw)
-        flat_stream_loop<NT, true>(t, wrapped, k_begin, k_end, ko, kep, da, step, k_wave, rec_w, out_w, lane);
+        flat_stream_loop<NT, true>(t, second, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
     else
-        flat_stream_loop<NT, false>(t, wrapped, k_begin, k_end, ko, kep, da, step, k_wave, rec_w, out_w, lane);
+        flat_stream_loop<NT, false>(t, second, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
 }
 
 // ------------------------------------------------------------- albedo / energy
@@ -923,11 +964,11 @@ int launch_lambda_table(const gort_canopy *canopies_dev, int n_members, int nw, 
 }
 
 int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA, double *coef_dev,
-                           double *K_dev, void *stream)
+                           double *K_dev, int layout, void *stream)
 {
     if (nA <= 0) return GORT_OK;
     hipLaunchKernelGGL(geometry_stream_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       canopy_dev, angles_dev, nA, coef_dev, K_dev);
+                       canopy_dev, angles_dev, nA, coef_dev, K_dev, layout);
     return check_launch("geometry_stream_kernel");
 }
 
@@ -961,11 +1002,11 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
     if (n_members > 65535) return fail(GORT_EINVAL, "members stream: %d members in one launch (max 65535)", n_members);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(geometry_stream_kernel, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0, s,
-                       canopies_dev, angles_dev, nA, coef_dev, (double *)nullptr);
+                       canopies_dev, angles_dev, nA, coef_dev, (double *)nullptr, 0);
     int rc = check_launch("geometry_stream_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(expand_stream_kernel<false>, dim3((unsigned)((n + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
-                       s, canopies_dev, L_dev, nw, coef_dev, n, rsurf_dev, (double *)nullptr);
+                       s, canopies_dev, L_dev, nw, coef_dev, n, rsurf_dev, (double *)nullptr, 0);
     return check_launch("expand_stream_kernel");
 }
 
@@ -985,17 +1026,17 @@ bool expand_stream_workspace(int nw, long nA, bool want_scomp, size_t *ws_bytes,
 
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
                          const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev,
-                         void *group_ws_dev, double *group_sun_dev, void *stream, void *coef_ready_event)
+                         void *group_ws_dev, double *group_sun_dev, void *stream, void *coef_ready_event, bool grid_form)
 {
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
     hipStream_t s = (hipStream_t)stream;
-    const bool grouped = stream_uses_flat(nw, nA, scomp_dev != nullptr) && angles_dev && group_ws_dev && group_sun_dev;
+    const bool grouped = !grid_form && stream_uses_flat(nw, nA, scomp_dev != nullptr) && angles_dev && group_ws_dev && group_sun_dev;
     if (coef_ready_event && !grouped &&
         hipStreamWaitEvent(s, (hipEvent_t)coef_ready_event, 0) != hipSuccess)
         return fail(GORT_ENODEVICE, "stream expansion: cannot wait for the geometry kernel");
-    if (stream_uses_flat(nw, nA, scomp_dev != nullptr)) {
-        // wide streams: lines grouped by sun zenith where the stream allows it, per-line sun terms otherwise
+    if (!grid_form && stream_uses_flat(nw, nA, scomp_dev != nullptr)) {
+        // wide streams (records in layout 1): lines grouped by sun zenith where the stream allows it, per-line sun terms otherwise
         const int *direct_flag = nullptr;
         if (grouped) {
             const int rc = launch_expand_stream_grouped(canopy_dev, L_dev, nw, angles_dev, coef_dev, nA, rsurf_dev,
@@ -1009,19 +1050,19 @@ int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int
         const dim3 grid((unsigned)((nw + 255) / 256), (unsigned)groups), block(256);
         if (scomp_dev)
             hipLaunchKernelGGL(expand_stream_bands_kernel<true>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev, nA,
-                               rsurf_dev, scomp_dev);
+                               rsurf_dev, scomp_dev, grid_form ? 1 : 0);
         else
             hipLaunchKernelGGL(expand_stream_bands_kernel<false>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev,
-                               nA, rsurf_dev, scomp_dev);
+                               nA, rsurf_dev, scomp_dev, grid_form ? 1 : 0);
         return check_launch("expand_stream_bands_kernel");
     }
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (scomp_dev)
         hipLaunchKernelGGL(expand_stream_kernel<true>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev, n, rsurf_dev,
-                           scomp_dev);
+                           scomp_dev, grid_form ? 1 : 0);
     else
         hipLaunchKernelGGL(expand_stream_kernel<false>, grid, block, 0, s, canopy_dev, L_dev, nw, coef_dev, n, rsurf_dev,
-                           scomp_dev);
+                           scomp_dev, grid_form ? 1 : 0);
     return check_launch("expand_stream_kernel");
 }
 
@@ -1044,7 +1085,7 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 //                        band-preserving multiple of nw/gcd(nw,128))
 //   GORT_EXPAND_STEPS    steps per wave = panel height; 0 = one panel, every wave strides through the whole slab
 //   GORT_EXPAND_XCD      0 | 1 | 2                XCD mapping, see below; default automatic
-//   GORT_STREAM_WAVES    target number of waves of expand_flat_stream_kernel
+//   GORT_STREAM_WAVES    waves per panel of expand_flat_stream_kernel; GORT_STREAM_STEPS its steps per wave
 // Measured on the 50.25 GB metric slab, four slabs held at once per run (profiles/r01/tune_panels*.log):
 //   whole-slab strides (steps 0, stride 33616)   8.1-8.3 ms, 9.5 ms on some allocations
 //   panels of 6 steps x 2101 waves, XCD mode 1   7.04-7.30 ms (6.9-7.1 TB/s), 7.8 ms on some allocations
@@ -1064,7 +1105,11 @@ struct ExpandTuning {
     int depth = 2;
     int steps = -1;             // -1 = automatic: 6 with the static mapping, 16 with slot counters (fewer atomics)
     long waves = 2048;
-    long stream_waves = 32768;
+    // the per-line stream kernel is VALU bound with a heavy prologue (24 band constants per lane): long waves.  Panels
+    // of 64 steps x 33616 waves (2.2 GB per panel; streams up to 131 072 lines are ONE panel): 65 536 lines 232-290 us
+    // whatever the shape, 1 048 576 lines 3.76 ms against 3.83 (one panel) and 4.0-5.0 (8..16 steps), tools/dbg/perline_sweep.sh
+    long stream_waves = 32768;      // GORT_STREAM_WAVES: waves per panel of the per-line stream kernel (rounded like `waves`)
+    int stream_steps = 64;          // GORT_STREAM_STEPS: steps per wave = panel height of the per-line stream kernel
     ExpandTuning()
     {
         if (const char *v = getenv("GORT_EXPAND_VARIANT")) flat = strcmp(v, "row") != 0;
@@ -1072,6 +1117,8 @@ struct ExpandTuning {
         if (const char *v = getenv("GORT_EXPAND_DEPTH")) depth = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_WAVES")) waves = atol(v);
         if (const char *v = getenv("GORT_STREAM_WAVES")) stream_waves = atol(v);
+        if (const char *v = getenv("GORT_STREAM_STEPS")) stream_steps = atoi(v);
+        if (stream_steps < 1) stream_steps = 1;
         if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_mode = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_STEPS")) steps = atoi(v);
         if (xcd_mode < -1 || xcd_mode > 2) xcd_mode = -1;
@@ -1419,34 +1466,55 @@ static bool stream_uses_flat(int nw, long nA, bool want_scomp)
     return tuning().flat && !want_scomp && nw >= CHUNK && nA * (long)nw >= (1L << 22);
 }
 
+// panel shape of the per-line stream kernel: stride W (chunks) and steps K per wave
+static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
+{
+    const ExpandTuning &tune = tuning();
+    *stride = flat_stride(nw, chunks, tune.stream_waves);
+    *steps = tune.stream_steps;
+}
+
 // readable records the stream expansion may touch behind the last line (the caller also keeps ONE in front)
 long expand_stream_tail_pad_records(int nw, long nA)
 {
     if (!stream_uses_flat(nw, nA, false)) return 0;
-    const long stride = flat_stride(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK, tuning().stream_waves);
-    return stride * CHUNK / nw + 4;       // one step of prefetch (da lines) + wrap record + slack
+    long stride;
+    int steps;
+    stream_panel_shape(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK, &stride, &steps);
+    return 2 * (stride * CHUNK / nw) + 4;       // one step of prefetch (da lines) + wrap record + slack
 }
 
 static int launch_expand_stream_flat(const gort_canopy *canopy_dev, const double *L_dev, int nw,
                                      const double *coef_dev, long nA, double *rsurf_dev, int *xcd_slots_dev,
                                      const int *direct_flag_dev, hipStream_t s)
 {
+    (void)canopy_dev;
     const ExpandTuning &tune = tuning();
     const long n_total = nA * (long)nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(rsurf_dev) / sizeof(double)) % CHUNK);
     const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
-    const long stride = flat_stride(nw, chunks, tune.stream_waves);
-    // this kernel is bound by its arithmetic, not by the XCDs' write rates: equal duty
+    long stride;
+    int steps;
+    stream_panel_shape(nw, chunks, &stride, &steps);
+    const long panels = (chunks + (long)steps * stride - 1) / ((long)steps * stride);
+    if (panels * stride >= (1L << 31) || chunks >= (1L << 31) || stride * CHUNK >= (1L << 30))
+        return fail(GORT_EINVAL, "stream expansion: %ld chunks in %ld waves is beyond the kernel's 32-bit indices", chunks,
+                    panels * stride);
+    const int da = (int)(stride * CHUNK / nw);
     const int xcd_mode = resolve_xcd_mode(xcd_slots_dev);
-    const long useful = (stride + 3) / 4;
+    const long useful = (panels * stride + 3) / 4;
     XcdDuty duty;
-    const dim3 grid((unsigned)plan_xcd_duty(xcd_mode, useful, nullptr, duty));
+    const long nblocks = plan_xcd_duty(xcd_mode, useful, nullptr, duty);
+    if (nblocks >= (1L << 31)) return fail(GORT_EINVAL, "stream expansion: %ld workgroups in one launch", nblocks);
+    const dim3 grid((unsigned)nblocks);
     if (tune.nt)
-        hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev, direct_flag_dev);
+        hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, L_dev, nw, coef_dev, n_total, shift, stride,
+                           da, steps, make_fast_div((unsigned)stride), make_fast_div((unsigned)nw), rsurf_dev, xcd_mode, duty,
+                           useful, xcd_slots_dev, direct_flag_dev);
     else
-        hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, canopy_dev, L_dev, nw, coef_dev,
-                           n_total, shift, stride, rsurf_dev, xcd_mode, duty, useful, xcd_slots_dev, direct_flag_dev);
+        hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, L_dev, nw, coef_dev, n_total, shift, stride,
+                           da, steps, make_fast_div((unsigned)stride), make_fast_div((unsigned)nw), rsurf_dev, xcd_mode, duty,
+                           useful, xcd_slots_dev, direct_flag_dev);
     return check_launch("expand_flat_stream_kernel");
 }
 

@@ -155,6 +155,108 @@ __device__ inline SunTerms sun_terms(const double *__restrict__ L, int nw, int i
     return sun_terms(load_band(L, nw, i), s, ko, kep);
 }
 
+// ---- the STREAM family's form of a sample ---------------------------------------------------------------------
+// rsurf is linear in everything but the two numbers p_df and t'_df (gortt_brdf.c:616-634, 348-365), the only ones in
+// which sun zenith and band meet non-linearly.  Regrouping gortt.c:484-557 around them,
+//
+//   rsurf = alpha p_df + (P1 mgk + P2 rs) t'_df + (Q1 mgk + Q2 rs + Q3 Zf + Q4 Tf + Q5 p_ff + Q6 B)
+//
+// with NINE scalars per line (alpha .. Q6, line_terms) and six band constants, costs ~24 instructions + one
+// division per sample instead of the ~54 of sun_terms() + dot5(): the per-line stream kernel is fp64-VALU bound.
+// Every kernel that expands a STREAM (per line, grouped by sun zenith, band-major, per sample) evaluates exactly
+// these functions, written with explicit FMAs and without contraction so that all of them produce the same bits;
+// the LUT family keeps the five (sun zenith, band) terms and dot5().  The two families differ by rounding only
+// (a few 1e-16 relative; both are held to 1e-9 against the reference).
+struct LineTerms { double alpha, P1, P2, Q1, Q2, Q3, Q4, Q5, Q6, mu, t0, omtp0, m2; };
+constexpr int LINE_NTERMS = 13;                // <= GORT_COEF_STRIDE: a LineTerms record is what layout 1 of the stream records holds
+
+__device__ inline LineTerms line_terms(double aC, double aB, double aZ, double aG, double aT, double fd, double mu,
+                                       double t0, double tp0, double eps, double kep, double kk)
+{
+#pragma clang fp contract(off)
+    LineTerms l;
+    const double omfd = 1.0 - fd;
+    const double cfk = (aC * omfd) * kep;                 // aC (1-fd) k_openep
+    const double Zc = __builtin_fma(cfk, 1.0 - kk, aZ);   // what multiplies Z in the end
+    const double sCT = aC + aT;
+    l.alpha = aC * fd;
+    l.P1 = fd * sCT;
+    l.P2 = Zc * fd;
+    l.Q1 = tp0 * l.P1;
+    l.Q2 = __builtin_fma(l.P2, eps, __builtin_fma(cfk, kk, aG));
+    l.Q3 = Zc * omfd;
+    l.Q4 = omfd * sCT;
+    l.Q5 = aC * omfd;
+    l.Q6 = aB;
+    l.mu = mu;
+    l.t0 = t0;
+    l.omtp0 = 1.0 - tp0;
+    l.m2 = 1.0 + 2.0 * mu;
+    return l;
+}
+
+struct StreamBand { double g2, c1, c2, Rff, Tff, tff, pff, rs, mgk, Zf, Tf, B; };
+
+__device__ inline StreamBand stream_band(const BandTerms &t)
+{
+#pragma clang fp contract(off)
+    StreamBand b;
+    b.g2 = 2.0 * t.gam;
+    b.c1 = 1.0 - t.gam;
+    b.c2 = t.omega / 2.0;
+    b.Rff = t.Rff;  b.Tff = t.Tff;  b.tff = t.tff;  b.pff = t.pff;
+    b.rs = t.rs;    b.mgk = t.mgk;  b.Zf = t.Zf;    b.Tf = t.Tf;   b.B = t.B;
+    return b;
+}
+
+// p_df and t'_df of (sun zenith, band): R_df = (1-gamma)/(1+2 mu gamma), T_df = (omega/2)(1+2mu)(T_ff - t0)/(1-(2 gamma mu)^2)
+// (gortt_brdf.c:552, 467-471) share one division: 1/(1-x^2), x = 2 gamma mu
+__device__ __forceinline__ void sun_pair(const StreamBand &b, double mu, double t0, double omtp0, double m2, double &pdf,
+                                         double &tpdf)
+{
+#pragma clang fp contract(off)
+    const double x = b.g2 * mu;
+#ifdef GORT_IEEE_DIV
+    const double inv = 1.0 / __builtin_fma(-x, x, 1.0);
+#else
+    // v_rcp_f64 + two Newton steps instead of the correctly rounded division sequence: ~8 instead of ~14 issue slots of
+    // the ~38 per sample of the per-line kernel (1 048 576 lines: 3.76 -> 3.40 ms), at most an ulp or two off - the
+    // same function in every stream kernel, so the same bits everywhere; x = 1 (2 gamma mu = 1) is singular either way
+    const double den = __builtin_fma(-x, x, 1.0);
+    double inv = __builtin_amdgcn_rcp(den);
+    inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
+    inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
+#endif
+    const double Rdf = (b.c1 * (1.0 - x)) * inv;
+    const double Tdf = ((b.c2 * m2) * (b.Tff - t0)) * inv;
+    const double X = __builtin_fma(b.Rff, Tdf, t0 * Rdf);
+    pdf = __builtin_fma(-b.tff, X, Rdf);                  // gortt_brdf.c:628-630
+    tpdf = __builtin_fma(-b.pff, X, Tdf) * omtp0;         // :423-424, :361
+}
+
+__device__ __forceinline__ double stream_sample(double alpha, double P1, double P2, double Q1, double Q2, double Q3,
+                                                double Q4, double Q5, double Q6, const StreamBand &b, double pdf, double tpdf)
+{
+    const double lin = __builtin_fma(Q6, b.B, __builtin_fma(Q5, b.pff, __builtin_fma(Q4, b.Tf, __builtin_fma(Q3, b.Zf,
+                       __builtin_fma(Q2, b.rs, Q1 * b.mgk)))));
+    const double W = __builtin_fma(P2, b.rs, P1 * b.mgk);
+    return __builtin_fma(alpha, pdf, __builtin_fma(W, tpdf, lin));
+}
+
+__device__ __forceinline__ double stream_sample(const LineTerms &l, const StreamBand &b)
+{
+    double pdf, tpdf;
+    sun_pair(b, l.mu, l.t0, l.omtp0, l.m2, pdf, tpdf);
+    return stream_sample(l.alpha, l.P1, l.P2, l.Q1, l.Q2, l.Q3, l.Q4, l.Q5, l.Q6, b, pdf, tpdf);
+}
+
+// the line terms of a classic record (narrow kernels derive them on the fly; the wide ones read them precomputed)
+__device__ inline LineTerms line_terms_of_record(const double *__restrict__ rec, double kep, double ko)
+{
+    return line_terms(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], rec[S_FD], rec[S_MU], rec[S_T0], rec[S_TP0],
+                      rec[S_EPS], kep, kep + ko);
+}
+
 __device__ inline SunScalars load_sun(const double *__restrict__ rec)
 {
     SunScalars s;

@@ -59,8 +59,10 @@ int launch_member_spectra(const gort_leaf_soil *leaf_dev, int n_members, int nw,
 const float *prospect_coeff_table();      // [7][2101]
 const double *price_eof_table();          // [4][421]
 void interface_transmissivity_tables(const double **t12, const double **talf);   // [2101] each
+// layout 0: classic records (CoefSlot); 1: the stream family's LineTerms (gort_device.h), what the WIDE stream
+// expansions read (launch_expand_stream with a stream for which expand_stream_workspace() returns true)
 int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA,
-                           double *coef_dev, double *K_dev, void *stream);
+                           double *coef_dev, double *K_dev, int layout, void *stream);
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream);
@@ -100,12 +102,14 @@ long expand_stream_tail_pad_records(int nw, long nA);
 // Wide streams without component spectra are expanded line group by line group (gort_stream.hip): device
 // workspace of expand_stream_workspace() bytes (0 = that form does not apply), angles_dev = the lines themselves.
 // Without workspace (or GORT_STREAM_GROUP=0) every line gets its own sun terms.  Returns whether the stream is
-// wide enough for the flat forms at all.  coef_ready_event (hipEvent_t or null): the records are being written on
-// another stream; `stream` waits for the event before its first kernel that reads them.
+// wide enough for the flat forms at all (its records must then be in layout 1).  coef_ready_event (hipEvent_t or null):
+// the records are being written on another stream; `stream` waits for the event before its first kernel that reads
+// them.  grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's
+// five-term sample, so that every LUT path writes the same bits.
 bool expand_stream_workspace(int nw, long nA, bool want_scomp, size_t *ws_bytes, size_t *sun_bytes);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
                          const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev,
-                         void *group_ws_dev, double *group_sun_dev, void *stream, void *coef_ready_event);
+                         void *group_ws_dev, double *group_sun_dev, void *stream, void *coef_ready_event, bool grid_form);
 // gort_stream.hip
 bool stream_group_enabled();
 void stream_group_workspace(int nw, long nA, size_t *ws_bytes, size_t *sun_bytes);

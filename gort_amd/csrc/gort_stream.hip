@@ -10,11 +10,11 @@
 //                         listed per zenith, the lists cut into items of <= M lines, and every zenith entered
 //                         in a global dictionary whose slot is the row of the sun table.  No global atomics on
 //                         the lines themselves: a skewed stream (one sun zenith) costs the same as a flat one.
-//   stream_sun_kernel     sun[slot][5][nw] for the occupied slots - sun_terms() exactly as the LUT path.
+//   stream_sun_kernel     sun[slot][2][nw] = p_df, t'_df for the occupied slots (sun_pair, the stream family's form).
 //   expand_stream_grouped_kernel
-//                         wave = (item, 128-double segment of the row).  The five terms of the segment's bands
-//                         stay in registers for all lines of the item; per line 5 FMAs per sample, from the
-//                         line's five coefficients (preloaded, one line per lane, read back with v_readlane).
+//                         wave = (item, 112-position segment of the row).  p_df, t'_df and six band constants of the
+//                         segment's bands stay in registers for all lines of the item; per line 10 FMAs per sample
+//                         from the line's nine terms (scalar cache, one line ahead).
 //                         A row starts s = (line * nw) mod 16 doubles past a 128-B boundary, different for every
 //                         line, so the values are rotated by s through a wave-private LDS strip (the wave also
 //                         evaluates the 16 bands in front of its segment) and leave as whole 128-B lines:
@@ -39,6 +39,7 @@ constexpr int GRP_GSLOTS = 1024;     // global dictionary = rows of the sun tabl
 constexpr int GRP_GMAX = 512;        // distinct sun zeniths per call
 constexpr int GRP_THREADS = 1024;
 constexpr int GRP_LPT = 4;           // lines per thread of stream_group_kernel: tiles of up to 4096 lines
+constexpr int SUN_NTERMS = 2;        // (sun zenith, band) numbers of the stream family's sample: p_df, t'_df
 constexpr int SEG = 128;             // bands a wave evaluates per line
 constexpr int SEGP = 112;            // positions a wave stores per line: seven 128-B lines
 constexpr int HALO = 16;             // doubles a row may start past a 128-B boundary (exclusive)
@@ -213,7 +214,9 @@ __global__ __launch_bounds__(GRP_THREADS) void stream_group_kernel(const double 
     if (tid == 0) n_items[tile] = total_items;
 }
 
-// sun[slot][5][nw] for every occupied slot of the global dictionary (blockIdx.y, blockIdx.y + gridDim.y, ...)
+// sun[slot][2][nw] = p_df, t'_df (sun_pair, gort_device.h) for every occupied slot of the global dictionary
+// (blockIdx.y, blockIdx.y + gridDim.y, ...); the scalars mu, t0, 1 - t'0, 1 + 2 mu are formed from the zenith exactly
+// as line_terms() forms them from a line's record
 __global__ __launch_bounds__(256) void stream_sun_kernel(const gort_canopy *__restrict__ canopy,
                                                           const double *__restrict__ L, int nw,
                                                           const unsigned long long *__restrict__ gkeys,
@@ -222,20 +225,19 @@ __global__ __launch_bounds__(256) void stream_sun_kernel(const gort_canopy *__re
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (flags[0] != -1 || i >= nw) return;
     const gort_canopy &c = *canopy;
-    BandTerms t;
+    StreamBand t;
     bool have = false;
     for (int slot = blockIdx.y; slot < GRP_GSLOTS; slot += gridDim.y) {
         const unsigned long long key = gkeys[slot];
         if (key == KEY_EMPTY) continue;
-        if (!have) { t = load_band(L, nw, i); have = true; }
+        if (!have) { t = stream_band(load_band(L, nw, i)); have = true; }
         const SunScalars s = sun_from_zenith(c, __longlong_as_double((long long)key));
-        const SunTerms b = sun_terms(t, s, c.k_open, c.k_openep);
-        double *o = sun + (long)slot * 5 * nw;
-        o[0 * nw + i] = b.C0;
-        o[1 * nw + i] = b.B;
-        o[2 * nw + i] = b.Z;
-        o[3 * nw + i] = b.G;
-        o[4 * nw + i] = b.T;
+        const LineTerms l = line_terms(0.0, 0.0, 0.0, 0.0, 0.0, s.fd, s.mu, s.t0, s.tp0, s.eps, c.k_openep, c.k_openep + c.k_open);
+        double pdf, tpdf;
+        sun_pair(t, l.mu, l.t0, l.omtp0, l.m2, pdf, tpdf);
+        double *o = sun + (long)slot * SUN_NTERMS * nw;
+        o[i] = pdf;
+        o[nw + i] = tpdf;
     }
 }
 
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256) void stream_sun_kernel(const gort_canopy *__re
 // the wave's strip holds band 112 seg - 16 + i at index i.
 template <bool NT>
 __global__ __launch_bounds__(256) void expand_stream_grouped_kernel(const double *__restrict__ sun,
+                                                                     const double *__restrict__ L,
                                                                      const double *__restrict__ coef, int nw,
                                                                      const int *__restrict__ flags,
                                                                      const int *__restrict__ n_items,
@@ -288,32 +291,39 @@ __global__ __launch_bounds__(256) void expand_stream_grouped_kernel(const double
 
     // the item's lines, one per lane (read back with v_readlane: no dependent scalar load per line)
     const int my_line = order[it.first + (lane < count ? lane : 0)];
-    // sun terms of the wave's 128 bands, two per lane
-    const double *__restrict__ sp = sun + (long)slot * 5 * nw;
+    // the wave's 128 bands, two per lane: p_df, t'_df of the item's sun zenith and the six band constants of the
+    // stream family's sample (gort_device.h)
+    const double *__restrict__ sp = sun + (long)slot * SUN_NTERMS * nw;
     const int band0 = seg * SEGP - HALO + 2 * lane;
-    double t[2][5];
+    StreamBand t[2];
+    double pdf[2], tpdf[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int bj = band0 + j;
         const bool ok = bj >= 0 && bj < nw;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) t[j][q] = ok ? sp[(long)q * nw + bj] : 0.0;
+        t[j] = stream_band(load_band(L, nw, ok ? bj : 0));
+        pdf[j] = ok ? sp[bj] : 0.0;
+        tpdf[j] = ok ? sp[(long)nw + bj] : 0.0;
     }
     double *strip = s_strip[wv];
     const int nw16 = nw & 15;
     const int p0 = seg * SEGP + 2 * lane;                    // position in a row's aligned image (lanes < 56 store)
     const bool storer = lane < SEGP / 2;
-    // the five coefficients of a line come through the scalar cache, one line ahead
+    // the nine line terms come through the scalar cache (records in layout 1), one line ahead
     int a = __builtin_amdgcn_readlane(my_line, 0);
     const double *__restrict__ rec = coef + (long)a * GORT_COEF_STRIDE;
-    double c0 = rec[A_C], c1 = rec[A_B], c2 = rec[A_Z], c3 = rec[A_G], c4 = rec[A_T];
+    double c[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) c[q] = rec[q];
     for (int i = 0; i < count; ++i) {
         const int a_next = __builtin_amdgcn_readlane(my_line, i + 1 < count ? i + 1 : i);
         const double *__restrict__ rn = coef + (long)a_next * GORT_COEF_STRIDE;
-        const double n0 = rn[A_C], n1 = rn[A_B], n2 = rn[A_Z], n3 = rn[A_G], n4 = rn[A_T];
+        double n[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) n[q] = rn[q];
         dbl2 v;
-        v.x = dot5(c0, c1, c2, c3, c4, t[0][0], t[0][1], t[0][2], t[0][3], t[0][4]);
-        v.y = dot5(c0, c1, c2, c3, c4, t[1][0], t[1][1], t[1][2], t[1][3], t[1][4]);
+        v.x = stream_sample(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], t[0], pdf[0], tpdf[0]);
+        v.y = stream_sample(c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], t[1], pdf[1], tpdf[1]);
         *reinterpret_cast<dbl2 *>(strip + 2 * lane) = v;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -344,7 +354,8 @@ __global__ __launch_bounds__(256) void expand_stream_grouped_kernel(const double
             }
         }
         a = a_next;
-        c0 = n0;  c1 = n1;  c2 = n2;  c3 = n3;  c4 = n4;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) c[q] = n[q];
     }
 }
 
@@ -353,7 +364,6 @@ struct GroupTuning {
     int tile = 2048, lines_per_item = 32;
     GroupTuning()
     {
-        if (const char *v = getenv("GORT_STREAM_GROUP")) enabled = atoi(v) != 0;
         if (const char *v = getenv("GORT_STREAM_TILE")) tile = atoi(v);
         if (const char *v = getenv("GORT_STREAM_ITEM")) lines_per_item = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_NT")) nt = atoi(v) != 0;
@@ -418,7 +428,7 @@ void stream_group_workspace(int nw, long nA, size_t *ws_bytes, size_t *sun_bytes
     *sun_bytes = 0;
     if (!group_tuning().enabled || nw < SEG || nA <= 0 || nA >= (1L << 31)) return;
     *ws_bytes = group_layout(nA).bytes;
-    *sun_bytes = sizeof(double) * 5 * (size_t)nw * GRP_GSLOTS;
+    *sun_bytes = sizeof(double) * SUN_NTERMS * (size_t)nw * GRP_GSLOTS;
 }
 
 // Everything of the grouped form on `stream`: dictionary + lists, sun table, expansion.  *direct_flag_dev is the
@@ -458,11 +468,11 @@ int launch_expand_stream_grouped(const gort_canopy *canopy_dev, const double *L_
     const int shift0 = (int)((reinterpret_cast<uintptr_t>(rsurf_dev) / sizeof(double)) % 16);
     const FastDiv dt = fast_div_for((unsigned)per_tile), dq = fast_div_for((unsigned)nq);
     if (group_tuning().nt)
-        hipLaunchKernelGGL(expand_stream_grouped_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, sun_dev, coef_dev,
+        hipLaunchKernelGGL(expand_stream_grouped_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, sun_dev, L_dev, coef_dev,
                            nw, flags, n_items, items, order, g.n_tiles, tiles_per_xcd, g.max_items, nq, dt, dq, shift0,
                            rsurf_dev);
     else
-        hipLaunchKernelGGL(expand_stream_grouped_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, sun_dev, coef_dev,
+        hipLaunchKernelGGL(expand_stream_grouped_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, sun_dev, L_dev, coef_dev,
                            nw, flags, n_items, items, order, g.n_tiles, tiles_per_xcd, g.max_items, nq, dt, dq, shift0,
                            rsurf_dev);
     return launch_ok("expand_stream_grouped_kernel");

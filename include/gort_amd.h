@@ -186,15 +186,18 @@ int  gort_rsurf_stream(gort_engine *e, const double *angles, long nA,
 int  gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA,
                            double *rsurf_dev, double *scomp_dev, double *K_dev);
 
-/* Wide streams (>= 4M samples, >= 128 bands, no component spectra) are expanded in one of two forms, chosen on
- * the device per call: lines grouped by sun zenith (few distinct sun zeniths: the five (sun zenith, band) terms
- * are shared, 5 FMAs per sample) or per-line sun terms (every line its own sun zenith).  Same bits either way.
+/* Wide streams (>= 4M samples, >= 128 bands, no component spectra) are expanded in one of two forms that write the
+ * same bits (and the same bits as the narrow-stream kernels): per line (every line forms p_df, t'_df of its own sun
+ * zenith: ~24 instructions + a reciprocal per sample; the default, and the faster one up to ~1M lines) or with the
+ * lines grouped by sun zenith on the device (few distinct sun zeniths: the two numbers are shared, 10 FMAs per
+ * sample; falls back to per line on the device when a stream has too many).
  *   gort_engine_stream_form         form of the last gort_rsurf_stream[_dev] call: 0 = narrow stream (other
  *                                   kernels), 1 = grouped, 2 = per line; synchronises the engine's stream
- *   gort_engine_set_stream_grouping 0 = always per line (also GORT_STREAM_GROUP=0), 1 = automatic (default);
- *                                   automatic: after a call whose lines had too many distinct sun zeniths the next
- *                                   15 calls go per line without trying (streams are mostly of one kind);
- *                                   calling this function forgets that history
+ *   gort_engine_set_stream_grouping 0 = per line (default), 1 = group streams of >= 200 000 lines
+ *                                   (GORT_STREAM_GROUP_MIN), 2 = group whenever the stream allows it; also
+ *                                   GORT_STREAM_GROUP=0|1|2.  In modes 1 and 2, after a call whose lines had too many
+ *                                   distinct sun zeniths the next 15 calls go per line without trying; calling this
+ *                                   function forgets that history
  *   gort_engine_last_stream_ms      duration (ms, HIP events on the engine's stream) of the expansion stage of
  *                                   the last stream call - grouping, sun table and expansion kernels; <0 if none.
  * New surface for tests and bench tools, not reference surface. */

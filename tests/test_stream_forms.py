@@ -1,5 +1,6 @@
 """The two forms of the wide-stream expansion (gort_amd/csrc/gort_stream.hip): lines grouped by sun zenith and
-per-line sun terms must write the SAME BITS, equal the LUT path on grid angles and agree with the oracle.
+per-line sun terms must write the SAME BITS (as must the narrow stream kernels: tests/test_pipe_and_cli.py compares
+chunked with whole streams), agree with the LUT path on grid angles to rounding and with the oracle to 1e-9.
 
 Reference interface: the per-line loop of main(), gortt.c:232-329 (+ gortt_rsurf, gortt.c:385-578)."""
 import numpy as np
@@ -34,12 +35,12 @@ def _run(eng, torch, ang, nw, grouping, out=None):
     a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
     if out is None:
         out = torch.full((ang.shape[0], nw), -7.0, dtype=torch.float64, device="cuda")
-    eng.set_stream_grouping(grouping)
+    eng.set_stream_grouping(2 if grouping else 0)      # 2: group whenever possible (automatic mode has a size threshold)
     torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
     eng.rsurf_stream_dev(a, out)
     eng.synchronize()
     form = eng.stream_form()
-    eng.set_stream_grouping(True)
+    eng.set_stream_grouping(0)
     return out, form
 
 
@@ -150,8 +151,9 @@ def test_too_many_sun_zeniths_fall_back_on_the_device(setup):
 
 
 def test_grid_lines_through_the_stream_equal_the_lut(setup):
-    """The metric grid's angles (a slab of it) streamed as lines `vza phi sza 0`: grouped stream == LUT kernel, bit for bit
-    (both take their sun terms from sun_terms() and expand with dot5())."""
+    """The metric grid's angles (a slab of it) streamed as lines `vza phi sza 0`: the stream family (regrouped sample:
+    alpha p_df + W t'_df + linear part) against the LUT family (five terms, dot5) - the same numbers up to rounding of
+    two different associations: 1e-13 relative."""
     eng, c, torch = setup
     wl = np.arange(400.0, 2501.0)
     eng.set_spectra(*api.spectra(wl))
@@ -164,4 +166,4 @@ def test_grid_lines_through_the_stream_equal_the_lut(setup):
     ang = np.array([[float(r % 91), float(l), float(r // 91), 0.0] for r in rows for l in range(361)])
     s, form = _run(eng, torch, ang, wl.size, True)
     assert form == "grouped"
-    assert _bits_equal(s, lut)
+    assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13

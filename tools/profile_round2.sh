@@ -21,7 +21,7 @@ prof bench_stats --kernel-trace --stats --output-format csv -d "$OUT/bench_stats
 prof bench_pmc_write --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_pmc_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0
 prof bench_pmc_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0
 # ---- B
-for c in 91 all; do
+for c in 91 all; do      # bench_stream.py runs every case in both forms: per line (default) and grouped (mode 2)
   prof stream_${c}_stats --kernel-trace --stats --output-format csv -d "$OUT/stream_${c}_stats" -- python3 "$R/tools/bench_stream.py" 65536 20 "$c"
   prof stream_${c}_pmc_write --pmc WRITE_SIZE --output-format csv -d "$OUT/stream_${c}_pmc_write" -- python3 "$R/tools/bench_stream.py" 65536 3 "$c"
   prof stream_${c}_pmc_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/stream_${c}_pmc_fetch" -- python3 "$R/tools/bench_stream.py" 65536 3 "$c"
