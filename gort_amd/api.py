@@ -68,7 +68,7 @@ PIPE_SCOMP, PIPE_ENERGY, PIPE_ENERGY_ONLY = 1, 2, 4
 DECLARED_SYMBOLS = [
     "gort_last_error", "gort_version", "gort_canopy_defaults", "gort_leaf_soil_defaults",
     "gort_canopy_newstyle", "gort_canopy_set_lai", "gort_canopy_init", "gort_price_soil",
-    "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_format_f6", "gort_lut_format", "gort_lut_read",
+    "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_format_f6", "gort_format_f6_row", "gort_lut_format", "gort_lut_read",
     "gort_device_count", "gort_dev_malloc", "gort_dev_free", "gort_memcpy_h2d", "gort_memcpy_d2h",
     "gort_gap_probabilities", "gort_gap_probabilities_dev",
     "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",

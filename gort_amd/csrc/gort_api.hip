@@ -513,7 +513,7 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     const size_t coef_bytes = sizeof(double) * GORT_COEF_STRIDE * (size_t)(nA + 1 + tail);
     const bool fresh = coef_bytes > e->coef.cap;
     if ((rc = e->coef.reserve(coef_bytes))) return rc;
-    if (fresh) GORT_HIP(hipMemsetAsync(e->coef.p, 0, coef_bytes, e->stream));      // pads hold finite values
+    if (fresh) GORT_HIP(hipMemsetAsync(e->coef.p, 0, coef_bytes, e->stream));      // pads: readable, contents don't-care (padded lanes are never stored)
     double *coef = e->coef.as<double>() + GORT_COEF_STRIDE;
     int *xcd_slots = nullptr;
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
@@ -819,7 +819,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     }
     const bool fresh = coef_bytes > coef_buf.cap;
     if ((rc = coef_buf.reserve(coef_bytes))) return rc;
-    if (fresh) GORT_HIP(hipMemsetAsync(coef_buf.p, 0, coef_bytes, gs));      // pads hold finite values
+    if (fresh) GORT_HIP(hipMemsetAsync(coef_buf.p, 0, coef_bytes, gs));      // pads: readable, contents don't-care (padded lanes are never stored)
     double *coef8 = coef_buf.as<double>() + 8;
     if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, coef8, true, gs))) return rc;
     if ((rc = sun_buf.reserve(sun_bytes))) return rc;

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 // n_total = angles x nw doubles.  HBM3E on this part sustains its write rate only when
 // every wave store covers whole 128-B lines: a plain 8-B-per-lane fill of the 50 GB slab
 // runs at 6.5 TB/s when its wave stores are 512-B aligned and at 3.2 TB/s when they start
-// 8 B off (tools/store_probe.hip) - and with nw = 2101 (odd) any band-major mapping is
+// 8 B off (tools/probes/store_probe.hip) - and with nw = 2101 (odd) any band-major mapping is
 // 8-B aligned at best.  So the slab is cut into 1-KiB chunks (128 doubles) aligned in
 // ABSOLUTE address, one chunk per wave-step (16 B per lane, one global_store_dwordx4),
 // and a wave takes chunks c, c + W, c + 2W, ... where the stride W (in chunks) is a
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(THREADS) void expand_grid_kernel(const double *__re
 //
 // Everything that moves per step is wave-uniform and lives in SGPRs: the chunk's output
 // address and the address of the angle record, whose five coefficients arrive through
-// the scalar cache (tools/store_probe2.hip: one scalar record per 1-KiB step costs 2 %,
+// the scalar cache (tools/probes/store_probe2.hip: one scalar record per 1-KiB step costs 2 %,
 // per 512-B step 30 %).  In ~6 % of the waves (nw = 2101) the band index wraps inside
 // the chunk, i.e. the chunk spans two angles: those waves fetch both records and each
 // element picks its own.  The coefficient buffer carries one pad record in front and a
@@ -802,6 +802,7 @@ __device__ __forceinline__ void flat_stream_loop(const StreamBand (&t)[EPL], con
     }
 }
 
+// 70 VGPRs, 7 waves/SIMD.  Forcing 8 (amdgpu_waves_per_eu) spills 68 B per lane to scratch and halves the rate.
 template <bool NT>
 __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const double *__restrict__ L, int nw,
                                                                   const double *__restrict__ coef, long n_total,
@@ -1107,7 +1108,7 @@ struct ExpandTuning {
     long waves = 2048;
     // the per-line stream kernel is VALU bound with a heavy prologue (24 band constants per lane): long waves.  Panels
     // of 64 steps x 33616 waves (2.2 GB per panel; streams up to 131 072 lines are ONE panel): 65 536 lines 232-290 us
-    // whatever the shape, 1 048 576 lines 3.76 ms against 3.83 (one panel) and 4.0-5.0 (8..16 steps), tools/dbg/perline_sweep.sh
+    // whatever the shape, 1 048 576 lines 3.76 ms against 3.83 (one panel) and 4.0-5.0 (8..16 steps), tools/probes/perline_sweep.sh
     long stream_waves = 32768;      // GORT_STREAM_WAVES: waves per panel of the per-line stream kernel (rounded like `waves`)
     int stream_steps = 64;          // GORT_STREAM_STEPS: steps per wave = panel height of the per-line stream kernel
     ExpandTuning()
@@ -1294,7 +1295,7 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
     int rc = GORT_OK;
     // ONE pass with equal weights: the rates of the XCDs while all of them run.  Iterating on the result drives
     // the slow XCDs' weights further down (to 25/32), which suits this bare store pattern but not the LUT kernel
-    // (tools/weights_sweep.py: 27-28 is its optimum, 25 already loses half the gain).
+    // (tools/probes/weights_sweep.py: 27-28 is its optimum, 25 already loses half the gain).
     for (int iter = 0; iter < 1 && rc == GORT_OK; ++iter) {
         XcdDuty duty;
         const long grid = plan_xcd_duty(1, useful, weights, duty);
@@ -1336,7 +1337,7 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
     // What is being measured is a trait of the device - the XCDs of one XCC_ID parity write ~15 % slower than the
     // others on every MI355X seen so far (the odd XCC_IDs in every standalone probe, the even dispatch slots in one process) - under a few % of
     // run-to-run noise, and a weight that is off by one
-    // costs more than it gains (tools/weights_sweep.py).  So the eight results are averaged within each parity.
+    // costs more than it gains (tools/probes/weights_sweep.py).  So the eight results are averaged within each parity.
     if (rc == GORT_OK) {
         double mean[2] = {0.0, 0.0};
         for (int x = 0; x < 8; ++x) mean[x & 1] += 0.25 * weights[x];

@@ -273,7 +273,7 @@ __device__ inline SunScalars load_sun(const double *__restrict__ rec)
 //           The XCDs do not write equally fast - on the parts measured the XCDs of one parity (the odd XCC_IDs in
 //           every standalone probe; the even dispatch slots in one process) sustain ~80 % of the others, and a launch ends with its slowest XCD - so XCD x uses only w[x] of every 32 of its
 //           workgroups (the others return at once) and owns a range of logical blocks in proportion
-//           (calibrate_xcd_weights; tools/xcd_stream_probe.hip: 7.06 -> 6.70 ms for the 50 GB slab).
+//           (calibrate_xcd_weights; tools/probes/xcd_stream_probe.hip: 7.06 -> 6.70 ms for the 50 GB slab).
 //   mode 2  dynamic: read the XCD the workgroup really runs on (HW_REG_XCC_ID) and take the next free slot of
 //           that XCD's range with one returning atomic; if the range is used up take one from the next XCD.
 //           The ranges sum to the grid, so every workgroup finds a slot within 8 tries.  The launcher zeroes

@@ -356,37 +356,110 @@ extern "C" void gort_gauleg(double x1, double x2, double *x, double *w, int n)
 // ------------------------------------------------------------------ "%f" formatter
 
 // printf("%f") is where the text boundary spends its time (hundreds of MB of digits per
-// second of GPU work).  For |v| < 9e12 the value times 1e6 is formed exactly as a double
+// second of GPU work).  For |v| < 4e9 the value times 1e6 is formed exactly as a double
 // plus an FMA error term, rounded to an integer with ties to even exactly as glibc rounds
 // the decimal expansion, and the digits are emitted by hand; anything else goes to snprintf.
-extern "C" int gort_format_f6(double v, char *dst)
+namespace {
+
+const char DIGIT_PAIRS[201] =
+    "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+    "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
+
+// round(|v| * 1e6) with ties to even on the EXACT product: av * 1e6 = p + e with p < 2^52, so ulp(p) <= 0.5 and
+// |e| <= ulp(p)/2; p - n is exact and a multiple of ulp(p): unless it is exactly +-0.5 the error term cannot move the
+// value across a rounding boundary; at +-0.5 the sign of e decides, e == 0 is a true tie
+#define GORT_ROUND_E6_BODY                                    \
+    const double p = av * 1.0e6;                              \
+    const double e = __builtin_fma(av, 1.0e6, -p);            \
+    double n = __builtin_nearbyint(p);                        \
+    const double a = p - n;                                   \
+    if (a == 0.5) { if (e > 0.0) n += 1.0; }                  \
+    else if (a == -0.5) { if (e < 0.0) n -= 1.0; }            \
+    return (unsigned long long)n;
+
+inline unsigned long long round_e6_generic(double av) { GORT_ROUND_E6_BODY }
+// the same with hardware FMA and ROUNDSD instead of two libm calls per value (every host of an MI355X has them;
+// checked once at run time)
+__attribute__((target("fma,sse4.1"))) inline unsigned long long round_e6_fma(double av) { GORT_ROUND_E6_BODY }
+
+inline char *emit_f6(unsigned long long q, bool neg, char *o)
+{
+    const unsigned long long ip = q / 1000000ULL;
+    const unsigned frac = (unsigned)(q - ip * 1000000ULL);
+    if (neg) *o++ = '-';
+    if (ip < 10) {
+        *o++ = (char)('0' + ip);
+    } else {
+        char tmp[24];
+        int k = 0;
+        unsigned long long t = ip;
+        do { tmp[k++] = (char)('0' + t % 10); t /= 10; } while (t);
+        while (k) *o++ = tmp[--k];
+    }
+    *o++ = '.';
+    const unsigned hi = frac / 10000u, lo = frac - hi * 10000u, mid = lo / 100u;
+    std::memcpy(o, DIGIT_PAIRS + 2 * hi, 2);
+    std::memcpy(o + 2, DIGIT_PAIRS + 2 * mid, 2);
+    std::memcpy(o + 4, DIGIT_PAIRS + 2 * (lo - mid * 100u), 2);
+    return o + 6;
+}
+
+template <bool FMA> inline int format_f6_one(double v, char *dst)
 {
     if (v != v) { std::memcpy(dst, "-nan", 4); return 4; }
     const double av = std::fabs(v);
     if (!(av < 4.0e9)) return std::snprintf(dst, 352, "%f", v);
-    // exact: av * 1e6 = p + e with p < 2^52, so ulp(p) <= 0.5 and |e| <= ulp(p)/2
-    const double p = av * 1.0e6;
-    const double e = std::fma(av, 1.0e6, -p);
-    double n = std::nearbyint(p);                 // default rounding mode: ties to even
-    // p - n is exact and a multiple of ulp(p): unless it is exactly +-0.5 the error term cannot move
-    // the value across a rounding boundary; at +-0.5 the sign of e decides, e == 0 is a true tie
-    const double a = p - n;
-    if (a == 0.5) { if (e > 0.0) n += 1.0; }
-    else if (a == -0.5) { if (e < 0.0) n -= 1.0; }
-    unsigned long long q = (unsigned long long)n;
-    const unsigned long long ip = q / 1000000ULL;
-    unsigned frac = (unsigned)(q % 1000000ULL);
+    const unsigned long long q = FMA ? round_e6_fma(av) : round_e6_generic(av);
+    return (int)(emit_f6(q, std::signbit(v), dst) - dst);
+}
+
+__attribute__((target("fma,sse4.1"))) long format_row_fma(const double *v, long n, char *dst)
+{
     char *o = dst;
-    if (std::signbit(v)) *o++ = '-';
-    char tmp[24];
-    int k = 0;
-    unsigned long long t = ip;
-    do { tmp[k++] = (char)('0' + t % 10); t /= 10; } while (t);
-    while (k) *o++ = tmp[--k];
-    *o++ = '.';
-    for (int i = 5; i >= 0; --i) { o[i] = (char)('0' + frac % 10); frac /= 10; }
-    o += 6;
-    return (int)(o - dst);
+    for (long i = 0; i < n; ++i) { o += format_f6_one<true>(v[i], o); *o++ = ' '; }
+    return (long)(o - dst);
+}
+
+long format_row_generic(const double *v, long n, char *dst)
+{
+    char *o = dst;
+    for (long i = 0; i < n; ++i) { o += format_f6_one<false>(v[i], o); *o++ = ' '; }
+    return (long)(o - dst);
+}
+
+bool cpu_has_fma()
+{
+    static const bool has = __builtin_cpu_supports("fma") && __builtin_cpu_supports("sse4.1");
+    return has;
+}
+
+}  // namespace
+
+extern "C" int gort_format_f6(double v, char *dst)
+{
+    char tmp[360];
+    const long n = cpu_has_fma() ? format_row_fma(&v, 1, tmp) : format_row_generic(&v, 1, tmp);
+    std::memcpy(dst, tmp, (size_t)(n - 1));          // without the separator
+    return (int)(n - 1);
+}
+
+extern "C" long gort_format_f6_row(const double *v, long n, char *dst, size_t cap)
+{
+    if (!v || !dst || n < 0) return gort::fail(GORT_EINVAL, "gort_format_f6_row: bad argument");
+    // a value below 4e9 takes at most 18 bytes with its separator; larger ones (snprintf) up to 318: go one by one
+    // when the buffer is not roomy enough for the worst case of the whole row
+    if (cap >= (size_t)n * 24) {
+        bool small = true;
+        for (long i = 0; i < n && small; ++i) small = !(std::fabs(v[i]) >= 4.0e9);      // NaN counts as small
+        if (small) return cpu_has_fma() ? format_row_fma(v, n, dst) : format_row_generic(v, n, dst);
+    }
+    long used = 0;
+    for (long i = 0; i < n; ++i) {
+        if (cap - (size_t)used < 360) return gort::fail(GORT_EINVAL, "gort_format_f6_row: buffer too small");
+        used += gort_format_f6(v[i], dst + used);
+        dst[used++] = ' ';
+    }
+    return used;
 }
 
 // ------------------------------------------------------------- probability LUT text

@@ -105,6 +105,9 @@ void gort_gauleg(double x1, double x2, double *x, double *w, int n);
  * ties to even, glibc style), except that every NaN is written as "-nan" - which is what the
  * reference prints for its NaNs on x86 (gortt.c:310-324).  dst needs 352 bytes; returns the length. */
 int  gort_format_f6(double v, char *dst);
+/* n values, each followed by one space (the way a gortt row prints them, gortt.c:314-324); returns the bytes
+ * written or a negative code.  cap >= 24 n is always enough for values below 4e9 in magnitude. */
+long gort_format_f6_row(const double *v, long n, char *dst, size_t cap);
 
 /* probability LUT, text format of `gortt -W` / `gortt -P file`: gortt.c:123-146.
  * gort_lut_format writes into buf (needs <= 16 KiB), returns bytes written or <0. */

@@ -215,3 +215,24 @@ def test_error_codes_are_negative_and_null_handles_fail_cleanly():
     if api.device_count() == 0:
         assert L.gort_set_device(0) == api.ENODEVICE
         assert L.gort_get_device() < 0
+
+
+def test_format_f6_row_equals_single_values():
+    """gort_format_f6_row: n values, each followed by a space, the bytes of printf("%f ") per value - the fast path
+    (hardware FMA + ROUNDSD where the CPU has them) and the one-by-one path for rows with huge values."""
+    import ctypes as C
+    L = api.lib()
+    L.gort_format_f6_row.restype = C.c_long
+    L.gort_format_f6_row.argtypes = [C.c_void_p, C.c_long, C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    rows = [rng.uniform(0, 1, 2101), rng.uniform(-400, 400, 50), np.array([0.0, -0.0, 0.5e-6, 1.5e-6, 2.5e-6, 0.9999995, 3.9999e9]),
+            np.array([np.nan, 1e300, -5e9, 4.0e9, 1.0, np.inf]), np.zeros(0)]
+    for v in rows:
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        buf = C.create_string_buffer(max(24 * v.size + 8, 4096))
+        n = L.gort_format_f6_row(v.ctypes.data_as(C.c_void_p), v.size, buf, len(buf))
+        want = "".join(("-nan" if np.isnan(x) else "%f" % x) + " " for x in v)
+        assert n == len(want) and buf.raw[:n].decode() == want
+    tiny = C.create_string_buffer(16)
+    big = np.array([1e300, 1.0])
+    assert L.gort_format_f6_row(big.ctypes.data_as(C.c_void_p), 2, tiny, len(tiny)) == api.EINVAL

@@ -1,5 +1,5 @@
 #!/bin/bash
-# interleaved A/B of two library builds on the per-line stream kernel: tools/dbg/ab_lib.sh <suffix of variant>
+# interleaved A/B of two library builds on the per-line stream kernel: tools/probes/ab_lib.sh <suffix of variant>
 cd "$(dirname "$0")/../.."
 V=${1:-simple}
 for rep in 1 2 3; do for lib in gort_amd/libgort_amd.so gort_amd/libgort_amd_$V.so; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# build a variant library with extra -D flags: tools/dbg/build_variant.sh <suffix> <flags...>  -> gort_amd/libgort_amd_<suffix>.so
+# build a variant library with extra -D flags: tools/probes/build_variant.sh <suffix> <flags...>  -> gort_amd/libgort_amd_<suffix>.so
 set -e
 cd "$(dirname "$0")/../.."
 SUF=$1; shift

@@ -3,7 +3,7 @@
 # usage: tools/cli_breakdown.sh [lines] [bands]
 set -e
 N=${1:-1000000}; M=${2:-180}
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 python3 - "$N" "$M" <<'PY'
 import sys, numpy as np
 n, m = int(sys.argv[1]), int(sys.argv[2])

@@ -5,7 +5,7 @@
 #   3. rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE, one pass each (TCC slots: MI355X_MICROARCH.md)
 # Outputs under gpurun_out/prof/.  The python program itself follows `--` (no env/bash hop under rocprofv3).
 set -u
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=$R/gpurun_out/prof
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd "$R" && timeout -k 10 300 python3 bench.py > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"; echo "bench rc=$?"
