@@ -235,6 +235,52 @@ bool read_line(FILE *fp, std::string &line)
     return true;
 }
 
+// Angle lines in bulk: stdin is read in 8 MB blocks, lines are found with memchr and NUL-terminated in place (strtod
+// must not run on into the next line) - a getline() per line was half of the text mode's run time.  A last line
+// without a newline counts, as with fgets (gortt.c:232).
+struct LineReader {
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    bool eof = false;
+    LineReader() : buf((8u << 20) + 1) {}
+    // up to max_lines lines: their offsets into buf (valid until the next call); fewer only at end of input
+    long take(FILE *fp, long max_lines, std::vector<size_t> &offsets)
+    {
+        offsets.clear();
+        while ((long)offsets.size() < max_lines) {
+            char *nl = end > pos ? (char *)std::memchr(buf.data() + pos, '\n', end - pos) : nullptr;
+            if (nl) {
+                *nl = '\0';
+                offsets.push_back(pos);
+                pos = (size_t)(nl - buf.data()) + 1;
+                continue;
+            }
+            if (eof) {
+                if (end > pos) {                         // last line, no newline
+                    buf[end] = '\0';
+                    offsets.push_back(pos);
+                    pos = end;
+                }
+                break;
+            }
+            // out of complete lines: keep what is in use (the lines already handed out and the partial one),
+            // make room behind it and read on
+            const size_t base = offsets.empty() ? pos : offsets[0];
+            if (base > 0) {
+                std::memmove(buf.data(), buf.data() + base, end - base);
+                for (size_t &o : offsets) o -= base;
+                pos -= base;
+                end -= base;
+            }
+            if (buf.size() - 1 - end < (4u << 20)) buf.resize(buf.size() * 2 + 1);
+            const size_t got = std::fread(buf.data() + end, 1, buf.size() - 1 - end, fp);
+            end += got;
+            if (got == 0) eof = true;
+        }
+        return (long)offsets.size();
+    }
+};
+
 // "%lf %lf %lf %lf" of the reference's sscanf (gortt.c:234): four numbers, anything after them ignored
 bool parse_angles(const char *s, double v[4])
 {
@@ -550,7 +596,7 @@ int main(int argc, char **argv)
 
     // ---- producer (this thread): reads and parses chunk after chunk into the pipes' pinned slots (gortt.c:232-237) ----
     bool bad_line = false, eof = false;
-    std::string line, text;
+    LineReader reader;
     std::vector<size_t> offsets;
     std::string producer_error;
     long k_chunk = 0;
@@ -571,21 +617,15 @@ int main(int argc, char **argv)
         } else {
             // the chunk's lines are collected NUL-terminated (strtod must not run on into the next line) and
             // parsed by several threads; the first line that does not hold four numbers ends the input there
-            text.clear();
-            offsets.clear();
-            while ((long)offsets.size() < CHUNK) {
-                if (!read_line(stdin, line)) { eof = true; break; }
-                offsets.push_back(text.size());
-                text += line;
-                text.push_back('\0');
-            }
-            const long nl = (long)offsets.size();
+            const long nl = reader.take(stdin, CHUNK, offsets);
+            if (nl < CHUNK) eof = true;
+            const char *text = reader.buf.data();
             const unsigned workers = format_threads((size_t)nl * 64);            // ~4 strtod calls per line
             std::vector<long> first_bad(workers, nl);
             auto parse_lines = [&](unsigned t) {
                 const long a0 = nl * (long)t / workers, a1 = nl * (long)(t + 1) / workers;
                 for (long a = a0; a < a1; ++a)
-                    if (!parse_angles(text.data() + offsets[(size_t)a], &ang[(size_t)a * 4])) { first_bad[t] = a; break; }
+                    if (!parse_angles(text + offsets[(size_t)a], &ang[(size_t)a * 4])) { first_bad[t] = a; break; }
             };
             if (workers <= 1) {
                 parse_lines(0);
