@@ -1109,7 +1109,7 @@ struct ExpandTuning {
     // the per-line stream kernel is VALU bound with a heavy prologue (24 band constants per lane): long waves.  Panels
     // of 64 steps x 33616 waves (2.2 GB per panel; streams up to 131 072 lines are ONE panel): 65 536 lines 232-290 us
     // whatever the shape, 1 048 576 lines 3.76 ms against 3.83 (one panel) and 4.0-5.0 (8..16 steps), tools/probes/perline_sweep.sh
-    long stream_waves = 32768;      // GORT_STREAM_WAVES: waves per panel of the per-line stream kernel (rounded like `waves`)
+    long stream_waves = 16808;      // GORT_STREAM_WAVES: waves per panel of the per-line stream kernel (rounded like `waves`)
     int stream_steps = 64;          // GORT_STREAM_STEPS: steps per wave = panel height of the per-line stream kernel
     ExpandTuning()
     {
@@ -1471,7 +1471,11 @@ static bool stream_uses_flat(int nw, long nA, bool want_scomp)
 static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
 {
     const ExpandTuning &tune = tuning();
-    *stride = flat_stride(nw, chunks, tune.stream_waves);
+    // small streams: fewer waves, so that a wave still has ~6 steps to spread its prologue (24 band constants per lane)
+    // over - 3000 lines: 20 us with 8404 waves, 36 us with 33616; 8192 lines: 37 against 43 (tools/probes/perline_small.sh)
+    long target = tune.stream_waves;
+    if (chunks / 6 < target) target = chunks / 6 < 4202 ? 4202 : chunks / 6;
+    *stride = flat_stride(nw, chunks, target);
     *steps = tune.stream_steps;
 }
 
