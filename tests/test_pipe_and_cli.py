@@ -134,3 +134,37 @@ def test_cli_pipeline_many_chunks_in_order_and_devices():
     rc, out4, err4 = _gortt(["-LAI", "4.0", "-prnprop"], b"\n".join(text.split(b"\n")[:5001]) + b"\n")
     assert rc != 0 and out4 == b"\n".join(lines[:5001]) + b"\n"
     assert b"expected number of angles (9000) does not match with number found (5000)" in err4
+
+
+def test_cli_bulk_reader_edge_cases():
+    """The text reader takes stdin in 8 MB blocks and cuts lines with memchr: lines of very different lengths across
+    block boundaries, CRLF endings, a last line without a newline, a blank line (an error at the right line number, as
+    the reference's sscanf would report it: gortt.c:234-237), extra columns."""
+    rng = np.random.default_rng(17)
+    n, wl = 140000, [650.0, 865.0]
+    ang = np.round(_lines(rng, n, distinct=False), 3)
+    head = ("%d %d 650 865\n" % (n, len(wl))).encode()
+    def line(i, r):
+        pad = " " * int(rng.integers(0, 40)) if i % 7 == 0 else ""
+        tail = (" extra %d columns" % i) * int(rng.integers(0, 6)) if i % 11 == 0 else ""
+        eol = "\r\n" if i % 5 == 0 else "\n"
+        return ("%s%.3f %.3f\t%.3f   %.3f%s%s" % (pad, r[0], r[1], r[2], r[3], tail, eol)).encode()
+    body = b"".join(line(i, r) for i, r in enumerate(ang))
+    assert len(body) > (8 << 20) // 2                                   # several chunks, more than one block with the rows below
+    text = ("%d %d 650 865\n" % (2 * n, len(wl))).encode() + body + body[:-1]      # ... and no newline at the very end
+    rc, out, err = _gortt(["-LAI", "4.0", "--binary-out"], text)
+    assert rc == 0 and err == b"", err[-300:]
+    rows = np.frombuffer(out[len(text.split(b"\n", 1)[0]) + 1:], dtype="<f8").reshape(2 * n, 4 + len(wl))
+    assert np.array_equal(rows[:n, :4], ang) and np.array_equal(rows[n:, :4], ang)
+    assert np.array_equal(rows[:n, 4:].view(np.int64), rows[n:, 4:].view(np.int64))
+    c = O.make_canopy(lai=4.0)
+    idx = np.sort(rng.choice(n, 25, replace=False))
+    ref, _, _ = O.rsurf_stream(c, ang[idx], *O.spectra(wl), want_K=False)
+    assert relerr(rows[idx, 4:], ref, floor=1e-12) <= REGRESSION
+    # a blank line in the second block: rows in front of it are written, the message names its line
+    parts = text.split(b"\n")
+    k = 200001
+    parts[k] = b""
+    rc, out2, err2 = _gortt(["-LAI", "4.0", "--binary-out"], b"\n".join(parts))
+    assert rc != 0 and ("error on input, line %d" % k).encode() in err2
+    assert len(out2) == len(parts[0]) + 1 + (k - 1) * 8 * (4 + len(wl))
