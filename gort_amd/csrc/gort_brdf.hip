@@ -253,7 +253,11 @@ constexpr int GEOM_ROWS = 4;
 // 2: FUSED for grids of a few bands (BASELINE config 3 is one band): the node's samples are formed right here from
 // its coefficients - no 128-B record per node written and read back (383 MB each way for the hemisphere grid,
 // more than the arithmetic costs) - with the same sun_terms()/dot5() as the two-kernel path: same bits.
-__global__ __launch_bounds__(GEOM_ROW_THREADS) void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
+#ifndef GORT_GEOM_WAVES
+#define GORT_GEOM_WAVES 3      // 168 VGPRs instead of 171: a third wave per SIMD, C3 133 -> 125 us; 4 would spill to scratch
+#endif
+__global__ __launch_bounds__(GEOM_ROW_THREADS) __attribute__((amdgpu_waves_per_eu(GORT_GEOM_WAVES)))
+void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
                                                                           double *__restrict__ coef, int compact,
                                                                           const double *__restrict__ Lall, int nw,
