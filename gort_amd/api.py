@@ -70,7 +70,8 @@ DECLARED_SYMBOLS = [
     "gort_canopy_newstyle", "gort_canopy_set_lai", "gort_canopy_init", "gort_price_soil",
     "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_format_f6", "gort_format_f6_row", "gort_lut_format", "gort_lut_read",
     "gort_device_count", "gort_dev_malloc", "gort_dev_free", "gort_memcpy_h2d", "gort_memcpy_d2h",
-    "gort_gap_probabilities", "gort_gap_probabilities_dev",
+    "gort_gap_probabilities", "gort_gap_probabilities_dev", "gort_gap_cache_stats", "gort_gap_cache_clear",
+    "gort_canopy_key", "gort_lut_cache_store", "gort_lut_cache_load",
     "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
@@ -150,6 +151,14 @@ def lib():
         L.gort_energy_stream_dev.argtypes = L.gort_energy_stream.argtypes
         L.gort_energy_members_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
         L.gort_gap_probabilities.argtypes = [C.c_void_p, C.c_int]
+        L.gort_gap_cache_stats.argtypes = [C.POINTER(C.c_long)] * 3
+        L.gort_gap_cache_stats.restype = None
+        L.gort_gap_cache_clear.argtypes = []
+        L.gort_gap_cache_clear.restype = None
+        L.gort_canopy_key.argtypes = [C.POINTER(Canopy)]
+        L.gort_canopy_key.restype = C.c_uint64
+        L.gort_lut_cache_store.argtypes = [C.c_char_p, C.POINTER(Canopy)]
+        L.gort_lut_cache_load.argtypes = [C.c_char_p, C.POINTER(Canopy)]
         L.gort_gap_probabilities_dev.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.gort_canopy_newstyle.argtypes = [C.POINTER(Canopy), C.c_float, C.c_float, C.c_float]
         L.gort_canopy_set_lai.argtypes = [C.POINTER(Canopy), C.c_float]
@@ -359,6 +368,34 @@ def gap_probabilities(members):
     for i, m in enumerate(members):
         C.memmove(C.byref(m), C.byref(arr[i]), C.sizeof(Canopy))
     return members
+
+
+def gap_cache_stats():
+    """(hits, misses, entries) of the in-process cache of gap tables per crown geometry."""
+    h, m, n = C.c_long(), C.c_long(), C.c_long()
+    lib().gort_gap_cache_stats(C.byref(h), C.byref(m), C.byref(n))
+    return h.value, m.value, n.value
+
+
+def gap_cache_clear():
+    lib().gort_gap_cache_clear()
+
+
+def canopy_key(canopy):
+    """64-bit key of the crown geometry the gap tables depend on (r, b, h1, h2, lambda, favd, q08)."""
+    return int(lib().gort_canopy_key(C.byref(canopy)))
+
+
+def lut_cache_store(directory, canopy):
+    _check(lib().gort_lut_cache_store(os.fsencode(directory), C.byref(canopy)))
+
+
+def lut_cache_load(directory, canopy):
+    """True: the canopy's gap tables were filled in from <directory>; False: no valid entry for this geometry."""
+    rc = lib().gort_lut_cache_load(os.fsencode(directory), C.byref(canopy))
+    if rc < 0:
+        _check(rc)
+    return rc == 0
 
 
 class Engine:

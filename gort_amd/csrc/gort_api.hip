@@ -7,10 +7,14 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <sched.h>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "gort_internal.h"
@@ -161,23 +165,128 @@ extern "C" int gort_gap_probabilities_dev(gort_canopy *members_dev, int n_member
     return launch_gap_probabilities(members_dev, n_members, stream);
 }
 
+// The tables of the crown geometries this process has seen (include/gort_amd.h): an ensemble filter re-submits the
+// same members with new leaf/soil parameters every cycle, and `gortt` drivers loop over spectra for one stand.
+namespace {
+struct GapEntry {
+    double geo[6];
+    int q08;
+    double p_n0[GORT_NTH], epgap[GORT_NTH], k_open, k_openep;
+};
+struct GapCache {
+    std::mutex mu;
+    std::unordered_multimap<uint64_t, GapEntry> map;
+    std::deque<uint64_t> order;                              // insertion order: the oldest entry goes first
+    long hits = 0, misses = 0;
+    size_t cap = 4096;
+    GapCache()
+    {
+        if (const char *v = getenv("GORT_GAP_CACHE")) cap = atol(v) > 0 ? (size_t)atol(v) : 0;
+    }
+};
+GapCache &gap_cache()
+{
+    static GapCache c;
+    return c;
+}
+bool same_geometry(const GapEntry &e, const gort_canopy &c)
+{
+    const double g[6] = {c.r, c.b, c.h1, c.h2, c.lambda, c.favd};
+    return std::memcmp(e.geo, g, sizeof g) == 0 && e.q08 == (c.use_q08 ? 1 : 0);
+}
+}  // namespace
+
+extern "C" void gort_gap_cache_stats(long *hits, long *misses, long *entries)
+{
+    GapCache &gc = gap_cache();
+    std::lock_guard<std::mutex> lock(gc.mu);
+    if (hits) *hits = gc.hits;
+    if (misses) *misses = gc.misses;
+    if (entries) *entries = (long)gc.map.size();
+}
+
+extern "C" void gort_gap_cache_clear(void)
+{
+    GapCache &gc = gap_cache();
+    std::lock_guard<std::mutex> lock(gc.mu);
+    gc.map.clear();
+    gc.order.clear();
+    gc.hits = gc.misses = 0;
+}
+
 extern "C" int gort_gap_probabilities(gort_canopy *members, int n_members)
 {
     if (!members || n_members < 0) return fail(GORT_EINVAL, "gort_gap_probabilities: bad argument");
     if (n_members == 0) return GORT_OK;
+    GapCache &gc = gap_cache();
+    // 1) members whose geometry is known take their tables from the cache; the others are compacted for the device
+    std::vector<int> todo;
+    {
+        std::lock_guard<std::mutex> lock(gc.mu);
+        for (int m = 0; m < n_members; ++m) {
+            bool hit = false;
+            if (gc.cap) {
+                auto range = gc.map.equal_range(gort_canopy_key(&members[m]));
+                for (auto it = range.first; it != range.second && !hit; ++it)
+                    if (same_geometry(it->second, members[m])) {
+                        std::memcpy(members[m].p_n0, it->second.p_n0, sizeof it->second.p_n0);
+                        std::memcpy(members[m].epgap, it->second.epgap, sizeof it->second.epgap);
+                        members[m].k_open = it->second.k_open;
+                        members[m].k_openep = it->second.k_openep;
+                        hit = true;
+                    }
+            }
+            if (hit) ++gc.hits;
+            else todo.push_back(m);
+        }
+        gc.misses += (long)todo.size();
+    }
+    if (todo.empty()) return GORT_OK;
     if (gort_device_count() <= 0) return fail(GORT_ENODEVICE, "gort_gap_probabilities: no HIP device");
+    const int n = (int)todo.size();
+    std::vector<gort_canopy> packed;
+    gort_canopy *host = members;
+    if (n != n_members) {
+        packed.resize((size_t)n);
+        for (int i = 0; i < n; ++i) packed[(size_t)i] = members[todo[(size_t)i]];
+        host = packed.data();
+    }
     gort_canopy *dev = nullptr;
-    const size_t bytes = sizeof(gort_canopy) * (size_t)n_members;
+    const size_t bytes = sizeof(gort_canopy) * (size_t)n;
     GORT_HIP(hipMalloc((void **)&dev, bytes));
     int rc = GORT_OK;
-    hipError_t e = hipMemcpy(dev, members, bytes, hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = launch_gap_probabilities(dev, n_members, nullptr);
-        if (rc == GORT_OK) e = hipMemcpy(members, dev, bytes, hipMemcpyDeviceToHost);
+        rc = launch_gap_probabilities(dev, n, nullptr);
+        if (rc == GORT_OK) e = hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost);
     }
     (void)hipFree(dev);
     if (e != hipSuccess) return fail(GORT_ENODEVICE, "gort_gap_probabilities: %s", hipGetErrorString(e));
-    return rc;
+    if (rc) return rc;
+    // 2) hand the results back and remember them
+    std::lock_guard<std::mutex> lock(gc.mu);
+    for (int i = 0; i < n; ++i) {
+        gort_canopy &c = members[todo[(size_t)i]];
+        if (host != members) c = host[i];
+        if (!gc.cap) continue;
+        while (gc.map.size() >= gc.cap && !gc.order.empty()) {
+            auto it = gc.map.find(gc.order.front());
+            if (it != gc.map.end()) gc.map.erase(it);
+            gc.order.pop_front();
+        }
+        GapEntry en;
+        const double g[6] = {c.r, c.b, c.h1, c.h2, c.lambda, c.favd};
+        std::memcpy(en.geo, g, sizeof g);
+        en.q08 = c.use_q08 ? 1 : 0;
+        std::memcpy(en.p_n0, c.p_n0, sizeof en.p_n0);
+        std::memcpy(en.epgap, c.epgap, sizeof en.epgap);
+        en.k_open = c.k_open;
+        en.k_openep = c.k_openep;
+        const uint64_t key = gort_canopy_key(&c);
+        gc.map.emplace(key, en);
+        gc.order.push_back(key);
+    }
+    return GORT_OK;
 }
 
 // ----------------------------------------------------------------------- engine

@@ -12,9 +12,11 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #ifndef GORT_DATA_DIR
@@ -476,6 +478,94 @@ extern "C" long gort_lut_format(const gort_canopy *c, char *buf, size_t cap)
     int k = std::snprintf(buf + n, cap - n, "-1 %0.40f %0.40f\n", c->k_open, c->k_openep);
     if (k < 0 || (size_t)k >= cap - n) return gort::fail(GORT_EINVAL, "gort_lut_format: buffer too small");
     return (long)(n + (size_t)k);
+}
+
+// ---- gap-table cache keyed on crown geometry (new surface: generalises -W / -P, gortt.c:123-146) ----
+
+namespace {
+struct GapKey { double r, b, h1, h2, lambda, favd; int32_t q08; };
+
+GapKey gap_key_of(const gort_canopy *c)
+{
+    GapKey k;
+    std::memset(&k, 0, sizeof k);                            // padding bytes too: the key is hashed as bytes
+    k.r = c->r;  k.b = c->b;  k.h1 = c->h1;  k.h2 = c->h2;  k.lambda = c->lambda;  k.favd = c->favd;
+    k.q08 = c->use_q08 ? 1 : 0;
+    return k;
+}
+
+std::string gap_cache_path(const char *dir, uint64_t key)
+{
+    char name[64];
+    std::snprintf(name, sizeof name, "/gap-%016llx.lut", (unsigned long long)key);
+    return std::string(dir) + name;
+}
+}  // namespace
+
+extern "C" uint64_t gort_canopy_key(const gort_canopy *c)
+{
+    if (!c) return 0;
+    const GapKey k = gap_key_of(c);
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&k);
+    uint64_t h = 1469598103934665603ull;                     // FNV-1a
+    for (size_t i = 0; i < sizeof k; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+extern "C" int gort_lut_cache_store(const char *dir, const gort_canopy *c)
+{
+    if (!dir || !c) return gort::fail(GORT_EINVAL, "gort_lut_cache_store: bad argument");
+    const std::string path = gap_cache_path(dir, gort_canopy_key(c));
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    FILE *fp = std::fopen(tmp.c_str(), "w");
+    if (!fp) return gort::fail(GORT_EIO, "gort_lut_cache_store: cannot write %s", tmp.c_str());
+    for (int j = 0; j < 90; ++j) std::fprintf(fp, "%d %a %a\n", j, c->p_n0[j], c->epgap[j]);
+    std::fprintf(fp, "-1 %a %a\n", c->k_open, c->k_openep);
+    // p_n0[90] / epgap[90] are not part of the -W format (the reference reads them back as 0); kept here so that a
+    // cache hit returns every bit gort_gap_probabilities computed
+    const GapKey k = gap_key_of(c);
+    std::fprintf(fp, "# gort-gap-lut 1 %a %a %a %a %a %a %d %a %a\n", k.r, k.b, k.h1, k.h2, k.lambda, k.favd, (int)k.q08, c->p_n0[90],
+                 c->epgap[90]);
+    const bool ok = std::fflush(fp) == 0 && !std::ferror(fp);
+    std::fclose(fp);
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {
+        std::remove(tmp.c_str());
+        return gort::fail(GORT_EIO, "gort_lut_cache_store: cannot write %s", path.c_str());
+    }
+    return GORT_OK;
+}
+
+extern "C" int gort_lut_cache_load(const char *dir, gort_canopy *c)
+{
+    if (!dir || !c) return gort::fail(GORT_EINVAL, "gort_lut_cache_load: bad argument");
+    const std::string path = gap_cache_path(dir, gort_canopy_key(c));
+    FILE *fp = std::fopen(path.c_str(), "r");
+    if (!fp) return 1;
+    double pn[GORT_NTH] = {0}, ep[GORT_NTH] = {0}, ko = 0, koe = 0;
+    int rows = 0, j;
+    double x1, x2;
+    bool closed = false;
+    while (std::fscanf(fp, "%d %lf %lf", &j, &x1, &x2) == 3) {
+        if (j >= 0 && j < 90) { pn[j] = x1; ep[j] = x2; ++rows; }
+        else if (j < 0) { ko = x1; koe = x2; closed = true; }
+    }
+    GapKey f;
+    std::memset(&f, 0, sizeof f);
+    int version = 0, q08 = 0;
+    double pn90 = 0, ep90 = 0;
+    const int got = std::fscanf(fp, " # gort-gap-lut %d %lf %lf %lf %lf %lf %lf %d %lf %lf", &version, &f.r, &f.b, &f.h1, &f.h2,
+                                &f.lambda, &f.favd, &q08, &pn90, &ep90);
+    std::fclose(fp);
+    f.q08 = q08;
+    const GapKey k = gap_key_of(c);
+    // another geometry with the same hash, a damaged or a foreign file: no entry
+    if (got != 10 || version != 1 || rows != 90 || !closed || std::memcmp(&f, &k, sizeof k) != 0) return 1;
+    for (int t = 0; t < 90; ++t) { c->p_n0[t] = pn[t]; c->epgap[t] = ep[t]; }
+    c->p_n0[90] = pn90;
+    c->epgap[90] = ep90;
+    c->k_open = ko;
+    c->k_openep = koe;
+    return GORT_OK;
 }
 
 extern "C" int gort_lut_read(const char *path, gort_canopy *c)

@@ -14,7 +14,7 @@
 //     beyond 32);
 //   * -soil_spectra, which in the reference only dumps a table and exits with failure,
 //     is rejected with a message.
-// Extensions (double-dash, unknown options to the reference): --binary-in, --binary-out, --lut-hex, --gpus N.
+// Extensions (double-dash, unknown options to the reference): --binary-in, --binary-out, --lut-hex, --lut-cache DIR, --gpus N.
 //
 // The per-line loop of the reference (read, evaluate, print: gortt.c:232-329) is a three-stage pipeline here:
 // this thread reads and parses chunk i+1 into a pinned slot of a gort_pipe while the GPU evaluates chunk i and
@@ -128,6 +128,7 @@ struct Options {
     bool binary_in = false;    // --binary-in : after the text header, angle lines are records of 4 raw doubles
     bool binary_out = false;   // --binary-out: rows are raw doubles in print order (angles, then per band ..., K, energy)
     bool lut_hex = false;      // --lut-hex   : -W writes C99 hex floats (exact; -P of either program reads them)
+    std::string lut_cache;     // --lut-cache DIR : gap tables kept per crown geometry in DIR (gort_lut_cache_*)
     std::vector<int> devices;  // --gpus N (devices 0..N-1) or GORTT_DEVICES="0,2,3": chunks go round the devices
     std::string lut_file;
 };
@@ -157,6 +158,7 @@ void parse_args(int argc, char **argv, Options &o)
         if (!std::strcmp(a, "--binary-in")) o.binary_in = true;
         else if (!std::strcmp(a, "--binary-out")) o.binary_out = true;
         else if (!std::strcmp(a, "--lut-hex")) o.lut_hex = true;
+        else if (!std::strcmp(a, "--lut-cache")) o.lut_cache = val();
         else if (!std::strcmp(a, "--gpus")) {
             const int n = atoi(val());
             if (n < 1 || n > 64) {
@@ -401,7 +403,18 @@ int main(int argc, char **argv)
     check(gort_canopy_init(&o.canopy));
 
     // 1) gap probabilities on the device unless they come from a file (gortt.c:116-120)
-    if (!o.read_lut) check(gort_gap_probabilities(&o.canopy, 1));
+    if (!o.read_lut) {
+        const bool cached = !o.lut_cache.empty() && gort_lut_cache_load(o.lut_cache.c_str(), &o.canopy) == GORT_OK;
+        if (!cached) {
+            check(gort_gap_probabilities(&o.canopy, 1));
+            // a cache that cannot be written is not an error of the run
+            if (!o.lut_cache.empty() && gort_lut_cache_store(o.lut_cache.c_str(), &o.canopy) != GORT_OK)
+                std::fprintf(stderr, "%s: warning: %s\n", argv[0], gort_last_error());
+        }
+        if (getenv("GORTT_VERBOSE") && !o.lut_cache.empty())
+            std::fprintf(stderr, "gortt: gap tables %s %s/gap-%016llx.lut\n", cached ? "from" : "computed, kept in", o.lut_cache.c_str(),
+                         (unsigned long long)gort_canopy_key(&o.canopy));
+    }
     // 2) -W: write them and stop, before stdin is touched (gortt.c:123-128)
     if (o.write_lut) {
         if (o.lut_hex) {

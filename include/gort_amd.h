@@ -114,6 +114,19 @@ long gort_format_f6_row(const double *v, long n, char *dst, size_t cap);
 long gort_lut_format(const gort_canopy *c, char *buf, size_t cap);
 int  gort_lut_read(const char *path, gort_canopy *c);
 
+/* Gap-table cache keyed on crown geometry - generalises `-W` / `-P file` (gortt.c:123-146), where the user has to
+ * remember which file belongs to which crown geometry ("must be run with identical crown geometry").  The tables
+ * depend on r, b, h1, h2, lambda, favd and on -q08_pn_kopen only (gortt_pn_kopen.c:7-129, 1144-1200): the key is
+ * a 64-bit hash of those bit patterns.
+ * Files: <dir>/gap-<16 hex digits>.lut = the rows of `-W` as C99 hex floats (exact, unlike "%0.40f", which flushes
+ * the horizon values to zero), closed by a line "# gort-gap-lut 1 <r> <b> <h1> <h2> <lambda> <favd> <q08>" that is
+ * checked on load.  fscanf("%d %lf %lf") stops at that line, so a cache file is also a valid `-P` file for the
+ * reference and for this library.  Written to a temporary name and renamed: readers never see half a file.
+ * gort_lut_cache_load: GORT_OK = tables filled in, 1 = no (valid) entry, <0 = error. */
+uint64_t gort_canopy_key(const gort_canopy *c);
+int  gort_lut_cache_store(const char *dir, const gort_canopy *c);
+int  gort_lut_cache_load(const char *dir, gort_canopy *c);
+
 /* ============================== device entry points ============================== */
 
 int  gort_device_count(void);
@@ -142,6 +155,11 @@ void  gort_host_free(void *p);
  * gortt_gap_probabilities_Q08 (gortt_pn_kopen.c:1144-1200).
  * Each canopy must have been through gort_canopy_init. */
 int  gort_gap_probabilities(gort_canopy *members, int n_members);
+/* gort_gap_probabilities remembers the tables of the last GORT_GAP_CACHE (default 4096, 0 = off) distinct crown
+ * geometries of this process (key: gort_canopy_key + the geometry itself): a member whose geometry has been seen
+ * gets its tables from there, only the others go to the device.  Thread-safe. */
+void gort_gap_cache_stats(long *hits, long *misses, long *entries);
+void gort_gap_cache_clear(void);
 int  gort_gap_probabilities_dev(gort_canopy *members_dev, int n_members, void *stream);
 
 /* Opaque engine: owns a HIP stream, the device copy of one canopy, the spectra and

@@ -236,3 +236,49 @@ def test_format_f6_row_equals_single_values():
     tiny = C.create_string_buffer(16)
     big = np.array([1e300, 1.0])
     assert L.gort_format_f6_row(big.ctypes.data_as(C.c_void_p), 2, tiny, len(tiny)) == api.EINVAL
+
+
+def test_gap_table_file_cache_keyed_on_crown_geometry(golden, tmp_path):
+    """`-W`/`-P` generalised to a cache keyed on crown geometry.  No GPU: the tables stored are
+    the REFERENCE's own (golden canopies.npz, %.17g), the round trip through the hex-float file keeps every bit, the
+    file is a valid `-P` file, and another geometry / a damaged file is a miss, not a wrong hit."""
+    g = golden("canopies.npz")
+    c = api.make_canopy(lai=4.0)
+    for t in range(91):
+        c.p_n0[t] = float(g["default_lai4/p_n0"][0][t])
+        c.epgap[t] = float(g["default_lai4/epgap0"][t]) if t < 90 else 0.0
+    c.k_open, c.k_openep = (float(v) for v in g["default_lai4/kk"])
+    key = api.canopy_key(c)
+    assert key == api.canopy_key(api.make_canopy(lai=4.0)) and key != 0
+    d = str(tmp_path)
+    fresh = api.make_canopy(lai=4.0)
+    assert api.lut_cache_load(d, fresh) is False                      # empty directory
+    api.lut_cache_store(d, c)
+    path = os.path.join(d, "gap-%016x.lut" % key)
+    assert os.path.exists(path) and [f for f in os.listdir(d)] == [os.path.basename(path)]   # no temporary left behind
+    assert api.lut_cache_load(d, fresh) is True
+    assert list(fresh.p_n0) == list(c.p_n0) and list(fresh.epgap) == list(c.epgap)           # bit for bit
+    assert (fresh.k_open, fresh.k_openep) == (c.k_open, c.k_openep)
+    assert min(v for v in c.p_n0 if v > 0) < 1e-40                    # values "%0.40f" would have flushed to zero survive
+    # the same file through the -P reader: rows 0..89 and the KOpen line; the key line stops fscanf as EOF would
+    via_p = api.make_canopy(lai=4.0)
+    api.lut_read(path, via_p)
+    assert list(via_p.p_n0)[:90] == list(c.p_n0)[:90] and (via_p.k_open, via_p.k_openep) == (c.k_open, c.k_openep)
+    # the key covers exactly what the tables depend on
+    other = api.make_canopy(lai=3.0)
+    assert api.canopy_key(other) != key and api.lut_cache_load(d, other) is False
+    q08 = api.make_canopy(lai=4.0)
+    q08.use_q08 = 1
+    assert api.canopy_key(q08) != key
+    beta = api.make_canopy(lai=4.0)
+    beta.beta, beta.use_user_beta = 0.3, 1                            # -beta does not enter the gap tables
+    assert api.canopy_key(beta) == key
+    # a file under the right name whose key line belongs to another geometry (hash collision / renamed file): miss
+    text = open(path).read()
+    os.rename(path, os.path.join(d, "gap-%016x.lut" % api.canopy_key(other)))
+    assert api.lut_cache_load(d, other) is False
+    # truncated file: miss
+    open(path, "w").write(text[:len(text) // 2])
+    assert api.lut_cache_load(d, api.make_canopy(lai=4.0)) is False
+    with pytest.raises(api.GortError):
+        api.lut_cache_store(os.path.join(d, "no", "such", "dir"), c)

@@ -168,3 +168,44 @@ def test_cli_bulk_reader_edge_cases():
     rc, out2, err2 = _gortt(["-LAI", "4.0", "--binary-out"], b"\n".join(parts))
     assert rc != 0 and ("error on input, line %d" % k).encode() in err2
     assert len(out2) == len(parts[0]) + 1 + (k - 1) * 8 * (4 + len(wl))
+
+
+def _tables(c):
+    return np.array(list(c.p_n0) + list(c.epgap) + [c.k_open, c.k_openep]).view(np.int64)
+
+
+def test_gap_tables_cached_per_crown_geometry_in_process_and_on_disk(tmp_path):
+    """SURVEY.md 8(f) row 3.  In process: a member whose crown geometry has been seen takes its tables from the cache
+    (same bits), only the others go to the device, in mixed batches too.  `gortt --lut-cache DIR`: the second run
+    reads what the first one kept, writes the same bytes, and the file holds exactly what the device computed."""
+    api.gap_cache_clear()
+    a = api.gap_probabilities(api.make_canopy(lai=4.0))
+    assert api.gap_cache_stats() == (0, 1, 1)
+    b = api.gap_probabilities(api.make_canopy(lai=4.0, beta=0.25))       # -beta is not part of the geometry
+    assert api.gap_cache_stats() == (1, 1, 1)
+    assert np.array_equal(_tables(a), _tables(b))
+    batch = [api.make_canopy(lai=2.5), api.make_canopy(lai=4.0), api.make_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3),
+             api.make_canopy(lai=4.0, q08=True)]
+    api.gap_probabilities(batch)
+    assert api.gap_cache_stats() == (2, 4, 4)                            # one hit, three computed
+    api.gap_cache_clear()
+    assert api.gap_cache_stats() == (0, 0, 0)
+    for m, kw in zip(batch, (dict(lai=2.5), dict(lai=4.0), dict(newstyle=(2.0, 2.0, 0.6), lai=3.3), dict(lai=4.0, q08=True))):
+        alone = api.gap_probabilities(api.make_canopy(**kw))             # each computed on its own, cache empty
+        assert np.array_equal(_tables(m), _tables(alone)), kw
+    assert not np.array_equal(_tables(batch[1]), _tables(batch[3]))     # q08 is part of the key
+    # the CLI
+    text = b"3 4 450 600 800 1000\n10 0 30 20\n-40 10 55 200\n88 0 89 180\n"
+    d = str(tmp_path)
+    rc0, plain, _ = _gortt(["-LAI", "4.0", "-prnprop"], text)
+    rc1, first, err1 = _gortt(["-LAI", "4.0", "-prnprop", "--lut-cache", d], text, {"GORTT_VERBOSE": "1"})
+    rc2, second, err2 = _gortt(["-LAI", "4.0", "-prnprop", "--lut-cache", d], text, {"GORTT_VERBOSE": "1"})
+    assert rc0 == rc1 == rc2 == 0 and plain == first == second
+    assert b"gap tables computed, kept in" in err1 and b"gap tables from" in err2
+    kept = api.make_canopy(lai=4.0)
+    assert api.lut_cache_load(d, kept) and np.array_equal(_tables(kept), _tables(a))
+    # another stand: its own entry; an unwritable cache directory is a warning, not a failure
+    rc3, _, err3 = _gortt(["-LAI", "2.0", "--lut-cache", d], text, {"GORTT_VERBOSE": "1"})
+    assert rc3 == 0 and b"computed" in err3 and len(os.listdir(d)) == 2
+    rc4, out4, err4 = _gortt(["-LAI", "4.0", "-prnprop", "--lut-cache", os.path.join(d, "missing")], text)
+    assert rc4 == 0 and out4 == plain and b"warning" in err4

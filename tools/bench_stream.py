@@ -30,8 +30,10 @@ for name, sza in cases.items():
     if only and only not in name:
         continue
     a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), sza, np.zeros(n)], 1), device="cuda")
-    for grouping in (False, True):
-        eng.set_stream_grouping(2 if grouping else 0)      # 0 = per line (the default), 2 = group whenever the stream allows it
+    for grouping in (0, 2):                                 # 0 = per line (the default), 2 = group whenever the stream allows it
+        if os.environ.get("BENCH_STREAM_MODES") and str(grouping) not in os.environ["BENCH_STREAM_MODES"]:
+            continue
+        eng.set_stream_grouping(grouping)
         for _ in range(3):
             eng.rsurf_stream_dev(a, out)
         eng.synchronize()
