@@ -396,6 +396,7 @@ void check(int rc)
 int main(int argc, char **argv)
 {
     g_prog = argv[0];
+    const auto t_main = std::chrono::steady_clock::now();
     Options o;
     gort_canopy_defaults(&o.canopy);
     gort_leaf_soil_defaults(&o.leaf);
@@ -464,6 +465,7 @@ int main(int argc, char **argv)
     if (const char *v = std::getenv("GORTT_CHUNK_MB")) { const long m = atol(v); if (m >= 1 && m <= 4096) chunk_mb = (size_t)m; }
     const bool verbose = std::getenv("GORTT_VERBOSE") != nullptr;   // stage timings on stderr
     const auto t_start = std::chrono::steady_clock::now();
+    const double t_before = std::chrono::duration<double>(t_start - t_main).count();    // flags, gap tables (first HIP call), header, spectra
     auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     double t_acquire = 0, t_read = 0, t_submit = 0, t_wait = 0, t_write = 0;
     long CHUNK = (long)((chunk_mb << 20) / (sizeof(double) * per_line_out));
@@ -675,11 +677,15 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "gortt: %ld lines in %ld chunks of <= %ld; setup %.3f s, total %.3f s; producer: slot wait %.3f, "
                      "read+parse %.3f, submit %.3f; consumer: chunk wait %.3f, format+write %.3f\n", na, k_chunk, CHUNK,
                      t_setup, since(t_start), t_acquire, t_read, t_submit, t_wait, t_write);
+    const auto t_down = std::chrono::steady_clock::now();
     for (Dev &dv : devs) {
         if (dv.id >= 0) gort_set_device(dv.id);
         gort_pipe_destroy(dv.pipe);
         gort_engine_destroy(dv.eng);
     }
+    if (verbose)
+        std::fprintf(stderr, "gortt: %.3f s from main() to the first chunk's setup (HIP start-up, gap tables, header, spectra), "
+                     "%.3f s to free pipes and engines\n", t_before, since(t_down));
     if (!producer_error.empty()) die("%s: %s\n", g_prog, producer_error.c_str());
     if (!consumer_error.empty()) die("%s: %s\n", g_prog, consumer_error.c_str());
     if (bad_line) {
