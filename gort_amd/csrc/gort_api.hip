@@ -651,6 +651,13 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if (ws_bytes && ((rc = e->sgroup.reserve(ws_bytes)) || (rc = e->ssun.reserve(sun_bytes)))) return rc;
     for (int i = 0; i < 2; ++i)
         if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
+    if (stream_fuses(e->nw, scomp_dev != nullptr)) {
+        GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
+        rc = launch_geometry_stream_fused(c, e->L.as<double>(), e->nw, angles_dev, nA, rsurf_dev, K_dev, e->stream);
+        GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
+        e->stream_form = 0;
+        return rc;
+    }
     // The grouped form first sorts the lines by sun zenith and builds its sun table - work that does not need the
     // per-line geometry, whose ~35 fp64 transcendentals are a 15 us latency chain whatever the line count: the
     // geometry kernel runs beside it on the second stream.

@@ -212,10 +212,16 @@ __device__ inline void store_coef(double *rec, const gort_canopy &c, const GeomO
 // layout 0: the classic record (five coefficients, sun scalars, component-spectra extras: CoefSlot);
 // layout 1: the LineTerms of the stream family's regrouped sample (gort_device.h) for the wide stream kernels, which
 //           read them through the scalar cache once per 128 samples and must not spend VALU work on deriving them
+// FUSED (few bands, no component spectra): the line's samples are formed right here from the record in registers -
+// the same functions the narrow expansion kernels apply to the stored record, so the same bits - and no record is
+// written: one launch instead of two (a 181-line x 1-band call is launch latency and nothing else), and for long
+// narrow streams no 128 B of record written and read back per 8 B of result.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy *__restrict__ canopy,
                                                                const double *__restrict__ angles, long nA,
                                                                double *__restrict__ coef, double *__restrict__ K,
-                                                               int layout)
+                                                               int layout, const double *__restrict__ L, int nw,
+                                                               double *__restrict__ rsurf)
 {
     const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nA) return;
@@ -226,7 +232,14 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
     GeomOut g;
     geometry_core(c, vza, sza, raa, g);
-    if (layout == 0) {
+    if (FUSED) {
+        double rec[GORT_COEF_STRIDE];
+        store_coef(rec, c, g);
+        const LineTerms l = line_terms_of_record(rec, c.k_openep, c.k_open);
+        const double *__restrict__ Lm = L + member * L_NSLOT * nw;
+        double *__restrict__ o = rsurf + (member * nA + a) * nw;
+        for (int i = 0; i < nw; ++i) o[i] = stream_sample(l, stream_band(load_band(Lm, nw, i)));
+    } else if (layout == 0) {
         store_coef(coef + (member * nA + a) * GORT_COEF_STRIDE, c, g);
     } else {
         double rec[GORT_COEF_STRIDE];
@@ -973,9 +986,26 @@ int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_d
                            double *K_dev, int layout, void *stream)
 {
     if (nA <= 0) return GORT_OK;
-    hipLaunchKernelGGL(geometry_stream_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       canopy_dev, angles_dev, nA, coef_dev, K_dev, layout);
+    hipLaunchKernelGGL(geometry_stream_kernel<false>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       canopy_dev, angles_dev, nA, coef_dev, K_dev, layout, (const double *)nullptr, 0, (double *)nullptr);
     return check_launch("geometry_stream_kernel");
+}
+
+// few bands, no component spectra: one fused launch (GORT_STREAM_FUSE=0 keeps the two-kernel path, for tests)
+bool stream_fuses(int nw, bool want_scomp)
+{
+    const char *v = getenv("GORT_STREAM_FUSE");             // read per call: the tests switch it inside one process
+    return !(v && atoi(v) == 0) && !want_scomp && nw > 0 && nw <= 16;
+}
+
+// geometry and samples of a few-band stream in one launch (no records): rsurf_dev[nA][nw]
+int launch_geometry_stream_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
+                                 long nA, double *rsurf_dev, double *K_dev, void *stream)
+{
+    if (nA <= 0 || nw <= 0) return GORT_OK;
+    hipLaunchKernelGGL(geometry_stream_kernel<true>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       canopy_dev, angles_dev, nA, (double *)nullptr, K_dev, 0, L_dev, nw, rsurf_dev);
+    return check_launch("geometry_stream_kernel<fused>");
 }
 
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
@@ -1007,8 +1037,13 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
     if (n <= 0 || n_members <= 0) return GORT_OK;
     if (n_members > 65535) return fail(GORT_EINVAL, "members stream: %d members in one launch (max 65535)", n_members);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(geometry_stream_kernel, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0, s,
-                       canopies_dev, angles_dev, nA, coef_dev, (double *)nullptr, 0);
+    if (stream_fuses(nw, false)) {
+        hipLaunchKernelGGL(geometry_stream_kernel<true>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0, s,
+                           canopies_dev, angles_dev, nA, (double *)nullptr, (double *)nullptr, 0, L_dev, nw, rsurf_dev);
+        return check_launch("geometry_stream_kernel<fused>");
+    }
+    hipLaunchKernelGGL(geometry_stream_kernel<false>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0, s,
+                       canopies_dev, angles_dev, nA, coef_dev, (double *)nullptr, 0, (const double *)nullptr, 0, (double *)nullptr);
     int rc = check_launch("geometry_stream_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(expand_stream_kernel<false>, dim3((unsigned)((n + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,

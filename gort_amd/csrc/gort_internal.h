@@ -61,6 +61,11 @@ const double *price_eof_table();          // [4][421]
 void interface_transmissivity_tables(const double **t12, const double **talf);   // [2101] each
 // layout 0: classic records (CoefSlot); 1: the stream family's LineTerms (gort_device.h), what the WIDE stream
 // expansions read (launch_expand_stream with a stream for which expand_stream_workspace() returns true)
+// streams of few bands without component spectra: geometry and samples in ONE launch, no records (same bits as the
+// two-kernel path: the same functions on the same record, kept in registers)
+bool stream_fuses(int nw, bool want_scomp);
+int launch_geometry_stream_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
+                                 long nA, double *rsurf_dev, double *K_dev, void *stream);
 int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA,
                            double *coef_dev, double *K_dev, int layout, void *stream);
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records

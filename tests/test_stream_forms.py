@@ -3,6 +3,8 @@ per-line sun terms must write the SAME BITS (as must the narrow stream kernels: 
 chunked with whole streams), agree with the LUT path on grid angles to rounding and with the oracle to 1e-9.
 
 Reference interface: the per-line loop of main(), gortt.c:232-329 (+ gortt_rsurf, gortt.c:385-578)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -167,3 +169,50 @@ def test_grid_lines_through_the_stream_equal_the_lut(setup):
     s, form = _run(eng, torch, ang, wl.size, True)
     assert form == "grouped"
     assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13
+
+
+@pytest.mark.parametrize("nw", [1, 4, 16, 17])
+def test_few_band_streams_fused_launch_equals_two_kernels(setup, nw):
+    """Streams of up to 16 bands (C1, C2, an ensemble filter's observation operator) take ONE launch: geometry and samples
+    fused, no records.  Same bits as the two-kernel path (GORT_STREAM_FUSE=0), K included, NaN lines included; 17 bands
+    take the two-kernel path either way.  The member-batched entry point fuses the same way."""
+    eng, c, torch = setup
+    rng = np.random.default_rng(100 + nw)
+    wl = np.sort(rng.uniform(400.0, 2500.0, nw))
+    eng.set_spectra(*api.spectra(wl))
+    n = 5000
+    ang = _lines(rng, n, np.linspace(0.0, 89.0, 90))
+    ang[7, 2] = 95.0                                             # sun below the horizon: NaN row
+    ang[11, 0] = float("nan")
+    a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
+    res = {}
+    for fuse in ("1", "0"):
+        os.environ["GORT_STREAM_FUSE"] = fuse
+        out = torch.full((n, nw), -7.0, dtype=torch.float64, device="cuda")
+        K = torch.full((n, 4), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        eng.rsurf_stream_dev(a, out, K_t=K)
+        eng.synchronize()
+        res[fuse] = (out.cpu().numpy(), K.cpu().numpy())
+    os.environ.pop("GORT_STREAM_FUSE", None)
+    assert np.array_equal(res["1"][0].view(np.int64), res["0"][0].view(np.int64))
+    assert np.array_equal(res["1"][1].view(np.int64), res["0"][1].view(np.int64))
+    assert np.isnan(res["1"][0][7]).all() and np.isnan(res["1"][0][11]).all() and not np.isnan(res["1"][0][:7]).any()
+    ref, _, _ = O.rsurf_stream(O.make_canopy(lai=4.0), ang[:64], *O.spectra(wl), want_K=False)
+    assert relerr(res["1"][0][:64], ref, floor=1e-12) <= 1e-9
+
+
+def test_member_batched_few_band_stream_fuses_the_same_way():
+    from gort_amd.ensemble import DEFAULT, Ensemble
+    rng = np.random.default_rng(77)
+    wl = np.array([450.0, 555.0, 645.0, 858.5])
+    angles = np.stack([rng.uniform(-70, 70, 40), rng.uniform(0, 360, 40), rng.uniform(0, 75, 40), rng.uniform(0, 360, 40)], 1)
+    states = [dict(DEFAULT, LAI=float(x), Cab=float(y)) for x, y in zip(rng.uniform(0.5, 6, 9), rng.uniform(10, 60, 9))]
+    ens = Ensemble(wl).set_states(states)
+    os.environ["GORT_STREAM_FUSE"] = "1"
+    fused = ens.observe(angles)
+    os.environ["GORT_STREAM_FUSE"] = "0"
+    two = ens.observe(angles)
+    os.environ.pop("GORT_STREAM_FUSE", None)
+    ens.close()
+    assert fused.shape == (9, 40, 4) and np.array_equal(fused.view(np.int64), two.view(np.int64))

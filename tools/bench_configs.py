@@ -25,7 +25,7 @@ eng.set_spectra(*api.spectra([800.0]))
 ang = torch.tensor([[float(v), 0.0, 30.0, 0.0] for v in range(-90, 91)], dtype=torch.float64, device="cuda")
 out = torch.empty((181, 1), dtype=torch.float64, device="cuda")
 t = best(lambda: eng.rsurf_stream_dev(ang, out), eng)
-print("C2  181 tuples x 1 band          : %8.1f us  %.3e samples/s  (launch latency bound: 2 kernels)" % (t * 1e6, 181 / t))
+print("C2  181 tuples x 1 band          : %8.1f us  %.3e samples/s  (launch latency bound: one fused kernel)" % (t * 1e6, 181 / t))
 
 # C3: full hemisphere x 1 band (LUT entry point, few-band path)
 g = api.hemisphere_grid(); rows = g.nsza * g.nvza
