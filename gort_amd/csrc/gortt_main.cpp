@@ -14,7 +14,7 @@
 //     beyond 32);
 //   * -soil_spectra, which in the reference only dumps a table and exits with failure,
 //     is rejected with a message.
-// Extensions (double-dash, unknown options to the reference): --binary-in, --binary-out, --lut-hex, --lut-cache DIR, --gpus N.
+// Extensions (double-dash, unknown options to the reference): --binary-in, --binary-out, --lut-hex, --lut-cache DIR, --gpus N, --help.
 //
 // The per-line loop of the reference (read, evaluate, print: gortt.c:232-329) is a three-stage pipeline here:
 // this thread reads and parses chunk i+1 into a pinned slot of a gort_pipe while the GPU evaluates chunk i and
@@ -157,6 +157,19 @@ void parse_args(int argc, char **argv, Options &o)
         };
         if (!std::strcmp(a, "--binary-in")) o.binary_in = true;
         else if (!std::strcmp(a, "--binary-out")) o.binary_out = true;
+        else if (!std::strcmp(a, "--help")) {
+            // -u prints the reference's text and nothing else (compared byte for byte); the extensions are listed here
+            usage(argv[0]);
+            std::fputs("============ Extensions of this implementation (the reference rejects double-dash options):\n"
+                       "--binary-in      \tangle records on stdin as raw doubles (vza vaa sza saa) behind the text header line\n"
+                       "--binary-out     \toutput rows as raw doubles, same field order as the text row\n"
+                       "--lut-hex        \twith -W: write the gap probabilities as C99 hex floats (exact; -P reads them)\n"
+                       "--lut-cache DIR  \tkeep / look up the gap probabilities per crown geometry in DIR\n"
+                       "--gpus N         \tsend the chunks of the stream round N GPUs (or GORTT_DEVICES=0,2,..), rows in input order\n"
+                       "environment: GORTT_CHUNK_MB, GORTT_THREADS, GORTT_VERBOSE=1 (stage times on stderr)\n\n",
+                       stderr);
+            std::exit(EXIT_SUCCESS);
+        }
         else if (!std::strcmp(a, "--lut-hex")) o.lut_hex = true;
         else if (!std::strcmp(a, "--lut-cache")) o.lut_cache = val();
         else if (!std::strcmp(a, "--gpus")) {

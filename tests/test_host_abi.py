@@ -282,3 +282,17 @@ def test_gap_table_file_cache_keyed_on_crown_geometry(golden, tmp_path):
     assert api.lut_cache_load(d, api.make_canopy(lai=4.0)) is False
     with pytest.raises(api.GortError):
         api.lut_cache_store(os.path.join(d, "no", "such", "dir"), c)
+
+
+def test_cli_usage_and_help_need_no_gpu():
+    """`gortt -u` prints the reference's usage text byte for byte (golden case from the real reference) and `--help`
+    the same plus the list of this implementation's extensions; both exit 0 before any device call."""
+    import subprocess
+    cases = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "cli_cases.json")))}
+    u = subprocess.run([api.GORTT_BIN, "-u"], capture_output=True, timeout=60)
+    assert u.returncode == 0 and u.stdout == b""
+    assert u.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt") == cases["usage"]["stderr"]
+    h = subprocess.run([api.GORTT_BIN, "--help"], capture_output=True, timeout=60)
+    assert h.returncode == 0 and h.stderr.startswith(u.stderr)
+    for flag in (b"--binary-in", b"--binary-out", b"--lut-hex", b"--lut-cache DIR", b"--gpus N"):
+        assert flag in h.stderr[len(u.stderr):]
