@@ -138,7 +138,9 @@ extern "C" int gort_price_soil(const double *wl, int nw, const double rsl[4], do
 {
     const double *v1 = gort_price_eofs, *v2 = v1 + 421, *v3 = v2 + 421, *v4 = v3 + 421;
     for (int i = 0; i < nw; ++i) {
-        if (wl[i] < 400 || wl[i] > 2500)
+        // written so that a NaN is out of range too (the reference's `wl < 400 || wl > 2500`, gortt.c:1299, lets it
+        // through and indexes the soil vectors with (int)NaN)
+        if (!(wl[i] >= 400 && wl[i] <= 2500))
             return gort::fail(GORT_ERANGE, "gortt_price_soil: wavlength out of range (400-2500)");
         const int upper = (int)(1. + (wl[i] - 400) / 5.0);
         const int lower = (int)((wl[i] - 400) / 5.0);
@@ -301,7 +303,7 @@ extern "C" int gort_spectra(const gort_leaf_soil *s, const double *wl, int nw,
         return gort::fail(GORT_EINVAL, "gort_spectra: bad argument");
     // range errors: soil is checked first, as in main() (gortt.c:224 then :227)
     for (int i = 0; i < nw; ++i)
-        if (wl[i] < 400 || wl[i] > 2500)
+        if (!(wl[i] >= 400 && wl[i] <= 2500))                 // NaN included
             return gort::fail(GORT_ERANGE, "gortt_price_soil: wavlength out of range (400-2500)");
     if (s->use_alb_soil) {
         for (int i = 0; i < nw; ++i) rsoil[i] = s->alb_soil;
@@ -494,6 +496,21 @@ GapKey gap_key_of(const gort_canopy *c)
     return k;
 }
 
+// FNV-1a over the bit patterns of everything a cache file holds: damaged table rows are a miss, not a wrong hit
+uint64_t gap_tables_sum(const double *p_n0, const double *epgap, double k_open, double k_openep)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto eat = [&](const double *v, int n) {
+        const unsigned char *p = reinterpret_cast<const unsigned char *>(v);
+        for (size_t i = 0; i < sizeof(double) * (size_t)n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    };
+    eat(p_n0, GORT_NTH);
+    eat(epgap, GORT_NTH);
+    eat(&k_open, 1);
+    eat(&k_openep, 1);
+    return h;
+}
+
 std::string gap_cache_path(const char *dir, uint64_t key)
 {
     char name[64];
@@ -524,8 +541,8 @@ extern "C" int gort_lut_cache_store(const char *dir, const gort_canopy *c)
     // p_n0[90] / epgap[90] are not part of the -W format (the reference reads them back as 0); kept here so that a
     // cache hit returns every bit gort_gap_probabilities computed
     const GapKey k = gap_key_of(c);
-    std::fprintf(fp, "# gort-gap-lut 1 %a %a %a %a %a %a %d %a %a\n", k.r, k.b, k.h1, k.h2, k.lambda, k.favd, (int)k.q08, c->p_n0[90],
-                 c->epgap[90]);
+    std::fprintf(fp, "# gort-gap-lut 1 %a %a %a %a %a %a %d %a %a %016llx\n", k.r, k.b, k.h1, k.h2, k.lambda, k.favd, (int)k.q08,
+                 c->p_n0[90], c->epgap[90], (unsigned long long)gap_tables_sum(c->p_n0, c->epgap, c->k_open, c->k_openep));
     const bool ok = std::fflush(fp) == 0 && !std::ferror(fp);
     std::fclose(fp);
     if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {
@@ -553,13 +570,18 @@ extern "C" int gort_lut_cache_load(const char *dir, gort_canopy *c)
     std::memset(&f, 0, sizeof f);
     int version = 0, q08 = 0;
     double pn90 = 0, ep90 = 0;
-    const int got = std::fscanf(fp, " # gort-gap-lut %d %lf %lf %lf %lf %lf %lf %d %lf %lf", &version, &f.r, &f.b, &f.h1, &f.h2,
-                                &f.lambda, &f.favd, &q08, &pn90, &ep90);
+    unsigned long long sum = 0;
+    const int got = std::fscanf(fp, " # gort-gap-lut %d %lf %lf %lf %lf %lf %lf %d %lf %lf %16llx", &version, &f.r, &f.b, &f.h1, &f.h2,
+                                &f.lambda, &f.favd, &q08, &pn90, &ep90, &sum);
     std::fclose(fp);
+    pn[90] = pn90;
+    ep[90] = ep90;
     f.q08 = q08;
     const GapKey k = gap_key_of(c);
     // another geometry with the same hash, a damaged or a foreign file: no entry
-    if (got != 10 || version != 1 || rows != 90 || !closed || std::memcmp(&f, &k, sizeof k) != 0) return 1;
+    if (got != 11 || version != 1 || rows != 90 || !closed || std::memcmp(&f, &k, sizeof k) != 0 ||
+        sum != gap_tables_sum(pn, ep, ko, koe))
+        return 1;
     for (int t = 0; t < 90; ++t) { c->p_n0[t] = pn[t]; c->epgap[t] = ep[t]; }
     c->p_n0[90] = pn90;
     c->epgap[90] = ep90;

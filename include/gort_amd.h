@@ -119,8 +119,8 @@ int  gort_lut_read(const char *path, gort_canopy *c);
  * depend on r, b, h1, h2, lambda, favd and on -q08_pn_kopen only (gortt_pn_kopen.c:7-129, 1144-1200): the key is
  * a 64-bit hash of those bit patterns.
  * Files: <dir>/gap-<16 hex digits>.lut = the rows of `-W` as C99 hex floats (exact, unlike "%0.40f", which flushes
- * the horizon values to zero), closed by a line "# gort-gap-lut 1 <r> <b> <h1> <h2> <lambda> <favd> <q08>" that is
- * checked on load.  fscanf("%d %lf %lf") stops at that line, so a cache file is also a valid `-P` file for the
+ * the horizon values to zero), closed by a line "# gort-gap-lut 1 <r> <b> <h1> <h2> <lambda> <favd> <q08> <p_n0[90]>
+ * <epgap[90]> <checksum of the tables>" that is checked on load (a damaged or foreign file is a miss).  fscanf("%d %lf %lf") stops at that line, so a cache file is also a valid `-P` file for the
  * reference and for this library.  Written to a temporary name and renamed: readers never see half a file.
  * gort_lut_cache_load: GORT_OK = tables filled in, 1 = no (valid) entry, <0 = error. */
 uint64_t gort_canopy_key(const gort_canopy *c);

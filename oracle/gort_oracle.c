@@ -746,7 +746,7 @@ int gort_o_price_soil(const double *wl, int nw, const double rsl[4], double *rso
     for (i = 0; i < nw; i++) {
         int upper, lower;
         double fraction, lo, up;
-        if (wl[i] < 400 || wl[i] > 2500) return -1;
+        if (!(wl[i] >= 400 && wl[i] <= 2500)) return -1;      /* NaN too (the reference would index with (int)NaN) */
         upper = (int)(1. + (wl[i] - 400) / 5.0);
         lower = (int)((wl[i] - 400) / 5.0);
         fraction = (double)(wl[i] - 400.) / 5.0 - lower;
@@ -878,7 +878,7 @@ int gort_o_leaf_interp(const double *wl, int nw, const double *RT, double *rleaf
         int upper, lower;
         float fraction, omf;
         double ru, tu;
-        if (wl[i] < 400 || wl[i] > 2500) return -1;
+        if (!(wl[i] >= 400 && wl[i] <= 2500)) return -1;      /* NaN too (the reference would index with (int)NaN) */
         upper = (int)(1 + (wl[i] - 400.0) / 1.0);
         lower = (int)((wl[i] - 400.0) / 1.0);
         fraction = (float)((float)(wl[i] - 400.0) / 1.0 - lower);

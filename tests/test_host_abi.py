@@ -93,7 +93,7 @@ def test_spectra(golden):
     assert (rs == 0.2).all() and (rl == 0.45).all() and (tl == 0.45).all()
 
 
-@pytest.mark.parametrize("bad", [[399.0], [2500.5], [500.0, 2600.0]])
+@pytest.mark.parametrize("bad", [[399.0], [2500.5], [500.0, 2600.0], [500.0, float("nan")]])
 def test_wavelength_range_error(bad):
     with pytest.raises(api.GortError) as e:
         api.spectra(bad)
@@ -296,3 +296,25 @@ def test_cli_usage_and_help_need_no_gpu():
     assert h.returncode == 0 and h.stderr.startswith(u.stderr)
     for flag in (b"--binary-in", b"--binary-out", b"--lut-hex", b"--lut-cache DIR", b"--gpus N"):
         assert flag in h.stderr[len(u.stderr):]
+
+
+def test_host_entry_points_under_sanitizers(tmp_path):
+    """tools/probes/host_fuzz.cpp: gort_host.cpp (the part of the library without device code) compiled with
+    AddressSanitizer + UBSan and driven with hostile inputs - the exact "%f" formatter over random bit patterns against
+    snprintf, row buffers at their capacity limits, the `-P` reader and the gap-table cache on truncated / corrupted /
+    padded files (a damaged file must be a miss, never a wrong hit), wavelengths at and beyond the range incl. NaN."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    root = ROOT
+    exe = str(tmp_path / "host_fuzz")
+    build = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-fno-omit-frame-pointer", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "gort_amd", "csrc"),
+                            '-DGORT_DATA_DIR="%s"' % os.path.join(root, "gort_amd", "data"),
+                            os.path.join(root, "gort_amd", "csrc", "gort_host.cpp"), os.path.join(root, "tools", "probes", "host_fuzz.cpp"),
+                            "-o", exe], capture_output=True, timeout=600)
+    assert build.returncode == 0, build.stderr.decode()[-3000:]
+    run = subprocess.run([exe, "0.1"], capture_output=True, timeout=600, cwd=str(tmp_path))
+    assert run.returncode == 0 and b"host_fuzz: ok" in run.stdout, (run.stdout[-2000:], run.stderr[-3000:])
