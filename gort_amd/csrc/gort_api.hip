@@ -613,8 +613,16 @@ static int require_ready(const gort_engine *e, const char *who)
 extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *rsurf_dev,
                                      double *scomp_dev, double *K_dev)
 {
-    int rc = require_ready(e, "gort_rsurf_stream_dev");
-    if (rc) return rc;
+    int rc;
+    // The viewed proportions alone (K_dev, no reflectance): they depend on the canopy and the angles only, and the
+    // reference prints them for a header without wavelengths too (`N 0`: gortt_rsurf computes Kc, Kg, Kt, Kz in front
+    // of its wavelength loop, gortt.c:424-449) - no spectra needed, one launch of the geometry kernel
+    if (e && e->have_canopy && !rsurf_dev && !scomp_dev && K_dev) {
+        if (nA < 0 || (nA > 0 && !angles_dev)) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
+        if (nA == 0) return GORT_OK;
+        return launch_geometry_stream_fused(e->canopy.as<gort_canopy>(), nullptr, 0, angles_dev, nA, nullptr, K_dev, e->stream);
+    }
+    if ((rc = require_ready(e, "gort_rsurf_stream_dev"))) return rc;
     if (nA < 0 || (nA > 0 && (!angles_dev || !rsurf_dev))) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
     if (nA == 0) return GORT_OK;
     // line records with one pad record in front and a tail pad (the aligned flat expansion prefetches)

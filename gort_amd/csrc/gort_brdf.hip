@@ -1002,7 +1002,7 @@ bool stream_fuses(int nw, bool want_scomp)
 int launch_geometry_stream_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
                                  long nA, double *rsurf_dev, double *K_dev, void *stream)
 {
-    if (nA <= 0 || nw <= 0) return GORT_OK;
+    if (nA <= 0 || nw < 0 || (nw == 0 && !K_dev)) return GORT_OK;      // nw = 0: the proportions K alone
     hipLaunchKernelGGL(geometry_stream_kernel<true>, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        canopy_dev, angles_dev, nA, (double *)nullptr, K_dev, 0, L_dev, nw, rsurf_dev);
     return check_launch("geometry_stream_kernel<fused>");

@@ -178,10 +178,12 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
         PIPE_HIP(hipStreamWaitEvent(ks, s.ev_in, 0));
         int rc = GORT_OK;
         if (nw > 0 && s.d_rsurf) rc = gort_rsurf_stream_dev(p->e, s.d_ang, n, s.d_rsurf, s.d_scomp, s.d_K);
+        else if (nw == 0 && s.d_K) rc = gort_rsurf_stream_dev(p->e, s.d_ang, n, nullptr, nullptr, s.d_K);   // proportions only
         if (rc == GORT_OK && s.d_energy && nw > 0) rc = gort_energy_stream_dev(p->e, s.d_ang, n, s.d_energy);
         if (rc) return rc;
         PIPE_HIP(hipEventRecord(s.ev_k, ks));
         PIPE_HIP(hipStreamWaitEvent(p->s_out, s.ev_k, 0));
+        if (nw == 0 && s.d_K) PIPE_HIP(hipMemcpyAsync(s.h_K, s.d_K, D * 4 * nn, hipMemcpyDeviceToHost, p->s_out));
         if (nw > 0) {
             if (s.d_rsurf) {
                 PIPE_HIP(hipMemcpyAsync(s.h_rsurf, s.d_rsurf, D * nn * nw, hipMemcpyDeviceToHost, p->s_out));

@@ -466,7 +466,7 @@ int main(int argc, char **argv)
     }
 
     std::vector<double> rsoil(nw), rleaf(nw), tleaf(nw);
-    if (gort_spectra(&o.leaf, wl.data(), nw, rsoil.data(), rleaf.data(), tleaf.data()) != GORT_OK)
+    if (nw > 0 && gort_spectra(&o.leaf, wl.data(), nw, rsoil.data(), rleaf.data(), tleaf.data()) != GORT_OK)
         die("%s\n", gort_last_error());
 
     // one engine + one pipe of chunks in flight per device (--gpus N / GORTT_DEVICES="0,1,..": chunk k goes to
@@ -523,9 +523,8 @@ int main(int argc, char **argv)
                 }
             }
             if (o.prnprop) {
-                const double zero[4] = {0.0, 0.0, 0.0, 0.0};
                 dst.text("[ ", 2);
-                dst.nums(nw > 0 ? c.K + 4 * a : zero, 4);
+                dst.nums(c.K + 4 * a, 4);            // without wavelengths too (`N 0`): gortt.c:424-449 run in front of the loop
                 dst.text("] ", 2);
             }
             if (o.energy) dst.nums(c.energy + (size_t)a * nw * 3, 3L * nw);

@@ -201,7 +201,10 @@ int  gort_engine_get_member(gort_engine *e, int member, gort_canopy *canopy, dou
  *   angles[nA][4]   degrees
  *   rsurf[nA][nw]
  *   scomp[nA][nw][4]  C,G,T,Z (-prnspec), may be NULL
- *   K[nA][4]          Kc,Kg,Kt,Kz (-prnprop), may be NULL */
+ *   K[nA][4]          Kc,Kg,Kt,Kz (-prnprop), may be NULL
+ * gort_rsurf_stream_dev with rsurf = scomp = NULL and K given: the viewed proportions alone, which need a canopy but
+ * no spectra (the reference prints them for a header without wavelengths, `N 0`: gortt.c:424-449 run in front of
+ * the wavelength loop). */
 int  gort_rsurf_stream(gort_engine *e, const double *angles, long nA,
                        double *rsurf, double *scomp, double *K);
 int  gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA,

@@ -129,6 +129,20 @@ def cli_cases():
         ("wl_out_of_range", ["-LAI", "4.0"], "1 1 399\n10 0 30 20\n"),
         ("missing_lut_file", ["-LAI", "4.0", "-P", "/nonexistent/lut.dat"], readme),
         ("header_only_na", ["-LAI", "4.0"], "1\n"),
+        # round 2: empty and ragged inputs
+        ("zero_lines", ["-LAI", "4.0"], "0 2 500 600\n"),
+        ("zero_bands", ["-LAI", "4.0", "-prnprop"], "2 0\n10 0 30 20\n-20 5 40 100\n"),
+        ("more_lines_than_announced", ["-LAI", "4.0"], "1 1 800\n10 0 30 20\n20 0 30 20\n30 0 30 20\n"),
+        ("no_final_newline", ["-LAI", "4.0"], "2 2 650 865\n10 0 30 20\n20 10 35 200"),
+        ("crlf_lines", ["-LAI", "4.0"], "2 2 650 865\r\n10 0 30 20\r\n20 10 35 200\r\n"),
+        ("blank_line_in_stream", ["-LAI", "4.0"], "3 1 800\n10 0 30 20\n\n20 0 30 20\n"),
+        ("three_numbers_on_a_line", ["-LAI", "4.0"], "2 1 800\n10 0 30 20\n10 0 30\n"),
+        ("energy_prnprop", ["-LAI", "4.0", "-energy", "-prnprop"], "2 2 650 865\n0 0 0 0\n-45 90 60 300\n"),
+        ("scientific_notation", ["-LAI", "4.0"], "1 2 6.5e2 8.65E+02\n1e1 0.0e0 3.0e+1 2e1\n"),
+        ("negative_count", ["-LAI", "4.0"], "-1 1 800\n10 0 30 20\n"),
+        ("wl_at_the_limits", ["-LAI", "4.0"], "1 2 400 2500\n10 0 30 20\n"),
+        ("lai_zero", ["-LAI", "0"], "1 2 650 865\n10 0 30 20\n"),
+        ("diffuse_one", ["-LAI", "4.0", "-diffuse", "1.0", "-prnprop"], "1 2 650 865\n10 0 30 20\n"),
     ]
     out = []
     for name, args, stdin in cases:
