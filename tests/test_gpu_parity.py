@@ -437,6 +437,48 @@ def test_cli_text_identical_to_reference(case, tmp_path):
     assert errtxt == case["stderr"]
 
 
+def test_cli_random_command_lines_identical_to_reference():
+    """160 random command lines and inputs (tools/make_golden.py clifuzz: flag combinations in mixed case, old / new style
+    crown geometry, spectral overrides, output flags, odd wavelengths, negative zeniths, wild azimuths, horizon and
+    hot-spot lines) through the drop-in executable: exit code and stderr equal, stdout equal BYTE FOR BYTE - except that
+    a printed value may differ by one unit of the sixth decimal where the two computations straddle a rounding boundary
+    (relative differences of 1e-13 meet boundaries 1e-6 apart: a handful of the ~30 000 numbers at most)."""
+    cases = json.load(open(os.path.join(GOLDEN, "cli_fuzz_cases.json")))
+    assert len(cases) >= 150
+    identical, ulp6, numbers = 0, 0, 0
+    for case in cases:
+        run = subprocess.run([api.GORTT_BIN] + case["args"], input=case["stdin"].encode(), capture_output=True, timeout=300)
+        out, errtxt = run.stdout.decode("latin-1"), run.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt")
+        assert run.returncode == case["rc"], (case["name"], case["args"], errtxt)
+        assert errtxt == case["stderr"], (case["name"], case["args"])
+        if out == case["stdout"]:
+            identical += 1
+            numbers += len(out.split())
+            continue
+        a, b = out.split("\n"), case["stdout"].split("\n")
+        assert len(a) == len(b) and a[0] == b[0], (case["name"], case["args"])
+        for la, lb in zip(a[1:], b[1:]):
+            ta, tb = la.split(), lb.split()
+            assert len(ta) == len(tb), (case["name"], la, lb)
+            if ta and abs(float(ta[0])) == 90.0:
+                # a view zenith of exactly 90 degrees is the singular direction (tan = 1.6e16): Kc and Kt are +-1e14 and
+                # what they leave of each other is rounding; only the shape of the row and its NaN pattern are compared
+                assert [("nan" in x) for x in ta] == [("nan" in y) for y in tb], (case["name"], la, lb)
+                continue
+            for x, y in zip(ta, tb):
+                numbers += 1
+                if x == y:
+                    continue
+                assert x not in "[]{}" and y not in "[]{}" and "nan" not in x + y, (case["name"], x, y)
+                # (at a view zenith of exactly 90 degrees Kc is ~1e14: there the last printed digits are rounding, 1e-16 relative)
+                fx, fy = float(x), float(y)
+                assert abs(fx - fy) <= max(1.0000001e-6, 1e-12 * abs(fy)), (case["name"], case["args"], x, y)
+                ulp6 += 1
+    print("cli fuzz: %d of %d outputs byte-identical, %d of %d numbers one unit of the 6th decimal apart" %
+          (identical, len(cases), ulp6, numbers))
+    assert ulp6 <= 20 and identical >= len(cases) - 20
+
+
 def _run_gortt(args, stdin_bytes):
     run = subprocess.run([api.GORTT_BIN] + args, input=stdin_bytes, capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode("latin-1")

@@ -421,6 +421,72 @@ def fuzz_goldens():
     print("fuzz goldens done: %d canopies, %d with BRDF rows" % (len(specs), len(pick)))
 
 
+def cli_fuzz_goldens(n_cases=160, seed=777):
+    """Random command lines and inputs through the REAL reference CLI: flag combinations (old / new style crown geometry,
+    -LAI / -favd, -beta, -diffuse, leaf / soil overrides, PROSPECT and Price flags in mixed case, -q08_pn_kopen,
+    output flags), 1..6 wavelengths incl. non-integers and the limits, 1..8 angle lines incl. negative zeniths,
+    azimuths beyond +-360, near-horizon and horizon geometries.  stdout / stderr / rc kept; the test compares bytes."""
+    rng = np.random.default_rng(seed)
+    out, tried = [], 0
+
+    def num(x, nd=None):
+        if nd is None:
+            nd = int(rng.integers(0, 7))
+        t = ("%." + str(nd) + "f") % x
+        return t
+
+    while len(out) < n_cases and tried < 4 * n_cases:
+        tried += 1
+        args = []
+        style = rng.integers(0, 3)
+        if style == 0:
+            args += ["-HB", num(rng.uniform(0.5, 4), 3), "-BR", num(rng.uniform(0.4, 4), 3), "-PCC", num(rng.uniform(0.05, 0.95), 3)]
+        elif style == 1:
+            h1 = rng.uniform(1, 6)
+            args += ["-h1", num(h1, 2), "-h2", num(h1 + rng.uniform(0.5, 12), 2), "-b", num(rng.uniform(0.5, 6), 2),
+                     "-r", num(rng.uniform(0.4, 2.5), 2), "-lambda", num(rng.uniform(0.02, 0.9), 3)]
+        args += (["-LAI", num(rng.uniform(0.1, 8), 2)] if rng.random() < 0.7 else ["-favd", num(rng.uniform(0.05, 1.5), 3)])
+        if rng.random() < 0.25: args += ["-beta", num(rng.uniform(0, 1), 2)]
+        if rng.random() < 0.25: args += [str(rng.choice(["-diffuse", "-DIFF", "-diffusivity"])), num(rng.uniform(0, 1), 2)]
+        if rng.random() < 0.15: args += ["-alb_leaf", num(rng.uniform(0.05, 0.98), 2)]
+        if rng.random() < 0.15: args += ["-alb_soil", num(rng.uniform(0.01, 0.6), 2)]
+        for flag, lo, hi in (("-N", 1.0, 3.0), ("-Cab", 5, 80), ("-car", 1, 20), ("-cw", 0.002, 0.04), ("-CM", 0.001, 0.02),
+                             ("-canth", 0, 5), ("-cbrown", 0, 1), ("-rsl1", 0.05, 0.5), ("-rsl2", -0.1, 0.2), ("-RSL3", -0.05, 0.05),
+                             ("-rsl4", -0.01, 0.01)):
+            if rng.random() < 0.2: args += [flag, num(rng.uniform(lo, hi), 4)]
+        if rng.random() < 0.12: args += ["-q08_pn_kopen"]
+        nw = int(rng.integers(1, 7))
+        if rng.random() < 0.35: args += ["-prnprop"]
+        if rng.random() < 0.25: args += ["-prnspec"]
+        if rng.random() < 0.15: args += ["-energy"]
+        order = rng.permutation(len(args)) if False else None   # flag order matters (new style switches old style off): keep
+        wl = [float(rng.choice([400.0, 2500.0, rng.uniform(400, 2500), float(rng.integers(400, 2501))])) for _ in range(nw)]
+        na = int(rng.integers(1, 9))
+        lines = []
+        for _ in range(na):
+            kind = rng.integers(0, 6)
+            vza, sza = rng.uniform(-85, 85), rng.uniform(0, 80)
+            if kind == 0: vza, sza = rng.uniform(86, 89.9), rng.uniform(0, 89.9)
+            if kind == 1: sza = rng.uniform(-80, -1)
+            if kind == 2: vza = sza                                   # hot spot direction when the azimuths agree
+            vaa, saa = rng.uniform(-400, 760), rng.uniform(-400, 760)
+            if kind == 2: vaa = saa
+            if kind == 3: vza, sza = float(rng.integers(-89, 90)), float(rng.integers(0, 90))     # table nodes
+            # exactly the horizon (the reference prints -nan); zeniths BEYOND 90 degrees are left out: there the reference
+            # reads past the end of its 91-entry tables and prints whatever lies behind them (DESIGN.md 1, deviations)
+            if kind == 4 and rng.random() < 0.3: vza = 90.0
+            lines.append(" ".join(num(v) for v in (vza, vaa, sza, saa)))
+        stdin = "%d %d %s\n" % (na, nw, " ".join(num(w, int(rng.integers(0, 4))) for w in wl)) + "\n".join(lines) + "\n"
+        rc, so, se = run(GORTT, args, stdin)
+        if rc not in (0, 1) or len(so) > 20000:
+            continue                                                  # a crash of the reference is not a fixture
+        out.append({"name": "fuzz%03d" % len(out), "args": args, "stdin": stdin, "rc": rc, "stdout": so,
+                    "stderr": se.replace(GORTT, "gortt")})
+    print("cli fuzz: %d cases kept of %d tried; %d with rc 1, %d with -nan" %
+          (len(out), tried, sum(c["rc"] for c in out), sum("-nan" in c["stdout"] for c in out)))
+    json.dump(out, open(os.path.join(GOLD, "cli_fuzz_cases.json"), "w"), indent=0)
+
+
 def main():
     for b in (GORTT, GORTT_FP):
         if not os.path.exists(b):
@@ -432,6 +498,7 @@ def main():
     if "config" in what: config_goldens()
     if "c5" in what: c5_goldens()
     if "fuzz" in what: fuzz_goldens()
+    if "clifuzz" in what: cli_fuzz_goldens()
 
 
 if __name__ == "__main__":
