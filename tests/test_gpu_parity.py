@@ -479,6 +479,36 @@ def test_cli_random_command_lines_identical_to_reference():
     assert ulp6 <= 20 and identical >= len(cases) - 20
 
 
+def test_cli_long_stream_identical_to_reference():
+    """4000 random lines x 3 bands with -prnspec -prnprop from the real reference (tests/golden/cli_bulk.json.gz) through
+    the drop-in in SMALL chunks (many chunks in flight, several formatting threads) and in one chunk: the same bytes
+    either way, and the reference's bytes up to a unit of the sixth decimal in a handful of the 76 000 numbers."""
+    import gzip
+    case = json.load(gzip.open(os.path.join(GOLDEN, "cli_bulk.json.gz"), "rt"))
+    outs = []
+    for env in ({"GORTT_CHUNK_MB": "1"}, {"GORTT_CHUNK_MB": "1", "GORTT_THREADS": "7"}, {}):
+        e = dict(os.environ)
+        e.update(env)
+        run = subprocess.run([api.GORTT_BIN] + case["args"], input=case["stdin"].encode(), capture_output=True, timeout=600, env=e)
+        assert run.returncode == 0 and run.stderr == b"", run.stderr[-2000:]
+        outs.append(run.stdout.decode("latin-1"))
+    assert outs[0] == outs[1] == outs[2]
+    a, b = outs[0].split("\n"), case["stdout"].split("\n")
+    assert len(a) == len(b) and a[0] == b[0]
+    apart = 0
+    for la, lb in zip(a[1:], b[1:]):
+        if la == lb:
+            continue
+        ta, tb = la.split(), lb.split()
+        assert len(ta) == len(tb)
+        for x, y in zip(ta, tb):
+            if x != y:
+                assert abs(float(x) - float(y)) <= 1.0000001e-6, (x, y)
+                apart += 1
+    print("cli bulk: %d numbers one unit of the 6th decimal apart" % apart)
+    assert apart <= 12
+
+
 def _run_gortt(args, stdin_bytes):
     run = subprocess.run([api.GORTT_BIN] + args, input=stdin_bytes, capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode("latin-1")

@@ -487,6 +487,23 @@ def cli_fuzz_goldens(n_cases=160, seed=777):
     json.dump(out, open(os.path.join(GOLD, "cli_fuzz_cases.json"), "w"), indent=0)
 
 
+def cli_bulk_golden(n=4000, seed=4040):
+    """One LONG stream through the real reference (4000 random lines x 3 bands, -prnspec -prnprop): what the drop-in's
+    chunked, multi-threaded text path has to reproduce row for row.  Kept gzipped (stdin + stdout)."""
+    import gzip
+    rng = np.random.default_rng(seed)
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(-360, 720, n), rng.uniform(0, 89, n), rng.uniform(-360, 720, n)], 1)
+    ang[::97, 2] = np.round(ang[::97, 2])                              # some table nodes
+    ang[::101, 0] = ang[::101, 2]; ang[::101, 1] = ang[::101, 3]       # some hot-spot directions
+    stdin = "%d 3 550.5 865 1650.25\n" % n + "".join("%.5f %.4f %.6f %.3f\n" % tuple(r) for r in ang)
+    args = ["-LAI", "3.5", "-prnspec", "-prnprop"]
+    rc, so, se = run(GORTT, args, stdin)
+    assert rc == 0 and so.count("\n") == n + 1
+    with gzip.open(os.path.join(GOLD, "cli_bulk.json.gz"), "wt") as f:
+        json.dump({"args": args, "stdin": stdin, "stdout": so, "stderr": se}, f)
+    print("cli bulk: %d lines, %d bytes of reference output" % (n, len(so)))
+
+
 def main():
     for b in (GORTT, GORTT_FP):
         if not os.path.exists(b):
@@ -499,6 +516,7 @@ def main():
     if "c5" in what: c5_goldens()
     if "fuzz" in what: fuzz_goldens()
     if "clifuzz" in what: cli_fuzz_goldens()
+    if "clibulk" in what: cli_bulk_golden()
 
 
 if __name__ == "__main__":
