@@ -509,6 +509,49 @@ def test_cli_long_stream_identical_to_reference():
     assert apart <= 12
 
 
+def _wide_stream_lines(n, seed):
+    # the same lines as tools/make_golden.py::wide_stream_lines (the reference computed a sample of them)
+    rng = np.random.default_rng(seed)
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(-360, 720, n), rng.integers(0, 90, n).astype(float), rng.uniform(-360, 720, n)], 1)
+    k = n // 2
+    ang[k:, 2] = rng.uniform(0, 89, n - k)
+    ang[::211, 0] = ang[::211, 2]; ang[::211, 1] = ang[::211, 3]
+    ang[::307, 0] = 89.5
+    return np.round(ang, 6)
+
+
+def test_wide_stream_kernels_against_the_reference():
+    """The WIDE stream kernels pinned to the real reference itself (not only to the restatement): 60 000 lines x 180
+    bands (as many bands as the reference's 999-character header takes; 1.08e7 samples: the per-line flat kernel, and
+    the grouped form for the half of the stream with 90 distinct sun zeniths) - 100 of the lines were computed by the
+    reference at %.17g (tests/golden/wide_stream.npz)."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, "wide_stream.npz"))
+    wl, pick, ref = g["wl"], g["pick"], g["rsurf"]
+    hb, br, pcc, lai = (float(x) for x in g["canopy"])
+    ang = _wide_stream_lines(int(g["n_lines"]), int(g["seed"]))
+    eng = api.Engine()
+    eng.set_canopy(api.gap_probabilities(api.make_canopy(newstyle=(hb, br, pcc), lai=lai)))
+    eng.set_spectra(*api.spectra(wl))
+    a = torch.as_tensor(ang, device="cuda")
+    worst = {}
+    for name, mode, lines in (("per-line", 0, slice(None)), ("grouped", 2, slice(0, len(ang) // 2))):
+        sub = a[lines].contiguous()
+        out = torch.full((sub.shape[0], len(wl)), -7.0, dtype=torch.float64, device="cuda")
+        eng.set_stream_grouping(mode)
+        torch.cuda.synchronize()
+        eng.rsurf_stream_dev(sub, out)
+        eng.synchronize()
+        assert eng.stream_form() == name
+        idx = pick[pick < sub.shape[0]]
+        got = out[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+        worst[name] = err(got, ref[: len(idx)])
+        assert worst[name] <= REGRESSION, (name, worst)
+    eng.set_stream_grouping(0)
+    eng.close()
+    print("wide stream vs reference:", worst)
+
+
 def _run_gortt(args, stdin_bytes):
     run = subprocess.run([api.GORTT_BIN] + args, input=stdin_bytes, capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode("latin-1")

@@ -504,6 +504,35 @@ def cli_bulk_golden(n=4000, seed=4040):
     print("cli bulk: %d lines, %d bytes of reference output" % (n, len(so)))
 
 
+def wide_stream_lines(n=60000, seed=9090):
+    """The angle lines of the wide-stream fixture: shared by the generator and tests/test_gpu_parity.py."""
+    rng = np.random.default_rng(seed)
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(-360, 720, n), rng.integers(0, 90, n).astype(float), rng.uniform(-360, 720, n)], 1)
+    k = n // 2
+    ang[k:, 2] = rng.uniform(0, 89, n - k)                              # half of them with a sun zenith of their own
+    ang[::211, 0] = ang[::211, 2]; ang[::211, 1] = ang[::211, 3]        # hot spot
+    ang[::307, 0] = 89.5
+    return np.round(ang, 6)
+
+
+def wide_stream_golden():
+    """The WIDE stream kernels (>= 128 bands, >= 4.2e6 samples per call: the per-line flat kernel and the grouped form)
+    against the real reference and not only against our restatement: 180 bands (what fits the reference's 999-character
+    header) x 60 000 lines run on the GPU, of which the reference computes a sample of ~100 at %.17g here."""
+    wl = np.round(np.linspace(400, 2500, 180))
+    ang = wide_stream_lines()
+    pick = np.unique(np.concatenate([np.arange(0, len(ang), 641), [0, 211, 307, 30000, 30001, len(ang) - 1]]))
+    args = ["-HB", "2.0", "-BR", "2.0", "-PCC", "0.6", "-LAI", "3.3"]
+    rc, so, se = run(GORTT_FP, args, stream_text(ang[pick], wl))
+    assert rc == 0, se
+    rows = [ln.split() for ln in so.strip().split("\n")[1:]]
+    vals = np.array([[float(t) for t in r[4:]] for r in rows])
+    assert vals.shape == (len(pick), len(wl))
+    np.savez_compressed(os.path.join(GOLD, "wide_stream.npz"), wl=wl, pick=pick, rsurf=vals,
+                        canopy=np.array([2.0, 2.0, 0.6, 3.3]), n_lines=len(ang), seed=9090)
+    print("wide stream: %d sample lines x %d bands from the reference, NaN rows %d" % (len(pick), len(wl), int(np.isnan(vals).all(1).sum())))
+
+
 def main():
     for b in (GORTT, GORTT_FP):
         if not os.path.exists(b):
@@ -517,6 +546,7 @@ def main():
     if "fuzz" in what: fuzz_goldens()
     if "clifuzz" in what: cli_fuzz_goldens()
     if "clibulk" in what: cli_bulk_golden()
+    if "wide" in what: wide_stream_golden()
 
 
 if __name__ == "__main__":
