@@ -552,6 +552,37 @@ def test_wide_stream_kernels_against_the_reference():
     print("wide stream vs reference:", worst)
 
 
+def test_lut_kernel_against_the_reference():
+    """The headline kernel pinned to the real reference directly: the full integer-degree hemisphere grid x 180 bands
+    (4.3 GB LUT, expand_flat_kernel with its panels, XCD ranges and slab edges) computed in two slabs; 169 of its
+    nodes were computed by the reference at %.17g (tests/golden/lut_nodes.npz), incl. the corners of the grid and two
+    horizon rows that are -nan in the reference."""
+    import torch
+    g = np.load(os.path.join(GOLDEN, "lut_nodes.npz"))
+    wl, nodes, ref = g["wl"], g["nodes"], g["rsurf"]
+    grid = api.hemisphere_grid()
+    eng = api.Engine()
+    eng.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
+    eng.set_spectra(*api.spectra(wl))
+    rows = grid.nsza * grid.nvza
+    lut = torch.full((rows * grid.nphi, len(wl)), -7.0, dtype=torch.float64, device="cuda")
+    cut = 3001                                              # an odd cut: both slabs start and end off the chunk grid
+    torch.cuda.synchronize()
+    eng.rsurf_grid_dev(grid, 0, cut, lut[: cut * grid.nphi])
+    eng.rsurf_grid_dev(grid, cut, rows, lut[cut * grid.nphi:])
+    eng.synchronize()
+    idx = (nodes[:, 0] * grid.nvza + nodes[:, 1]) * grid.nphi + nodes[:, 2]
+    got = lut[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+    bad = np.where(np.isnan(got) != np.isnan(ref))
+    assert bad[0].size == 0, (nodes[np.unique(bad[0])], got[bad][:4], ref[bad][:4])
+    assert np.isnan(ref).all(axis=1).sum() >= 2
+    e = err(got, ref)
+    print("LUT kernel vs reference: %.2e over %d nodes x %d bands" % (e, len(nodes), len(wl)))
+    assert e <= REGRESSION
+    assert not bool((lut == -7.0).any())                    # every sample of both slabs written
+    eng.close()
+
+
 def _run_gortt(args, stdin_bytes):
     run = subprocess.run([api.GORTT_BIN] + args, input=stdin_bytes, capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode("latin-1")

@@ -533,6 +533,25 @@ def wide_stream_golden():
     print("wide stream: %d sample lines x %d bands from the reference, NaN rows %d" % (len(pick), len(wl), int(np.isnan(vals).all(1).sum())))
 
 
+def lut_nodes_golden(n=160, seed=3131):
+    """The LUT kernel (expand_flat_kernel, the headline kernel) against the real reference directly: 160 random nodes
+    (sun zenith, view zenith, azimuth) of the integer-degree metric grid x 180 bands at %.17g, plus the grid's corners
+    and the horizon rows.  The reference sees a node as the line `vza phi sza 0`."""
+    rng = np.random.default_rng(seed)
+    wl = np.round(np.linspace(400, 2500, 180))
+    nodes = np.stack([rng.integers(0, 91, n), rng.integers(0, 91, n), rng.integers(0, 361, n)], 1)
+    nodes = np.concatenate([nodes, [[0, 0, 0], [0, 0, 360], [89, 89, 0], [89, 89, 180], [30, 30, 0], [30, 89, 90], [89, 30, 270],
+                                    [90, 45, 10], [45, 90, 10]]])       # the last two: horizon rows, -nan in the reference
+    ang = np.stack([nodes[:, 1], nodes[:, 2], nodes[:, 0], np.zeros(len(nodes))], 1).astype(float)
+    args = ["-LAI", "4.0"]
+    rc, so, se = run(GORTT_FP, args, stream_text(ang, wl))
+    assert rc == 0, se
+    vals = np.array([[float(t) for t in ln.split()[4:]] for ln in so.strip().split("\n")[1:]])
+    assert vals.shape == (len(nodes), len(wl))
+    np.savez_compressed(os.path.join(GOLD, "lut_nodes.npz"), wl=wl, nodes=nodes, rsurf=vals)
+    print("lut nodes: %d nodes x %d bands from the reference, NaN rows %d" % (len(nodes), len(wl), int(np.isnan(vals).all(1).sum())))
+
+
 def main():
     for b in (GORTT, GORTT_FP):
         if not os.path.exists(b):
@@ -547,6 +566,7 @@ def main():
     if "clifuzz" in what: cli_fuzz_goldens()
     if "clibulk" in what: cli_bulk_golden()
     if "wide" in what: wide_stream_golden()
+    if "lutnodes" in what: lut_nodes_golden()
 
 
 if __name__ == "__main__":
