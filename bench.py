@@ -103,7 +103,9 @@ def cpu_baseline(wl, budget_s=20.0, force_port=False, procs=1):
 def _ref_grid_worker(args):
     """One process of cpu_baseline_grid: the reference's gortt_rsurf (oracle/_ref/libgortt_ref.so, built from
     /root/reference by oracle/Makefile) on a share of the metric grid's nodes, all 2101 bands, no text I/O."""
-    so, nodes, wl = args
+    so, nodes, wl = args[:3]
+    keep = args[3] if len(args) > 3 else 0                  # return the rows of the first `keep` nodes (parity_reference)
+    rows = []
     import ctypes as C
     L = C.CDLL(so)
     D = C.c_double
@@ -127,7 +129,9 @@ def _ref_grid_worker(args):
         raa = abs(raa - 2 * np.pi * int(0.5 + raa / (2 * np.pi)))
         L.refshim_rsurf(vza, vaa, sza, saa, raa, po, ps, pk, pp)
         acc += out[0]
-    return time.perf_counter() - t0, len(nodes), acc
+        if len(rows) < keep:
+            rows.append(out.copy())
+    return time.perf_counter() - t0, len(nodes), acc, rows
 
 
 def cpu_baseline_grid(wl, procs, budget_s=12.0):
@@ -148,7 +152,8 @@ def cpu_baseline_grid(wl, procs, budget_s=12.0):
         return [tuple(int(x) for x in r) for r in np.stack([rng.integers(0, 90, n), rng.integers(0, 90, n), rng.integers(0, 361, n)], 1)]
     ctx = mp.get_context("spawn")                      # never fork a process that has initialised the GPU
     with ctx.Pool(procs) as pool:
-        dt, n, _ = pool.apply(_ref_grid_worker, ((so, draw(60), wl),))
+        first = draw(60)
+        dt, n, _, rows = pool.apply(_ref_grid_worker, ((so, first, wl, 24),))
         per_node = dt / n
         n_each = int(min(max(budget_s / per_node, 100), 20000))
         t0 = time.perf_counter()
@@ -156,7 +161,9 @@ def cpu_baseline_grid(wl, procs, budget_s=12.0):
         wall = time.perf_counter() - t0
     total = sum(r[1] for r in res) * len(wl)
     busy = max(r[0] for r in res)
-    return {"value": total / busy, "unit": "samples/s", "cores": procs, "kind": "reference",
+    # the first 24 nodes' rows travel back for a parity check of the GPU LUT against the reference itself (main())
+    return {"_check_nodes": first[:len(rows)], "_check_rows": np.array(rows),
+            "value": total / busy, "unit": "samples/s", "cores": procs, "kind": "reference",
             "sample": "reference gortt_rsurf (oracle/_ref/libgortt_ref.so = /root/reference compiled -O3; direct gap "
                       "probabilities, no text I/O): %d processes x %d random nodes of the metric grid x %d bands, slowest "
                       "process %.1f s (wall %.1f s incl. each process's 0.4 s gap-probability setup); cpu: %s"
@@ -359,6 +366,20 @@ def main():
             ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
             # (1) the SAME workload shape through the reference's own gortt_rsurf (grid nodes x 2101 bands, no text)
             same = cpu_baseline_grid(wl, ncores, budget_s=12.0)
+            if same is not None:
+                # the reference's own rows of 24 of its nodes, all 2101 bands, against the LUT this run wrote
+                cn, cr = np.array(same.pop("_check_nodes")), same.pop("_check_rows")
+                inside = cn[:, 0] < grid.nsza                 # reduced grids (--nsza, tests) hold only the first sun zeniths
+                cn, cr = cn[inside], cr[inside]
+            if same is not None and len(cn):
+                at = (cn[:, 0] * grid.nvza + cn[:, 1]) * grid.nphi + cn[:, 2]
+                mine = lut[torch.as_tensor(at, device="cuda")].cpu().numpy()
+                fin = np.isfinite(cr)
+                out["parity_reference"] = {
+                    "max_rel_err": float(np.max(np.abs(mine[fin] - cr[fin]) / np.maximum(np.abs(cr[fin]), 1e-12))),
+                    "nan_pattern_equal": bool(np.array_equal(np.isnan(mine), np.isnan(cr))),
+                    "samples_checked": int(cr.size), "tolerance": 1e-5,
+                    "against": "the reference's gortt_rsurf itself (oracle/_ref/libgortt_ref.so), %d nodes x %d bands" % cr.shape}
             # (2) the reference as a user runs it: the CLI with a -P LUT, random lines x 180 bands, text to /dev/null
             cli = cpu_baseline(wl, budget_s=10.0, procs=ncores)
             out["cpu_baseline"] = same if same is not None else cli
@@ -375,6 +396,10 @@ def main():
     # a headline number without its parity check is not a result: fail the run
     if rank == 0 and not args.no_parity:
         bad = parity is None or "error" in parity or not parity["nan_pattern_equal"] or not parity["max_rel_err"] <= parity["tolerance"]
+        pr = out.get("parity_reference")
+        if pr is not None and (not pr["nan_pattern_equal"] or not pr["max_rel_err"] <= pr["tolerance"]):
+            bad = True
+            parity = pr
         if bad:
             print("bench.py: parity check failed or missing: %r" % (parity,), file=sys.stderr)
             sys.exit(3)
