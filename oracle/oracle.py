@@ -171,3 +171,53 @@ def gauleg(n=32):
     x = np.zeros(n); w = np.zeros(n)
     lib().gort_o_gauleg(D(-1.0), D(1.0), _p(x), _p(w), n)
     return x, w
+
+
+# ---- the REAL reference at function level, where its build travelled (oracle/_ref/libgortt_ref.so, oracle/Makefile) ----
+REF_SO = os.path.join(HERE, "_ref", "libgortt_ref.so")
+
+
+def _reference_rows_worker(args):
+    flags, angles_deg, wl = args
+    L = C.CDLL(REF_SO)
+    argv_list = [b"gortt"] + [f.encode() for f in flags]
+    argv = (C.c_char_p * len(argv_list))(*argv_list)
+    L.refshim_canopy(len(argv_list), argv)
+    nw = len(wl)
+    w = np.ascontiguousarray(wl, dtype=np.float64)
+    rs, rl, tl = np.zeros(nw), np.zeros(nw), np.zeros(nw)
+    L.refshim_spectra(_p(w), nw, _p(rs), _p(rl), _p(tl))
+    L.refshim_rsurf.argtypes = [D] * 5 + [C.POINTER(D)] * 4
+    out, sc, K, pr = np.zeros(nw), np.zeros(4 * nw), np.zeros(4), np.zeros(4)
+    rows = np.empty((len(angles_deg), nw))
+    rad = np.pi / 180.0
+    for i, (vza, vaa, sza, saa) in enumerate(angles_deg):
+        # main()'s normalisation (gortt.c:240-279) for non-negative zeniths and azimuths within [0, 360]
+        assert vza >= 0 and sza >= 0 and 0 <= vaa <= 360 and 0 <= saa <= 360
+        vza, vaa, sza, saa = vza * rad, vaa * rad, sza * rad, saa * rad
+        raa = saa - vaa
+        raa = abs(raa - 2 * np.pi * int(0.5 + raa / (2 * np.pi)))
+        L.refshim_rsurf(vza, vaa, sza, saa, raa, _p(out), _p(sc), _p(K), _p(pr))
+        rows[i] = out
+    return rows
+
+
+def reference_rows(flags, angles_deg, wl, timeout=600):
+    """rsurf[len(angles)][len(wl)] from the reference's own gortt_rsurf (any number of bands - the CLI's 999-character
+    header is not in the way here), in a process of its own (the reference keeps global state and brings a Fortran
+    runtime); None where the reference build is absent."""
+    if not os.path.exists(REF_SO):
+        return None
+    import json
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        job, res = os.path.join(d, "job.json"), os.path.join(d, "rows.npy")
+        json.dump({"flags": list(flags), "angles": [[float(x) for x in a] for a in angles_deg], "wl": [float(w) for w in wl]},
+                  open(job, "w"))
+        code = ("import json, sys, numpy as np; sys.path.insert(0, %r); from oracle import oracle as O; j = json.load(open(%r)); "
+                "np.save(%r, O._reference_rows_worker((j['flags'], j['angles'], j['wl'])))" % (os.path.dirname(HERE), job, res))
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=timeout)
+        if run.returncode != 0:
+            raise RuntimeError("reference worker failed: " + run.stderr.decode()[-2000:])
+        return np.load(res)

@@ -583,6 +583,47 @@ def test_lut_kernel_against_the_reference():
     eng.close()
 
 
+def test_full_spectrum_stream_against_the_reference_function():
+    """2101 bands - more than the reference's CLI can read (999-character header) - against the reference's own
+    gortt_rsurf at function level (oracle/_ref/libgortt_ref.so travels with the snapshot; skipped where it is absent):
+    40 of 65 536 random lines through the per-line flat kernel and, for the 91-zenith half, the grouped form."""
+    import torch
+    if not os.path.exists(O.REF_SO):
+        pytest.skip("oracle/_ref/libgortt_ref.so did not travel")
+    rng = np.random.default_rng(808)
+    n = 65536
+    wl = np.arange(400.0, 2501.0)
+    ang = np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), rng.integers(0, 90, n).astype(float), rng.uniform(0, 360, n)], 1)
+    ang[n // 2:, 2] = rng.uniform(0, 89, n - n // 2)
+    pick = np.sort(rng.choice(n, 40, replace=False))
+    flags = ["-HB", "2.0", "-BR", "2.0", "-PCC", "0.6", "-LAI", "3.3"]
+    ref = O.reference_rows(flags, ang[pick], wl)
+    assert ref.shape == (40, 2101) and np.isfinite(ref).all()
+    eng = api.Engine()
+    eng.set_canopy(api.gap_probabilities(api.make_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3)))
+    eng.set_spectra(*api.spectra(wl))
+    a = torch.as_tensor(ang, device="cuda")
+    out = torch.full((n, 2101), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    eng.rsurf_stream_dev(a, out)
+    eng.synchronize()
+    assert eng.stream_form() == "per-line"
+    e1 = err(out[torch.as_tensor(pick, device="cuda")].cpu().numpy(), ref)
+    half = a[: n // 2].contiguous()
+    eng.set_stream_grouping(2)
+    out.fill_(-7.0)
+    torch.cuda.synchronize()
+    eng.rsurf_stream_dev(half, out[: n // 2])
+    eng.synchronize()
+    assert eng.stream_form() == "grouped"
+    lo = pick[pick < n // 2]
+    e2 = err(out[torch.as_tensor(lo, device="cuda")].cpu().numpy(), ref[: len(lo)])
+    eng.set_stream_grouping(0)
+    eng.close()
+    print("2101-band stream vs the reference function: per-line %.2e, grouped %.2e" % (e1, e2))
+    assert e1 <= REGRESSION and e2 <= REGRESSION
+
+
 def _run_gortt(args, stdin_bytes):
     run = subprocess.run([api.GORTT_BIN] + args, input=stdin_bytes, capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode("latin-1")
