@@ -71,6 +71,7 @@ DECLARED_SYMBOLS = [
     "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_format_f6", "gort_format_f6_row", "gort_lut_format", "gort_lut_read",
     "gort_device_count", "gort_dev_malloc", "gort_dev_free", "gort_memcpy_h2d", "gort_memcpy_d2h",
     "gort_gap_probabilities", "gort_gap_probabilities_dev", "gort_gap_cache_stats", "gort_gap_cache_clear",
+    "gort_canopy_check_geometry",
     "gort_canopy_key", "gort_lut_cache_store", "gort_lut_cache_load",
     "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",

@@ -242,6 +242,10 @@ extern "C" int gort_gap_probabilities(gort_canopy *members, int n_members)
         gc.misses += (long)todo.size();
     }
     if (todo.empty()) return GORT_OK;
+    for (int m : todo) {
+        const int rc = gort_canopy_check_geometry(&members[m]);
+        if (rc) return rc;
+    }
     if (gort_device_count() <= 0) return fail(GORT_ENODEVICE, "gort_gap_probabilities: no HIP device");
     const int n = (int)todo.size();
     std::vector<gort_canopy> packed;
@@ -476,8 +480,11 @@ static int stage_end(gort_engine *e)
 // caller: stage_begin() with room for n canopies, stage_end() afterwards
 static int upload_canopies(gort_engine *e, const gort_canopy *members, int n, int compute_gaps)
 {
-    int rc = e->canopy.reserve(sizeof(gort_canopy) * (size_t)n);
-    if (rc) return rc;
+    int rc;
+    if (compute_gaps)
+        for (int m = 0; m < n; ++m)
+            if ((rc = gort_canopy_check_geometry(&members[m]))) return rc;       // before anything is uploaded
+    if ((rc = e->canopy.reserve(sizeof(gort_canopy) * (size_t)n))) return rc;
     if ((rc = stage_h2d(e, e->canopy.p, members, sizeof(gort_canopy) * (size_t)n))) return rc;
     if (compute_gaps && (rc = launch_gap_probabilities(e->canopy.as<gort_canopy>(), n, e->stream))) return rc;
     if (n != e->n_members) e->have_spectra = false;    // spectra are per member

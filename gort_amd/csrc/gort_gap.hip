@@ -82,7 +82,10 @@ __device__ double projection_volume(const Crown &c, double t, double h)
 {
     const double st = sin(t);
     double vol = 0.0;
-    for (double z = c.h1_p + c.dz_p / 2.0; z <= c.h2_p; z += c.dz_p)
+    // <= 14 steps for any crown gort_canopy_init accepts (dz_p = (z2_p - z1_p) / 14 and h2_p - h1_p < z2_p - z1_p); the
+    // guard only keeps a step that rounds to nothing (a crown 1e300 wide) from spinning on the device for ever
+    int guard = 0;
+    for (double z = c.h1_p + c.dz_p / 2.0; z <= c.h2_p && guard < 64; z += c.dz_p, ++guard)
         vol += projected_section(c, t, st, h, z) * (c.dz_p);
     return vol;
 }
@@ -110,7 +113,8 @@ __device__ double expected_chord(const Crown &c, double hz, double thp)
     const double pcc = 1.0 / (c.h2_p - c.h1_p);
     const double st = sin(thp), ct = cos(thp);
     double es = 0.0;
-    for (double h = c.h1_p + dh / 2.0; h <= c.h2_p; h += dh)
+    int guard = 0;                                           // 20 steps; see projection_volume
+    for (double h = c.h1_p + dh / 2.0; h <= c.h2_p && guard < 64; h += dh, ++guard)
         es += mean_chord(c, hz, h, thp, st, ct) * (pcc * dh);
     return es;
 }

@@ -132,6 +132,23 @@ extern "C" int gort_canopy_init(gort_canopy *c)
     return GORT_OK;
 }
 
+// Degenerate crowns.  The reference has no check: a zero, negative, infinite or NaN radius ends in "Memory allocation
+// failed (gortt_alloc_1d)" (the size of its path-length histogram overflows), h1 = h2 or -HB 0 in an endless loop (a
+// midpoint rule whose step is 0), h2 < h1 in "Significant negative volume calculated in gortt_calc_vb" - all of them
+// inside gortt_gap_probabilities, i.e. not when the tables come from a -P file.  Here they are one clean error at the
+// same place: before the gap probabilities of such a crown would be computed.  (lambda and favd may be anything: the
+// reference carries NaN through, and so do the kernels.)
+extern "C" int gort_canopy_check_geometry(const gort_canopy *c)
+{
+    if (!c) return gort::fail(GORT_EINVAL, "gort_canopy_check_geometry: null canopy");
+    const double must_be_positive[] = {c->r, c->b, c->h2 - c->h1, c->ell, c->dz, c->dz_p, c->h2_p - c->h1_p};
+    for (double v : must_be_positive)
+        if (!(v > 0.0) || !std::isfinite(v))
+            return gort::fail(GORT_EINVAL, "invalid crown geometry (r=%g b=%g h1=%g h2=%g): radii and the height range of the "
+                              "crown centres must be positive and finite", c->r, c->b, c->h1, c->h2);
+    return GORT_OK;
+}
+
 // ------------------------------------------------------------------------ spectra
 
 extern "C" int gort_price_soil(const double *wl, int nw, const double rsl[4], double *rsoil)

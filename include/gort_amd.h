@@ -87,6 +87,10 @@ void gort_canopy_newstyle(gort_canopy *c, float hb, float br, float pcc);
 void gort_canopy_set_lai(gort_canopy *c, float lai);
 /* derived scalars + zenith/height tables: replaces gortt_init_params, gortt.c:632-868 */
 int  gort_canopy_init(gort_canopy *c);
+/* GORT_EINVAL for a crown whose gap probabilities the reference cannot compute either (it fails in an allocation,
+ * loops for ever or reports negative volumes: zero / negative / non-finite radii, h2 <= h1); called by every entry
+ * point that computes gap probabilities, before anything reaches the device */
+int  gort_canopy_check_geometry(const gort_canopy *c);
 
 /* Price soil reflectance: replaces gortt_price_soil, gortt.c:1286-1328 */
 int  gort_price_soil(const double *wl_nm, int nw, const double rsl[4], double *rsoil);

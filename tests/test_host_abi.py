@@ -318,3 +318,27 @@ def test_host_entry_points_under_sanitizers(tmp_path):
     assert build.returncode == 0, build.stderr.decode()[-3000:]
     run = subprocess.run([exe, "0.1"], capture_output=True, timeout=600, cwd=str(tmp_path))
     assert run.returncode == 0 and b"host_fuzz: ok" in run.stdout, (run.stdout[-2000:], run.stderr[-3000:])
+
+
+def test_degenerate_crown_geometry_is_refused_where_the_gap_probabilities_would_be_computed():
+    """The reference allocates a negative size, loops for ever or reports negative volumes for such crowns; the library
+    returns EINVAL from gort_canopy_check_geometry (called by every entry point that computes gap probabilities, before
+    anything reaches the device) - gort_canopy_init itself stays as permissive as gortt_init_params, because with
+    `-P file` the reference never looks at the crown that closely."""
+    L = api.lib()
+    L.gort_canopy_check_geometry.argtypes = [C.POINTER(api.Canopy)]
+    assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(lai=4.0))) == 0
+    assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3))) == 0
+    for kw in (dict(r=0.0), dict(r=-1.0), dict(b=0.0), dict(b=-2.0), dict(h1=5.0, h2=5.0), dict(h1=9.0, h2=5.0),
+               dict(r=float("nan")), dict(r=float("inf")), dict(h2=float("inf")), dict(r=1e300), dict(newstyle=(0.0, 2.0, 0.6)),
+               dict(newstyle=(2.0, 0.0, 0.6)), dict(newstyle=(2.0, -1.0, 0.6))):
+        c = api.make_canopy(lai=4.0, **kw)                                # init accepts it ...
+        assert L.gort_canopy_check_geometry(C.byref(c)) == api.EINVAL, kw  # ... the check does not
+        assert b"invalid crown geometry" in L.gort_last_error()
+        if api.device_count() == 0:
+            with pytest.raises(api.GortError) as e:                      # refused before the missing device is noticed
+                api.gap_probabilities(c)
+            assert e.value.code == api.EINVAL
+    # lambda and favd may be anything: the reference carries NaN through
+    assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(lai=float("inf")))) == 0
+    assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(lai=4.0, lam=-1.0))) == 0

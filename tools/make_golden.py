@@ -487,6 +487,47 @@ def cli_fuzz_goldens(n_cases=160, seed=777):
     json.dump(out, open(os.path.join(GOLD, "cli_fuzz_cases.json"), "w"), indent=0)
 
 
+def cli_hostile_goldens(n_cases=100, seed=999):
+    """Command lines a careless or hostile user types, through the real reference: non-numeric and negative values,
+    repeated and contradicting flags, unknown options in every position, prefixes that fall through to the catch-alls
+    (-b, -r, -n), headers with signs, fractions and garbage, angle lines with too few / non-numeric fields.  Cases on
+    which the reference itself crashes (a value flag as the last argument: SIGSEGV) or hangs are not fixtures."""
+    rng = np.random.default_rng(seed)
+    values = ["abc", "-1", "0", "1e3", "nan", "inf", "3.3.3", "", "  2", "0x10", "1,5", "-0.0", "1e-320", "9" * 30]
+    flags = ["-LAI", "-favd", "-h1", "-h2", "-b", "-r", "-lambda", "-HB", "-BR", "-PCC", "-beta", "-diffuse", "-alb_leaf",
+             "-alb_soil", "-N", "-cab", "-car", "-cw", "-cm", "-canth", "-cbrown", "-rsl1", "-rsl4", "-bogus", "-Bx", "-Rz",
+             "-nx", "-lam", "-Lambda", "-hb", "-pcc", "-PCCx", "-LAIx", "-Wx", "-prn", "-prnsp", "-energyzz", "-q08_pn", "-lidar",
+             "-soil", "-U", "--", "-", "-P"]
+    headers = ["1 2 650 865", "1 2 650 865 999", "1 2 650", "+1 +2 650 865", "1.9 2.9 650 865", "1 2 65e1 865.", "01 02 0650 0865",
+               "1 2 abc 865", "1 2 2500.0001 865", "x 2 650 865", "1 x 650 865", "1 -1", "", " ", "1 2 650 865 # comment"]
+    lines = ["10 0 30 20", "10 0 30", "10 0 30 x", "1e1 0e0 3e1 2e1", "10,0,30,20", "  10\t0  30   20  ", "+10 -0 +30 +20",
+             "10 0 30 20 extra", "nan 0 30 20", "inf 0 30 20", "10 0 1e400 20", "0x10 0 30 20", "10. .0 30. 20."]
+    out, tried = [], 0
+    while len(out) < n_cases and tried < 6 * n_cases:
+        tried += 1
+        args = []
+        for _ in range(int(rng.integers(1, 5))):
+            f = str(rng.choice(flags))
+            args.append(f)
+            if rng.random() < 0.8:
+                args.append(str(rng.choice(values)) if rng.random() < 0.6 else "%.3f" % rng.uniform(0.1, 5))
+        if rng.random() < 0.5:
+            args = ["-LAI", "4.0"] + args
+        if args and args[-1] in flags and rng.random() < 0.9:
+            args.append("1.5")                                     # keep most cases away from the trailing-flag SIGSEGV
+        stdin = str(rng.choice(headers)) + "\n" + "".join(str(rng.choice(lines)) + "\n" for _ in range(int(rng.integers(0, 4))))
+        try:
+            rc, so, se = run(GORTT, args, stdin, timeout=20)
+        except subprocess.TimeoutExpired:
+            continue
+        if rc not in (0, 1) or len(so) > 20000:
+            continue
+        out.append({"name": "hostile%03d" % len(out), "args": args, "stdin": stdin, "rc": rc, "stdout": so,
+                    "stderr": se.replace(GORTT, "gortt")})
+    print("cli hostile: %d cases kept of %d tried; %d with rc 1" % (len(out), tried, sum(c["rc"] for c in out)))
+    json.dump(out, open(os.path.join(GOLD, "cli_hostile_cases.json"), "w"), indent=0)
+
+
 def cli_bulk_golden(n=4000, seed=4040):
     """One LONG stream through the real reference (4000 random lines x 3 bands, -prnspec -prnprop): what the drop-in's
     chunked, multi-threaded text path has to reproduce row for row.  Kept gzipped (stdin + stdout)."""
@@ -565,6 +606,7 @@ def main():
     if "fuzz" in what: fuzz_goldens()
     if "clifuzz" in what: cli_fuzz_goldens()
     if "clibulk" in what: cli_bulk_golden()
+    if "clihostile" in what: cli_hostile_goldens()
     if "wide" in what: wide_stream_golden()
     if "lutnodes" in what: lut_nodes_golden()
 
