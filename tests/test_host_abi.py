@@ -330,7 +330,7 @@ def test_degenerate_crown_geometry_is_refused_where_the_gap_probabilities_would_
     assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(lai=4.0))) == 0
     assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3))) == 0
     for kw in (dict(r=0.0), dict(r=-1.0), dict(b=0.0), dict(b=-2.0), dict(h1=5.0, h2=5.0), dict(h1=9.0, h2=5.0),
-               dict(r=float("nan")), dict(r=float("inf")), dict(h2=float("inf")), dict(r=1e300), dict(newstyle=(0.0, 2.0, 0.6)),
+               dict(r=float("nan")), dict(r=float("inf")), dict(h2=float("inf")), dict(newstyle=(0.0, 2.0, 0.6)),
                dict(newstyle=(2.0, 0.0, 0.6)), dict(newstyle=(2.0, -1.0, 0.6))):
         c = api.make_canopy(lai=4.0, **kw)                                # init accepts it ...
         assert L.gort_canopy_check_geometry(C.byref(c)) == api.EINVAL, kw  # ... the check does not
