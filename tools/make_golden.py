@@ -162,6 +162,26 @@ def cli_cases():
     rc2, so2, _ = run(GORTT_FP, ["-LAI", "4.0", "-P", lut_path, "-prnprop"], pp)
     out.append({"name": "lut_roundtrip", "args": ["-LAI", "4.0", "-P", "@LUT@", "-prnprop"], "stdin": pp,
                 "rc": rc, "stdout": so, "stdout_fp": so2, "stderr": se, "lut_text": lut})
+    # round 2: damaged -P files (fscanf("%d %lf %lf") takes what it can: gortt.c:131-146)
+    rows = lut.strip().split("\n")
+    damaged = {
+        "lut_truncated": "\n".join(rows[:45]) + "\n",
+        "lut_garbage_line": "\n".join(rows[:30] + ["garbage here"] + rows[30:]) + "\n",
+        "lut_empty": "",
+        "lut_without_kopen": "\n".join(r for r in rows if not r.startswith("-1")) + "\n",
+        "lut_two_kopen_lines": lut + "-1 0.5 0.25\n",
+        "lut_rows_reversed": "\n".join(reversed(rows)) + "\n",
+        "lut_crlf": lut.replace("\n", "\r\n"),
+    }
+    pp2 = "2 2 650 865\n10 0 30 20\n60 0 50 180\n"
+    for name, text in damaged.items():
+        open(lut_path, "w").write(text)
+        rc, so, se = run(GORTT, ["-LAI", "4.0", "-P", lut_path, "-prnprop"], pp2)
+        rc2, so2, _ = run(GORTT_FP, ["-LAI", "4.0", "-P", lut_path, "-prnprop"], pp2)
+        assert rc in (0, 1)
+        out.append({"name": name, "args": ["-LAI", "4.0", "-P", "@LUT@", "-prnprop"], "stdin": pp2,
+                    "rc": rc, "stdout": so, "stdout_fp": so2, "stderr": se.replace(GORTT, "gortt"), "lut_text": text})
+        print("cli", name, "rc", rc, "| out", len(so))
     json.dump(out, open(os.path.join(GOLD, "cli_cases.json"), "w"), indent=1)
 
 
