@@ -342,3 +342,21 @@ def test_degenerate_crown_geometry_is_refused_where_the_gap_probabilities_would_
     # lambda and favd may be anything: the reference carries NaN through
     assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(lai=float("inf")))) == 0
     assert L.gort_canopy_check_geometry(C.byref(api.make_canopy(lai=4.0, lam=-1.0))) == 0
+
+
+def test_prospect_d_random_parameter_vectors(golden):
+    """96 random PROSPECT-D parameter vectors through the reference's own Fortran (tests/golden/prospect_fuzz.npz: the
+    usual ranges, N = 1, no absorbers, absorbers strong enough for every branch of the exponential-integral fit, negative
+    contents): the host implementation reproduces R and T on every 7th band, NaN pattern included."""
+    g = golden("prospect_fuzz.npz")
+    worst, nan_rows = 0.0, 0
+    for params, want in zip(g["params"], g["RT"]):
+        RT = api.prospect_d(*params)
+        got = np.stack([RT[:2101][g["bands"]], RT[2101:][g["bands"]]])
+        assert np.array_equal(np.isnan(got), np.isnan(want)), params
+        nan_rows += int(np.isnan(want).any())
+        m = np.isfinite(want)
+        if m.any():
+            worst = max(worst, float(np.max(np.abs(got[m] - want[m]) / np.maximum(np.abs(want[m]), 1e-12))))
+    assert worst <= 1e-12, worst
+    assert nan_rows >= 5                                     # the fixture does reach the NaN-producing corners

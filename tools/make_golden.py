@@ -507,6 +507,38 @@ def cli_fuzz_goldens(n_cases=160, seed=777):
     json.dump(out, open(os.path.join(GOLD, "cli_fuzz_cases.json"), "w"), indent=0)
 
 
+def prospect_fuzz_golden(n=96, seed=5150):
+    """PROSPECT-D through the reference's own Fortran for random parameter vectors: the usual ranges, the edges (N = 1:
+    one layer, the Stokes system degenerates; no absorbers at all: tau = 1; absorbers so strong that k > 85: tau = 0,
+    and k in (4, 85]: the second Chebyshev fit), and values an ensemble filter may wander into (negative contents).
+    Every 7th band of R and T is kept (301 + 301 values per vector)."""
+    L = shim()
+    rng = np.random.default_rng(seed)
+    ps = []
+    for i in range(n):
+        kind = i % 8
+        N, cab, car, anth, cbrown, cw, cm = (rng.uniform(1.0, 3.5), rng.uniform(0, 100), rng.uniform(0, 30), rng.uniform(0, 10),
+                                             rng.uniform(0, 1.5), rng.uniform(0.0002, 0.05), rng.uniform(0.0005, 0.03))
+        if kind == 1: N = 1.0
+        if kind == 2: cab = car = anth = cbrown = 0.0
+        if kind == 3: cw, cm = rng.uniform(0.5, 5.0), rng.uniform(0.1, 2.0)          # k beyond 4, up to beyond 85
+        if kind == 4: cab, cbrown = rng.uniform(500, 5000), rng.uniform(5, 50)
+        if kind == 5: cw = cm = 0.0
+        if kind == 6: N = rng.uniform(1.0, 1.05)
+        if kind == 7: cab, cw = -rng.uniform(0, 5), -rng.uniform(0, 0.001)               # k may go negative: tau = 1 branch
+        ps.append((N, cab, car, anth, cbrown, cw, cm))
+    ps = np.array(ps)
+    keep = np.arange(0, 2101, 7)
+    RT = np.zeros((n, 2, keep.size))
+    for i, p_ in enumerate(ps):
+        out = np.zeros(4202)
+        L.refshim_prospect_raw(*[D(x) for x in p_], p(out))
+        RT[i, 0], RT[i, 1] = out[:2101][keep], out[2101:][keep]
+    np.savez_compressed(os.path.join(GOLD, "prospect_fuzz.npz"), params=ps, bands=keep, RT=RT)
+    print("prospect fuzz: %d vectors, NaN in %d of them, R range %.3g..%.3g" %
+          (n, int(np.isnan(RT).any(axis=(1, 2)).sum()), np.nanmin(RT[:, 0]), np.nanmax(RT[:, 0])))
+
+
 def cli_hostile_goldens(n_cases=100, seed=999):
     """Command lines a careless or hostile user types, through the real reference: non-numeric and negative values,
     repeated and contradicting flags, unknown options in every position, prefixes that fall through to the catch-alls
@@ -627,6 +659,7 @@ def main():
     if "clifuzz" in what: cli_fuzz_goldens()
     if "clibulk" in what: cli_bulk_golden()
     if "clihostile" in what: cli_hostile_goldens()
+    if "prospect" in what: prospect_fuzz_golden()
     if "wide" in what: wide_stream_golden()
     if "lutnodes" in what: lut_nodes_golden()
 
