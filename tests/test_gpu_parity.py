@@ -479,6 +479,25 @@ def test_cli_random_command_lines_identical_to_reference():
     assert ulp6 <= 20 and identical >= len(cases) - 20
 
 
+def test_ensemble_layer_against_forward_runs_of_the_reference():
+    """gort_amd.ensemble end to end (state vector -> flags as gortt parses them -> gap probabilities, PROSPECT-D and Price
+    spectra on the device -> all members' observation vectors in one fused launch) against 24 forward runs of the real
+    reference at %.17g (tests/golden/ensemble_states.npz); the albedo / absorption of the first six members too."""
+    from gort_amd.ensemble import Ensemble
+    g = np.load(os.path.join(GOLDEN, "ensemble_states.npz"))
+    names = [str(x) for x in g["names"]]
+    states = [dict(zip(names, (float(v) for v in st))) for st in g["states"]]
+    ens = Ensemble(g["wl"]).set_states(states)
+    got = ens.observe(g["angles"])
+    assert got.shape == g["rsurf"].shape
+    e1 = err(got, g["rsurf"])
+    en = ens.albedo(g["angles"][:3], 0, 6)
+    e2 = err(en, g["energy"])
+    ens.close()
+    print("ensemble vs reference forward runs: rsurf %.2e, energy %.2e" % (e1, e2))
+    assert e1 <= REGRESSION and e2 <= REGRESSION
+
+
 def test_device_prospect_d_random_parameter_vectors():
     """The device-side PROSPECT-D (gort_spectra.hip: the spectra of ensemble members are computed on the GPU) on the 96
     random parameter vectors the reference's Fortran was run on (tests/golden/prospect_fuzz.npz): every 7th band of R and

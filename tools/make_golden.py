@@ -539,6 +539,34 @@ def prospect_fuzz_golden(n=96, seed=5150):
           (n, int(np.isnan(RT).any(axis=(1, 2)).sum()), np.nanmin(RT[:, 0]), np.nanmax(RT[:, 0])))
 
 
+def ensemble_states_golden(n=24, seed=6060):
+    """The ensemble layer end to end against forward runs of the real reference: 24 random state vectors (HB, BR, PCC,
+    LAI, N, Cab, Car, Cw, Cm, rsl1 - gort_amd/ensemble.py STATE), each one run of gortt_fp with that member's flags on
+    the same 12 angle lines x 7 MODIS land bands (+ -energy for the first 6 members, 3 lines)."""
+    rng = np.random.default_rng(seed)
+    wl = np.array([450.0, 555.0, 645.0, 858.5, 1240.0, 1640.0, 2130.0])
+    ang = np.round(np.stack([rng.uniform(-70, 70, 12), rng.uniform(0, 360, 12), rng.uniform(0, 75, 12), rng.uniform(0, 360, 12)], 1), 4)
+    names = ("HB", "BR", "PCC", "LAI", "N", "Cab", "Car", "Cw", "Cm", "rsl1")
+    states, rows, energy = [], [], []
+    for i in range(n):
+        st = [float(np.float32(rng.uniform(1, 3))), float(np.float32(rng.uniform(1, 3.5))), float(np.float32(rng.uniform(0.2, 0.8))),
+              float(np.float32(rng.uniform(0.5, 6))), rng.uniform(1, 2.5), rng.uniform(10, 60), rng.uniform(2, 15),
+              rng.uniform(0.005, 0.03), rng.uniform(0.002, 0.015), rng.uniform(0.05, 0.4)]
+        flags = ["-HB", repr(st[0]), "-BR", repr(st[1]), "-PCC", repr(st[2]), "-LAI", repr(st[3]), "-N", repr(st[4]),
+                 "-cab", repr(st[5]), "-car", repr(st[6]), "-cw", repr(st[7]), "-cm", repr(st[8]), "-rsl1", repr(st[9])]
+        rc, so, se = run(GORTT_FP, flags, stream_text(ang, wl))
+        assert rc == 0, se
+        rows.append([[float(t) for t in ln.split()[4:]] for ln in so.strip().split("\n")[1:]])
+        if i < 6:
+            rc, so, se = run(GORTT_FP, flags + ["-energy"], stream_text(ang[:3], wl))
+            assert rc == 0, se
+            energy.append([[float(t) for t in ln.split()[4 + len(wl):]] for ln in so.strip().split("\n")[1:]])
+        states.append(st)
+    np.savez_compressed(os.path.join(GOLD, "ensemble_states.npz"), names=np.array(names), states=np.array(states), wl=wl,
+                        angles=ang, rsurf=np.array(rows), energy=np.array(energy).reshape(6, 3, len(wl), 3))
+    print("ensemble states: %d members x %d lines x %d bands from the reference" % (n, len(ang), len(wl)))
+
+
 def cli_hostile_goldens(n_cases=100, seed=999):
     """Command lines a careless or hostile user types, through the real reference: non-numeric and negative values,
     repeated and contradicting flags, unknown options in every position, prefixes that fall through to the catch-alls
@@ -660,6 +688,7 @@ def main():
     if "clibulk" in what: cli_bulk_golden()
     if "clihostile" in what: cli_hostile_goldens()
     if "prospect" in what: prospect_fuzz_golden()
+    if "ensemble" in what: ensemble_states_golden()
     if "wide" in what: wide_stream_golden()
     if "lutnodes" in what: lut_nodes_golden()
 
