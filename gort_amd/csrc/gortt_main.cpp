@@ -474,8 +474,11 @@ int main(int argc, char **argv)
     std::vector<int> devices = o.devices;
     if (devices.empty()) devices.push_back(-1);                 // -1: whatever device is current
     for (int d : devices)
-        if (d >= gort_device_count())
-            die("%s: device %d asked for (--gpus / GORTT_DEVICES), this machine has %d\n", argv[0], d, gort_device_count());
+        if (d >= gort_device_count()) {
+            std::fflush(stdout);
+            std::fprintf(stderr, "%s: device %d asked for (--gpus / GORTT_DEVICES), this machine has %d\n", argv[0], d, gort_device_count());
+            return EXIT_FAILURE;
+        }
     const size_t per_line_out = (size_t)nw * (1 + (o.prnspec ? 4 : 0) + (o.energy ? 3 : 0)) + 8;
     size_t chunk_mb = 48;                                        // GORTT_CHUNK_MB: output bytes per chunk
     if (const char *v = std::getenv("GORTT_CHUNK_MB")) { const long m = atol(v); if (m >= 1 && m <= 4096) chunk_mb = (size_t)m; }
