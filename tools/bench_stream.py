@@ -49,4 +49,15 @@ for name, sza in cases.items():
         e, w = float(np.median(ex)), float(np.median(wall))
         print("%-16s grouping=%d form=%-8s expansion %7.1f us (%5.0f GB/s, %.3f of 8 TB/s) | call %7.1f us  %.3e samples/s (%.3f)"
               % (name, grouping, form, e * 1e6, byts / e / 1e9, byts / e / 8e12, w * 1e6, n * wl.size / w, byts / w / 8e12), flush=True)
+        if os.environ.get("BENCH_STREAM_JSON"):              # the same in the shape of bench.py's line, one object per case and form
+            import json
+            with open(os.environ["BENCH_STREAM_JSON"], "a") as f:
+                f.write(json.dumps({
+                    "metric": "BRDF samples/sec, arbitrary-angle stream", "value": n * wl.size / w, "unit": "samples/s", "n_gpus": 1,
+                    "dtype": "f64", "data": "synthetic", "config": {"workload": "%d random lines x %d bands, sun zeniths: %s" % (n, wl.size, name),
+                                                                    "form": form},
+                    "ms_per_call": w * 1e3,
+                    "roofline": {"bound": "hbm", "kernel": "expansion stage (HIP events on the engine's stream)", "achieved": byts / e / 1e9,
+                                 "peak": 8000.0, "unit": "GB/s", "frac": byts / e / 8e12, "kernel_ms": e * 1e3,
+                                 "algorithmic_bytes_per_launch": byts, "traffic": None}}) + "\n")
 eng.set_stream_grouping(0)
