@@ -17,7 +17,7 @@ prof() { # name, then rocprofv3 args..., then -- program
 }
 # ---- A
 cd "$R" && timeout -k 10 400 python3 bench.py > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"; echo "bench rc=$?"
-prof bench_stats --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-parity --sustain-s 0
+prof bench_stats --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$R/bench.py" --steps 20 --warmup 3 --slab-candidates 1 --no-cpu-baseline --no-parity --sustain-s 0
 prof bench_pmc_write --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_pmc_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0
 prof bench_pmc_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0
 # ---- B
