@@ -303,6 +303,19 @@ bool parse_angles(const char *s, double v[4])
         char *end;
         v[q] = std::strtod(s, &end);
         if (end == s) return false;
+        // glibc's scanf("%lf") swallows an exponent marker that no digits follow ("1e", "10e+", "0x1p": the number is
+        // read without it, and the next field starts BEHIND the marker and its sign), strtod hands it back
+        const char *p = s;
+        while (std::isspace((unsigned char)*p)) ++p;
+        if (*p == '+' || *p == '-') ++p;
+        const bool hex = p[0] == '0' && (p[1] == 'x' || p[1] == 'X');
+        if (std::isdigit((unsigned char)*p) || *p == '.') {
+            if (hex ? (*end == 'p' || *end == 'P') : (*end == 'e' || *end == 'E')) {
+                const char *t = end + 1;
+                if (*t == '+' || *t == '-') ++t;
+                if (!std::isdigit((unsigned char)*t)) end = const_cast<char *>(t);
+            }
+        }
         s = end;
     }
     return true;

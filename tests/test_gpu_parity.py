@@ -559,6 +559,24 @@ def test_cli_hostile_command_lines_like_the_reference():
     assert not diffs, "%d of %d cases differ" % (len(diffs), len(cases))
 
 
+def test_cli_reads_numbers_like_the_reference():
+    """140 single-line inputs with one oddly spelled number each, in an angle line or in the header (signs, hex floats,
+    inf / nan / nan(chars), exponents without digits, junk glued to a number, overflow and underflow, non-ASCII digits):
+    same exit code, same stderr, same stdout as the reference (tools/make_golden.py clinumfmt) up to the sign of a NaN."""
+    cases = json.load(open(os.path.join(GOLDEN, "cli_number_format_cases.json"), encoding="utf-8"))
+    assert len(cases) >= 120
+    diffs = []
+    for case in cases:
+        run = subprocess.run([api.GORTT_BIN] + case["args"], input=case["stdin"].encode("utf-8"), capture_output=True, timeout=120)
+        out, errtxt = run.stdout.decode("latin-1"), run.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt")   # as the generator does
+        same_out = out == case["stdout"] or out.replace("-nan", "nan") == case["stdout"].replace("-nan", "nan")
+        if (run.returncode, errtxt) != (case["rc"], case["stderr"]) or not same_out:
+            diffs.append((case["name"], case["stdin"], (case["rc"], case["stdout"][:160], case["stderr"][:160]), (run.returncode, out[:160], errtxt[:160])))
+    for d in diffs:
+        print(json.dumps(d, ensure_ascii=False))
+    assert not diffs, "%d of %d cases differ" % (len(diffs), len(cases))
+
+
 def test_cli_long_stream_identical_to_reference():
     """4000 random lines x 3 bands with -prnspec -prnprop from the real reference (tests/golden/cli_bulk.json.gz) through
     the drop-in in SMALL chunks (many chunks in flight, several formatting threads) and in one chunk: the same bytes

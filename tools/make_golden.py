@@ -608,6 +608,37 @@ def cli_hostile_goldens(n_cases=100, seed=999):
     json.dump(out, open(os.path.join(GOLD, "cli_hostile_cases.json"), "w"), indent=0)
 
 
+def cli_number_formats_golden(seed=1212):
+    """How the reference READS numbers (sscanf "%lf" for angle fields, atoi / atof for the header, gortt.c:153-237): 140
+    single-line inputs with every spelling C's number parsers know - signs, hex floats, inf / nan / nan(chars), exponents
+    without digits, leading zeros, tabs, trailing junk glued to a number, numbers too large or too small for a double."""
+    rng = np.random.default_rng(seed)
+    toks = ["10", "+10", "-10", "010", "1e1", "1E1", "1e+1", "1.e1", ".1e2", "10.", "0x1p3", "0xA", "0XA.8", "1e", "1e+", "1.5e400",
+            "-1e400", "1e-400", "4.9e-324", "inf", "-inf", "INF", "infinity", "nan", "-nan", "NAN", "nan(abc)", "nan(", "10abc", "10e", "10x",
+            "1_0", "1'0", "١٠", "10\t", "\t10", "1 0", "--10", "+-10", "1.2.3", "0.0.0", "0", "-0", "+0", "00", ".", "-", "+", "e5", ".e5",
+            "1d1", "1f", "1L", "0b11", "1e1e1", "0x", "0x.p1", "0x1p", "1,0"]
+    out = []
+    for i in range(140):
+        if i % 2 == 0:                                              # one odd token in an angle line
+            f = ["10", "0", "30", "20"]
+            f[int(rng.integers(0, 4))] = str(rng.choice(toks))
+            stdin = "1 2 650 865\n" + " ".join(f) + "\n"
+        else:                                                       # one odd token in the header
+            h = ["1", "2", "650", "865"]
+            h[int(rng.integers(0, 4))] = str(rng.choice(toks))
+            stdin = " ".join(h) + "\n10 0 30 20\n"
+        try:
+            rc, so, se = run(GORTT, ["-LAI", "4.0"], stdin, timeout=20)
+        except subprocess.TimeoutExpired:
+            continue
+        if rc not in (0, 1) or len(so) > 20000:
+            continue
+        out.append({"name": "numfmt%03d" % len(out), "args": ["-LAI", "4.0"], "stdin": stdin, "rc": rc, "stdout": so,
+                    "stderr": se.replace(GORTT, "gortt")})
+    print("cli number formats: %d cases, %d with rc 1" % (len(out), sum(c["rc"] for c in out)))
+    json.dump(out, open(os.path.join(GOLD, "cli_number_format_cases.json"), "w"), indent=0, ensure_ascii=False)
+
+
 def cli_bulk_golden(n=4000, seed=4040):
     """One LONG stream through the real reference (4000 random lines x 3 bands, -prnspec -prnprop): what the drop-in's
     chunked, multi-threaded text path has to reproduce row for row.  Kept gzipped (stdin + stdout)."""
@@ -687,6 +718,7 @@ def main():
     if "clifuzz" in what: cli_fuzz_goldens()
     if "clibulk" in what: cli_bulk_golden()
     if "clihostile" in what: cli_hostile_goldens()
+    if "clinumfmt" in what: cli_number_formats_golden()
     if "prospect" in what: prospect_fuzz_golden()
     if "ensemble" in what: ensemble_states_golden()
     if "wide" in what: wide_stream_golden()
