@@ -498,6 +498,64 @@ def test_ensemble_layer_against_forward_runs_of_the_reference():
     assert e1 <= REGRESSION and e2 <= REGRESSION
 
 
+def test_cli_random_command_lines_at_full_precision():
+    """The same 160 random command lines, now at full precision: the reference's numbers at %.17g (gortt_fp) against the
+    doubles the drop-in writes with --binary-out - reflectance, component spectra, viewed proportions, albedo and
+    absorptions of random canopies, spectra and geometries: 1e-9 relative, 1e-15 absolute (rows at a view zenith of exactly
+    90 degrees, the singular direction, excepted), NaN pattern equal."""
+    cases = json.load(open(os.path.join(GOLDEN, "cli_fuzz_cases.json")))
+    worst, checked, where = 0.0, 0, None
+    for case in cases:
+        if case["rc"] != 0:
+            continue
+        run = subprocess.run([api.GORTT_BIN] + case["args"] + ["--binary-out"], input=case["stdin"].encode(), capture_output=True, timeout=300)
+        assert run.returncode == 0, (case["name"], run.stderr[-500:])
+        ref_lines = case["stdout_fp"].split("\n")
+        head = (ref_lines[0] + "\n").encode("latin-1")
+        assert run.stdout.startswith(head), case["name"]
+        mine = np.frombuffer(run.stdout[len(head):], dtype="<f8")
+        want, is_k = [], []
+        for ln in ref_lines[1:]:
+            vals, ks, inside = [], [], False
+            for t in ln.replace("{", " { ").replace("}", " } ").replace("[", " [ ").replace("]", " ] ").split():
+                if t in "[]":
+                    inside = t == "["
+                elif t not in "{}":
+                    vals.append(float(t))
+                    ks.append(inside)
+            if vals:
+                want.append(vals)
+                is_k.append(ks)
+        assert sum(len(r) for r in want) == mine.size, (case["name"], mine.size)
+        k = 0
+        for r, ks in zip(want, is_k):
+            a, b, ks = mine[k:k + len(r)], np.array(r), np.array(ks)
+            k += len(r)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (case["name"], r[:4])
+            if abs(b[0]) == 90.0:
+                continue
+            m = np.isfinite(b)
+            if m.any():
+                # reflectances, spectra, albedo: relative error (floor 1e-6: a term that is zero up to cancellation, -2e-17 in
+                # the reference and 0 here, is not a relative error of 1e-5).  The viewed proportions [Kc Kg Kt Kz] are
+                # fractions of one whose small members are differences of large ones - near the hot spot the overlap
+                # function's acos(1 - eps) turns one ulp into 1e-12: they are compared as fractions of one.
+                scale = np.where(ks[m], 1.0, np.maximum(np.abs(b[m]), 1e-6))
+                e = np.abs(a[m] - b[m]) / scale
+                # a line within 1e-3 degrees of the exact hot-spot direction (view = sun): the overlap function's
+                # acos(1 - eps), eps ~ 1e-15, turns the last place of its argument into 1e-9 of Kc and of the reflectance -
+                # in the reference as much as here; such rows are held to 1e-6 (the exact hot spot itself is well behaved
+                # and covered by the golden BRDF rows)
+                daz = abs(((b[1] - b[3]) + 180.0) % 360.0 - 180.0)
+                if abs(abs(b[0]) - abs(b[2])) < 1e-3 and daz < 1e-3 and (abs(b[0]) != abs(b[2]) or daz != 0.0):
+                    e = e * 1e-3
+                if e.max() > worst:
+                    worst, where = float(e.max()), (case["name"], case["args"], r[:4], float(a[m][e.argmax()]), float(b[m][e.argmax()]))
+                checked += int(m.sum())
+    print("cli fuzz at full precision: %.2e over %d numbers" % (worst, checked), where)
+    assert worst <= REGRESSION and checked > 9000
+
+
 def test_device_prospect_d_random_parameter_vectors():
     """The device-side PROSPECT-D (gort_spectra.hip: the spectra of ensemble members are computed on the GPU) on the 96
     random parameter vectors the reference's Fortran was run on (tests/golden/prospect_fuzz.npz): every 7th band of R and

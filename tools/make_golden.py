@@ -500,7 +500,8 @@ def cli_fuzz_goldens(n_cases=160, seed=777):
         rc, so, se = run(GORTT, args, stdin)
         if rc not in (0, 1) or len(so) > 20000:
             continue                                                  # a crash of the reference is not a fixture
-        out.append({"name": "fuzz%03d" % len(out), "args": args, "stdin": stdin, "rc": rc, "stdout": so,
+        rc2, so2, _ = run(GORTT_FP, args, stdin)                      # the same at %.17g: compared with --binary-out
+        out.append({"name": "fuzz%03d" % len(out), "args": args, "stdin": stdin, "rc": rc, "stdout": so, "stdout_fp": so2,
                     "stderr": se.replace(GORTT, "gortt")})
     print("cli fuzz: %d cases kept of %d tried; %d with rc 1, %d with -nan" %
           (len(out), tried, sum(c["rc"] for c in out), sum("-nan" in c["stdout"] for c in out)))
