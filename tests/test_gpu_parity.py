@@ -437,6 +437,18 @@ def test_cli_text_identical_to_reference(case, tmp_path):
     assert errtxt == case["stderr"]
 
 
+def _run_cases(cases, extra_args=(), encoding="latin-1", timeout=300):
+    """The drop-in executable on every case, four processes at a time (each start-up costs ~0.3 s of HIP initialisation;
+    the box allows six GPU processes, this one included), results in case order."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(case):
+        return subprocess.run([api.GORTT_BIN] + list(case["args"]) + list(extra_args), input=case["stdin"].encode(encoding),
+                              capture_output=True, timeout=timeout)
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        return list(pool.map(one, cases))
+
+
 def test_cli_random_command_lines_identical_to_reference():
     """160 random command lines and inputs (tools/make_golden.py clifuzz: flag combinations in mixed case, old / new style
     crown geometry, spectral overrides, output flags, odd wavelengths, negative zeniths, wild azimuths, horizon and
@@ -446,8 +458,7 @@ def test_cli_random_command_lines_identical_to_reference():
     cases = json.load(open(os.path.join(GOLDEN, "cli_fuzz_cases.json")))
     assert len(cases) >= 150
     identical, ulp6, numbers = 0, 0, 0
-    for case in cases:
-        run = subprocess.run([api.GORTT_BIN] + case["args"], input=case["stdin"].encode(), capture_output=True, timeout=300)
+    for case, run in zip(cases, _run_cases(cases, encoding="utf-8")):
         out, errtxt = run.stdout.decode("latin-1"), run.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt")
         assert run.returncode == case["rc"], (case["name"], case["args"], errtxt)
         assert errtxt == case["stderr"], (case["name"], case["args"])
@@ -505,10 +516,8 @@ def test_cli_random_command_lines_at_full_precision():
     90 degrees, the singular direction, excepted), NaN pattern equal."""
     cases = json.load(open(os.path.join(GOLDEN, "cli_fuzz_cases.json")))
     worst, checked, where = 0.0, 0, None
-    for case in cases:
-        if case["rc"] != 0:
-            continue
-        run = subprocess.run([api.GORTT_BIN] + case["args"] + ["--binary-out"], input=case["stdin"].encode(), capture_output=True, timeout=300)
+    cases = [c for c in cases if c["rc"] == 0]
+    for case, run in zip(cases, _run_cases(cases, ["--binary-out"], encoding="utf-8")):
         assert run.returncode == 0, (case["name"], run.stderr[-500:])
         ref_lines = case["stdout_fp"].split("\n")
         head = (ref_lines[0] + "\n").encode("latin-1")
@@ -595,8 +604,7 @@ def test_cli_hostile_command_lines_like_the_reference():
     cases = json.load(open(os.path.join(GOLDEN, "cli_hostile_cases.json")))
     assert len(cases) >= 90
     diffs = []
-    for case in cases:
-        run = subprocess.run([api.GORTT_BIN] + case["args"], input=case["stdin"].encode(), capture_output=True, timeout=120)
+    for case, run in zip(cases, _run_cases(cases, encoding="utf-8", timeout=120)):
         out, errtxt = run.stdout.decode("latin-1"), run.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt")
         # deviation: degenerate crown geometry - the reference fails in an allocation or reports negative
         # volumes (or loops for ever: such cases are not in the fixture); the drop-in refuses the geometry up front
@@ -624,8 +632,7 @@ def test_cli_reads_numbers_like_the_reference():
     cases = json.load(open(os.path.join(GOLDEN, "cli_number_format_cases.json"), encoding="utf-8"))
     assert len(cases) >= 120
     diffs = []
-    for case in cases:
-        run = subprocess.run([api.GORTT_BIN] + case["args"], input=case["stdin"].encode("utf-8"), capture_output=True, timeout=120)
+    for case, run in zip(cases, _run_cases(cases, encoding="utf-8", timeout=120)):
         out, errtxt = run.stdout.decode("latin-1"), run.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt")   # as the generator does
         same_out = out == case["stdout"] or out.replace("-nan", "nan") == case["stdout"].replace("-nan", "nan")
         if (run.returncode, errtxt) != (case["rc"], case["stderr"]) or not same_out:
