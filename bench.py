@@ -307,6 +307,7 @@ def main():
                 raise
             print("bench.py: --rehearse --gather does not fit one GPU at this size; gather skipped", file=sys.stderr)
             allgather_ms = None
+            barrier()                                       # the ranks that got through are waiting in theirs
 
     # ---- parity spot check (outside the timed region): sampled rows vs the CPU oracle ----
     parity = None
