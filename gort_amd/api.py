@@ -77,12 +77,17 @@ DECLARED_SYMBOLS = [
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
     "gort_rsurf_members_grid_dev", "gort_rsurf_members_stream", "gort_rsurf_members_stream_dev",
-    "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_last_expand_ms",
-    "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs", "gort_selftest_index_math",
+    "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
-    "gort_engine_stream_form", "gort_engine_set_stream_grouping", "gort_engine_last_stream_ms",
     "gort_host_malloc", "gort_host_free", "gort_set_device", "gort_get_device",
     "gort_pipe_create", "gort_pipe_acquire", "gort_pipe_submit", "gort_pipe_wait", "gort_pipe_release", "gort_pipe_destroy",
+]
+
+#: include/gort_amd_tuning.h: measurement and tuning hooks, not part of the drop-in boundary
+TUNING_SYMBOLS = [
+    "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_set_stream_form", "gort_engine_stream_form",
+    "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
+    "gort_selftest_index_math",
 ]
 
 _lib = None
@@ -127,7 +132,7 @@ def lib():
         L.gort_pipe_destroy.argtypes = [C.c_void_p]
         L.gort_pipe_destroy.restype = None
         L.gort_engine_stream_form.argtypes = [C.c_void_p]
-        L.gort_engine_set_stream_grouping.argtypes = [C.c_void_p, C.c_int]
+        L.gort_engine_set_stream_form.argtypes = [C.c_void_p, C.c_int]
         L.gort_engine_last_stream_ms.argtypes = [C.c_void_p]
         L.gort_engine_last_stream_ms.restype = D
         L.gort_engine_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -481,15 +486,16 @@ class Engine:
                                            _ptr(scomp_t), _ptr(K_t)))
 
     def stream_form(self):
-        """'narrow' | 'grouped' | 'per-line': which kernels expanded the last stream call (synchronises)."""
+        """'narrow' | 'flat' | 'lds': which kernel expanded the last stream call (include/gort_amd_tuning.h)."""
         m = lib().gort_engine_stream_form(self.h)
         if m < 0:
             _check(m)
-        return {0: "narrow", 1: "grouped", 2: "per-line"}[m]
+        return {0: "narrow", 1: "flat", 2: "lds"}[m]
 
-    def set_stream_grouping(self, on):
-        """False/0 never, True/1 automatic (size threshold), 2 whenever the stream allows it."""
-        _check(lib().gort_engine_set_stream_grouping(self.h, int(on)))
+    def set_stream_form(self, form):
+        """Wide streams: 0 / 'auto', 1 / 'flat' (panels of long waves), 2 / 'lds' (LDS-resident band table)."""
+        form = {"auto": 0, "flat": 1, "lds": 2}.get(form, form)
+        _check(lib().gort_engine_set_stream_form(self.h, int(form)))
 
     def last_stream_ms(self):
         return lib().gort_engine_last_stream_ms(self.h)

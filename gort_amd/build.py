@@ -23,8 +23,12 @@ ARCH = "gfx950"
 # (-ffp-contract=off): they feed integer truncations / are compared to the last bits.
 UNITS = [
     ("gort_gap.hip", ["-ffp-contract=off"]),
-    ("gort_brdf.hip", []),
-    ("gort_stream.hip", []),
+    ("gort_geometry.hip", []),
+    ("gort_tables.hip", []),
+    ("gort_lut_expand.hip", []),
+    ("gort_stream_expand.hip", []),
+    ("gort_energy.hip", []),
+    ("gort_xcd.hip", []),
     ("gort_pipe.hip", []),
     ("gort_spectra.hip", []),
     ("gort_api.hip", []),
@@ -55,8 +59,9 @@ def build(force=False, verbose_resources=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(ROOT, "include", "gort_amd.h"), os.path.join(SRC, "gort_internal.h"),
-               os.path.join(SRC, "gort_device.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(ROOT, "include", "gort_amd.h"), os.path.join(ROOT, "include", "gort_amd_tuning.h"),
+               os.path.join(SRC, "gort_internal.h"), os.path.join(SRC, "gort_device.h"), os.path.join(SRC, "gort_geometry.h"),
+               os.path.join(SRC, "gort_flat.h"), os.path.abspath(__file__)]
     data = [os.path.join(PKG, "data", f) for f in ("prospect_d_coeffs.f32", "price_soil_eofs.f64")]
     common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
               "-I" + SRC, "--offload-arch=" + ARCH]

@@ -69,16 +69,9 @@ struct gort_engine {
     size_t ev_used = 0;
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
-    DevBuf sgroup, ssun;                 // workspace of the grouped stream expansion (gort_stream.hip)
-    int stream_grouping = 0;             // 0 per line (default), 1 group large streams (size threshold, verdict memory), 2 group whenever possible
-    long group_min_lines = 200000;       // GORT_STREAM_GROUP_MIN: automatic mode groups streams of at least this many lines
-    int stream_form = 0;                 // form of the last stream call: 0 narrow, 1 grouped, 2 per line, -1 ask the device
+    int wide_form_pref = 0;              // wide streams: 0 automatic, 1 flat panels, 2 LDS-resident (gort_amd_tuning.h)
+    int stream_form = 0;                 // form of the last stream call: 0 narrow, 1 flat panels, 2 LDS-resident
     hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call
-    hipEvent_t ev_sgeo[2] = {nullptr, nullptr};       // stream call: inputs ready / geometry done (second stream)
-    int *group_verdict = nullptr;        // pinned: flags[0] of the last grouping attempt (-1 = it held)
-    hipEvent_t ev_verdict = nullptr;
-    bool group_verdict_pending = false;
-    int group_skip = 0;                  // calls left before the grouped form is tried again
     char *stage = nullptr;               // pinned staging of the setters' small uploads (stage_begin / stage_h2d)
     size_t stage_cap = 0, stage_off = 0;
     hipEvent_t ev_stage = nullptr;
@@ -313,8 +306,7 @@ extern "C" int gort_engine_create(gort_engine **out)
         return fail(GORT_ENODEVICE, "gort_engine_create: cannot create streams/events");
     }
     if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
-    if (const char *v = getenv("GORT_STREAM_GROUP")) { const int m = atoi(v); e->stream_grouping = m < 0 ? 0 : (m > 2 ? 2 : m); }
-    if (const char *v = getenv("GORT_STREAM_GROUP_MIN")) e->group_min_lines = atol(v);
+    if (const char *v = getenv("GORT_STREAM_FORM")) { const int m = atoi(v); e->wide_form_pref = m < 0 ? 0 : (m > 2 ? 2 : m); }
     if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
     if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
         int w[8];
@@ -340,16 +332,12 @@ extern "C" void gort_engine_destroy(gort_engine *e)
         if (ev) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
-                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots,
-                      &e->sgroup, &e->ssun})
+                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots})
         b->release();
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_stream) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : e->ev_sgeo) if (ev) (void)hipEventDestroy(ev);
-    if (e->ev_verdict) (void)hipEventDestroy(e->ev_verdict);
     if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
     if (e->stage) (void)hipHostFree(e->stage);
-    if (e->group_verdict) (void)hipHostFree(e->group_verdict);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -627,7 +615,7 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if (e && e->have_canopy && !rsurf_dev && !scomp_dev && K_dev) {
         if (nA < 0 || (nA > 0 && !angles_dev)) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
         if (nA == 0) return GORT_OK;
-        return launch_geometry_stream_fused(e->canopy.as<gort_canopy>(), nullptr, 0, angles_dev, nA, nullptr, K_dev, e->stream);
+        return launch_geometry_stream_fused(e->canopy.as<gort_canopy>(), 1, nullptr, 0, angles_dev, nA, nullptr, K_dev, e->stream);
     }
     if ((rc = require_ready(e, "gort_rsurf_stream_dev"))) return rc;
     if (nA < 0 || (nA > 0 && (!angles_dev || !rsurf_dev))) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
@@ -642,66 +630,27 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     int *xcd_slots = nullptr;
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
-    size_t ws_bytes = 0, sun_bytes = 0;
-    const bool wide = expand_stream_workspace(e->nw, nA, scomp_dev != nullptr, &ws_bytes, &sun_bytes);
-    // Since the stream family's regrouped sample (gort_device.h) the per-line kernel is as fast as the grouped form or
-    // faster (1 048 576 lines: 3.35 ms per line, 3.43 grouped; 65 536: 232 against 252 us, it has no grouping pass), so
-    // per line is the default; mode 1 groups streams of at least group_min_lines, mode 2 whenever the stream allows it
-    if (e->stream_grouping == 0 || (e->stream_grouping == 1 && nA < e->group_min_lines)) ws_bytes = 0;
-    // Whether the grouped form applies is decided on the device, call by call; giving a stream up costs ~40 us of
-    // grouping and of launches that return at once.  Streams are mostly of one kind, so the verdict of the last
-    // attempt (copied back asynchronously, looked at only once it has arrived) suspends further attempts for the
-    // next GROUP_RETRY calls.
-    constexpr int GROUP_RETRY = 15;
-    if (wide && ws_bytes) {
-        if (e->group_verdict_pending && hipEventQuery(e->ev_verdict) == hipSuccess) {
-            e->group_verdict_pending = false;
-            e->group_skip = (*e->group_verdict != -1) ? GROUP_RETRY : 0;
-        }
-        if (e->group_skip > 0 && !e->group_verdict_pending) {
-            --e->group_skip;
-            ws_bytes = 0;
-        }
+    const bool wide = stream_is_wide(e->nw, nA, scomp_dev != nullptr);
+    // wide streams: the LDS-resident kernel where the band table fits a CU's LDS (nw <= ~2130), else flat panels
+    int wide_form = 0;
+    if (wide) {
+        wide_form = e->wide_form_pref ? e->wide_form_pref : 2;
+        if (wide_form == 2 && !stream_lds_applies(e->nw, nA)) wide_form = 1;
     }
-    if (ws_bytes && ((rc = e->sgroup.reserve(ws_bytes)) || (rc = e->ssun.reserve(sun_bytes)))) return rc;
     for (int i = 0; i < 2; ++i)
         if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
     if (stream_fuses(e->nw, scomp_dev != nullptr)) {
         GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
-        rc = launch_geometry_stream_fused(c, e->L.as<double>(), e->nw, angles_dev, nA, rsurf_dev, K_dev, e->stream);
+        rc = launch_geometry_stream_fused(c, 1, e->L.as<double>(), e->nw, angles_dev, nA, rsurf_dev, K_dev, e->stream);
         GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
         e->stream_form = 0;
         return rc;
     }
-    // The grouped form first sorts the lines by sun zenith and builds its sun table - work that does not need the
-    // per-line geometry, whose ~35 fp64 transcendentals are a 15 us latency chain whatever the line count: the
-    // geometry kernel runs beside it on the second stream.
-    const bool beside = ws_bytes != 0 && e->pipeline;
-    if (beside) {
-        for (int i = 0; i < 2; ++i)
-            if (!e->ev_sgeo[i]) GORT_HIP(hipEventCreateWithFlags(&e->ev_sgeo[i], hipEventDisableTiming));
-        GORT_HIP(hipEventRecord(e->ev_sgeo[0], e->stream));            // inputs ready, previous readers of coef done
-        GORT_HIP(hipStreamWaitEvent(e->aux, e->ev_sgeo[0], 0));
-        if ((rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, 1, e->aux))) return rc;
-        GORT_HIP(hipEventRecord(e->ev_sgeo[1], e->aux));
-    } else if ((rc = launch_geometry_stream(c, angles_dev, nA, coef, K_dev, wide ? 1 : 0, e->stream))) {
-        return rc;
-    }
+    if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, wide ? 1 : 0, e->stream))) return rc;
     GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
-    rc = launch_expand_stream(c, e->L.as<double>(), e->nw, angles_dev, coef, nA, rsurf_dev, scomp_dev, xcd_slots,
-                              ws_bytes ? e->sgroup.p : nullptr, ws_bytes ? e->ssun.as<double>() : nullptr, e->stream,
-                              beside ? (void *)e->ev_sgeo[1] : nullptr, false);
+    rc = launch_expand_stream(c, e->L.as<double>(), e->nw, coef, nA, rsurf_dev, scomp_dev, xcd_slots, wide_form, e->stream, false);
     GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
-    if (rc == GORT_OK && ws_bytes && !e->group_verdict_pending) {
-        if (!e->group_verdict) {
-            GORT_HIP(hipHostMalloc((void **)&e->group_verdict, sizeof(int), hipHostMallocDefault));
-            GORT_HIP(hipEventCreateWithFlags(&e->ev_verdict, hipEventDisableTiming));
-        }
-        GORT_HIP(hipMemcpyAsync(e->group_verdict, e->sgroup.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        GORT_HIP(hipEventRecord(e->ev_verdict, e->stream));
-        e->group_verdict_pending = true;
-    }
-    e->stream_form = !wide ? 0 : (ws_bytes ? -1 : 2);          // -1: decided on the device, see gort_engine_stream_form
+    e->stream_form = wide_form;
     return rc;
 }
 
@@ -839,23 +788,17 @@ extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, 
     return GORT_OK;
 }
 
-extern "C" int gort_engine_set_stream_grouping(gort_engine *e, int on)
+extern "C" int gort_engine_set_stream_form(gort_engine *e, int form)
 {
-    if (!e) return fail(GORT_EINVAL, "gort_engine_set_stream_grouping: null engine");
-    e->stream_grouping = on < 0 ? 0 : (on > 2 ? 2 : on);
-    e->group_skip = 0;                       // forget what earlier streams were like
-    e->group_verdict_pending = false;
+    if (!e || form < 0 || form > 2) return fail(GORT_EINVAL, "gort_engine_set_stream_form: bad argument");
+    e->wide_form_pref = form;
     return GORT_OK;
 }
 
 extern "C" int gort_engine_stream_form(gort_engine *e)
 {
     if (!e) return fail(GORT_EINVAL, "gort_engine_stream_form: null engine");
-    if (e->stream_form >= 0) return e->stream_form;
-    int direct = 0;
-    GORT_HIP(hipStreamSynchronize(e->stream));
-    GORT_HIP(hipMemcpy(&direct, e->sgroup.p, sizeof(int), hipMemcpyDeviceToHost));      // flags[0] of the workspace
-    return direct != -1 ? 2 : 1;                                                         // -1 = clear
+    return e->stream_form;
 }
 
 extern "C" double gort_engine_last_stream_ms(gort_engine *e)
@@ -925,8 +868,8 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         if (nw <= 8 && fuse) return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream);
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
-        return launch_expand_stream(c, e->L.as<double>(), nw, nullptr, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr,
-                                    nullptr, nullptr, e->stream, nullptr, true);
+        return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr, 0,
+                                    e->stream, true);
     }
     // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).
     // Full-size slabs: ONE buffer, reused by every call - the 191 MB of records the geometry kernel writes are

@@ -1,4 +1,4 @@
-// gort_device.h -- device-side building blocks shared by the HIP translation units (gort_brdf.hip, gort_stream.hip):
+// gort_device.h -- device-side building blocks shared by the HIP translation units:
 // angle conventions, gap-table lookup, the (sun zenith, band) two-stream terms, the 5-term expansion and the
 // workgroup -> XCD-range mapping of the flat kernels.  Every kernel form calls THESE functions, so that all of them
 // write the same bits for the same inputs (tests: stream == grid, grouped == per-line).
@@ -108,6 +108,10 @@ __device__ inline SunScalars sun_from_zenith(const gort_canopy &c, double sza)
     const Primed sp = prime(c.b / c.r, sin_sz / cos_sz);
     return sun_scalars(c, sza, cos_sz, sp);
 }
+
+// t'_ff = t_ff (1 - kopen) + kopen with kopen = k_open + k_openep (gortt_brdf.c:348-365): ONE fused operation in
+// lambda_table_kernel (what the compiler made of it since round 1) and wherever else it is re-derived from t_ff
+__device__ __forceinline__ double tpff_of(double tff, double kopen) { return __builtin_fma(tff, 1.0 - kopen, kopen); }
 
 struct SunTerms { double C0, B, Z, G, T; };
 struct BandTerms { double gam, omega, Rff, Tff, tff, pff, rs, mgk, Zf, Tf, B; };
@@ -318,6 +322,13 @@ __device__ __forceinline__ long xcd_logical_block(int xcd_mode, const XcdDuty &d
         return s_block;                                       // never -1 (pigeonhole), checked by the caller anyway
     }
     return b < useful ? b : -1;
+}
+
+inline int check_launch(const char *what)
+{
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(GORT_ENODEVICE, "%s: %s", what, hipGetErrorString(err));
+    return GORT_OK;
 }
 
 constexpr int EPL = 2;                  // elements (adjacent bands) per lane and step

@@ -1,0 +1,196 @@
+// gort_geometry.hip -- the angle-only stage: one thread per angle line (streams) or one workgroup per four LUT rows
+// (grids).  Per angle tuple the kernels evaluate the ~35 fp64 transcendentals of gortt_kg / gortt_kc / gortt_kuusk
+// (gort_geometry.h) once and leave a record for the expansion kernels - or, for a few bands, the samples themselves.
+//
+//   wavelength only      L[11][nw]          lambda_table_kernel (gort_tables.hip)
+//   angle tuple only     coef[nA][16]       geometry_*_kernel   (this file)
+//   (sun zenith, band)   C0,B,Z,G,T         sun_terms()         (gort_device.h)
+//   sample               rsurf = aC*C0 + aB*B + aZ*Z + aG*G + aT*T   (5 FMAs, 8 B stored)
+//
+// which is an exact regrouping of gortt.c:484-557 (no approximation; rounding differs at the 1e-16 level).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "gort_geometry.h"
+
+namespace gort {
+namespace {
+
+// layout 0: the classic record (five coefficients, sun scalars, component-spectra extras: CoefSlot);
+// layout 1: the LineTerms of the stream family's regrouped sample (gort_device.h) for the wide stream kernels, which
+//           read them through the scalar cache once per 128 samples and must not spend VALU work on deriving them
+// FUSED (few bands, no component spectra): the line's samples are formed right here from the record in registers -
+// the same functions the narrow expansion kernels apply to the stored record, so the same bits - and no record is
+// written: one launch instead of two (a 181-line x 1-band call is launch latency and nothing else), and for long
+// narrow streams no 128 B of record written and read back per 8 B of result.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy *__restrict__ canopy,
+                                                               const double *__restrict__ angles, long nA,
+                                                               double *__restrict__ coef, double *__restrict__ K,
+                                                               int layout, const double *__restrict__ L, int nw,
+                                                               double *__restrict__ rsurf)
+{
+    const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nA) return;
+    // blockIdx.z = ensemble member: its canopy, its nA records (the angle lines are shared)
+    const long member = blockIdx.z;
+    const gort_canopy &c = canopy[member];
+    double vza, sza, saa, raa;
+    normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
+    GeomOut g;
+    geometry_core(c, vza, sza, raa, g);
+    if (FUSED) {
+        double rec[GORT_COEF_STRIDE];
+        store_coef(rec, c, g);
+        const LineTerms l = line_terms_of_record(rec, c.k_openep, c.k_open);
+        const double *__restrict__ Lm = L + member * L_NSLOT * nw;
+        double *__restrict__ o = rsurf + (member * nA + a) * nw;
+        for (int i = 0; i < nw; ++i) o[i] = stream_sample(l, stream_band(load_band(Lm, nw, i)));
+    } else if (layout == 0) {
+        store_coef(coef + (member * nA + a) * GORT_COEF_STRIDE, c, g);
+    } else {
+        double rec[GORT_COEF_STRIDE];
+        store_coef(rec, c, g);
+        const LineTerms l = line_terms_of_record(rec, c.k_openep, c.k_open);
+        double *o = coef + (member * nA + a) * GORT_COEF_STRIDE;
+        o[0] = l.alpha;  o[1] = l.P1;  o[2] = l.P2;  o[3] = l.Q1;  o[4] = l.Q2;  o[5] = l.Q3;  o[6] = l.Q4;  o[7] = l.Q5;
+        o[8] = l.Q6;  o[9] = l.mu;  o[10] = l.t0;  o[11] = l.omtp0;  o[12] = l.m2;  o[13] = 0.0;  o[14] = 0.0;  o[15] = 0.0;
+    }
+    if (K) {
+        double *k = K + 4 * (member * nA + a);
+        k[0] = g.Kc;  k[1] = g.Kg;  k[2] = g.Kt;  k[3] = g.Kz;
+    }
+}
+
+// grid nodes generated from indices; identical to streaming "vza phi sza 0" (SURVEY 8d, C3).
+// One workgroup per GEOM_ROWS LUT rows, a row = (member, sun zenith, view zenith): the azimuth-independent terms
+// of each row are evaluated ONCE into LDS, the rows side by side on the first lanes of one wavefront (the ~25
+// transcendentals of a row are a serial chain: four rows cost the issue time of one), then the lanes walk the
+// GEOM_ROWS x nphi azimuth nodes.  With 361 nodes per row this removes ~70 % of the transcendentals of the
+// per-tuple form.
+constexpr int GEOM_ROW_THREADS = 128;
+constexpr int GEOM_ROWS = 4;
+// mode 0: full stream records (GORT_COEF_STRIDE doubles per node); 1: compact 64-B records for the LUT kernel;
+// 2: FUSED for grids of a few bands (BASELINE config 3 is one band): the node's samples are formed right here from
+// its coefficients - no 128-B record per node written and read back (383 MB each way for the hemisphere grid,
+// more than the arithmetic costs) - with the same sun_terms()/dot5() as the two-kernel path: same bits.
+#ifndef GORT_GEOM_WAVES
+#define GORT_GEOM_WAVES 3      // 168 VGPRs instead of 171: a third wave per SIMD, C3 133 -> 125 us; 4 would spill to scratch
+#endif
+__global__ __launch_bounds__(GEOM_ROW_THREADS) __attribute__((amdgpu_waves_per_eu(GORT_GEOM_WAVES)))
+void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
+                                                                          gort_grid g, long row_begin, long n_rows,
+                                                                          double *__restrict__ coef, int compact,
+                                                                          const double *__restrict__ Lall, int nw,
+                                                                          double *__restrict__ rsurf)
+{
+    __shared__ RowTerms s_row[GEOM_ROWS];
+    __shared__ int s_member[GEOM_ROWS];
+    __shared__ double s_vza_deg[GEOM_ROWS], s_sza_deg[GEOM_ROWS];
+    const long rows_per_member = (long)g.nsza * g.nvza;
+    const long first = (long)blockIdx.x * GEOM_ROWS;                   // first row of this block, relative to row_begin
+    const int rows_here = n_rows - first < GEOM_ROWS ? (int)(n_rows - first) : GEOM_ROWS;
+    if ((int)threadIdx.x < rows_here) {
+        const long grow = row_begin + first + threadIdx.x;
+        const long member = grow / rows_per_member;
+        const long row = grow - member * rows_per_member;
+        const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
+        const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
+        double vza, sza, saa, raa;
+        normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
+        row_terms(canopies[member], vza, sza, s_row[threadIdx.x]);
+        s_member[threadIdx.x] = (int)member;
+        s_vza_deg[threadIdx.x] = vza_deg;
+        s_sza_deg[threadIdx.x] = sza_deg;
+    }
+    __syncthreads();
+    const int nodes = rows_here * g.nphi;
+    for (int n = threadIdx.x; n < nodes; n += GEOM_ROW_THREADS) {
+        const int r = n / g.nphi, l = n - r * g.nphi;
+        const gort_canopy &c = canopies[s_member[r]];
+        double vza, sza, saa, raa;
+        normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
+        GeomOut o;
+        finish_angle(c, s_row[r], raa, o);
+        const long i = first * g.nphi + n;
+        if (compact == 2) {
+            double rec[GORT_COEF_STRIDE];
+            store_coef(rec, c, o);
+            const double *__restrict__ L = Lall + (long)s_member[r] * L_NSLOT * nw;
+            const SunScalars sun = load_sun(rec);
+            for (int b = 0; b < nw; ++b) {
+                const SunTerms t = sun_terms(L, nw, b, sun, c.k_open, c.k_openep);
+                rsurf[i * nw + b] = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t.C0, t.B, t.Z, t.G, t.T);
+            }
+        } else if (compact) {
+            // LUT path: only the five expansion coefficients, one 64-B record per node
+            double rec[GORT_COEF_STRIDE];
+            store_coef(rec, c, o);
+            double2 *dst = reinterpret_cast<double2 *>(coef + i * 8);
+            dst[0] = make_double2(rec[A_C], rec[A_B]);
+            dst[1] = make_double2(rec[A_Z], rec[A_G]);
+            dst[2] = make_double2(rec[A_T], 0.0);
+            dst[3] = make_double2(0.0, 0.0);
+        } else {
+            store_coef(coef + i * GORT_COEF_STRIDE, c, o);
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------- launchers
+
+// n_members > 1: blockIdx.z = member, canopy_dev[m], records coef_dev[m][nA][16], proportions K_dev[m][nA][4]
+int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const double *angles_dev, long nA,
+                           double *coef_dev, double *K_dev, int layout, void *stream)
+{
+    if (nA <= 0 || n_members <= 0) return GORT_OK;
+    if (n_members > 65535) return fail(GORT_EINVAL, "geometry: %d members in one launch (max 65535)", n_members);
+    hipLaunchKernelGGL(geometry_stream_kernel<false>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
+                       (hipStream_t)stream, canopy_dev, angles_dev, nA, coef_dev, K_dev, layout, (const double *)nullptr, 0,
+                       (double *)nullptr);
+    return check_launch("geometry_stream_kernel");
+}
+
+// few bands, no component spectra: one fused launch (GORT_STREAM_FUSE=0 keeps the two-kernel path, for tests)
+bool stream_fuses(int nw, bool want_scomp)
+{
+    const char *v = getenv("GORT_STREAM_FUSE");             // read per call: the tests switch it inside one process
+    return !(v && atoi(v) == 0) && !want_scomp && nw > 0 && nw <= 16;
+}
+
+// geometry and samples of a few-band stream in one launch (no records): rsurf_dev[m][nA][nw]
+int launch_geometry_stream_fused(const gort_canopy *canopy_dev, int n_members, const double *L_dev, int nw,
+                                 const double *angles_dev, long nA, double *rsurf_dev, double *K_dev, void *stream)
+{
+    if (nA <= 0 || nw < 0 || n_members <= 0 || (nw == 0 && !K_dev)) return GORT_OK;      // nw = 0: the proportions K alone
+    if (n_members > 65535) return fail(GORT_EINVAL, "geometry: %d members in one launch (max 65535)", n_members);
+    hipLaunchKernelGGL(geometry_stream_kernel<true>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
+                       (hipStream_t)stream, canopy_dev, angles_dev, nA, (double *)nullptr, K_dev, 0, L_dev, nw, rsurf_dev);
+    return check_launch("geometry_stream_kernel<fused>");
+}
+
+int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
+                         double *coef_dev, bool compact, void *stream)
+{
+    const long rows = row_end - row_begin;
+    if (rows <= 0) return GORT_OK;
+    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
+                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, coef_dev, compact ? 1 : 0,
+                       (const double *)nullptr, 0, (double *)nullptr);
+    return check_launch("geometry_grid_kernel");
+}
+
+int launch_geometry_grid_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g, long row_begin,
+                               long row_end, double *rsurf_dev, void *stream)
+{
+    const long rows = row_end - row_begin;
+    if (rows <= 0 || nw <= 0) return GORT_OK;
+    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
+                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, (double *)nullptr, 2, L_dev, nw, rsurf_dev);
+    return check_launch("geometry_grid_kernel (fused)");
+}
+
+}  // namespace gort

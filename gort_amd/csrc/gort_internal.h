@@ -3,6 +3,7 @@
 #define GORT_INTERNAL_H
 
 #include "gort_amd.h"
+#include "gort_amd_tuning.h"
 
 namespace gort {
 
@@ -59,15 +60,17 @@ int launch_member_spectra(const gort_leaf_soil *leaf_dev, int n_members, int nw,
 const float *prospect_coeff_table();      // [7][2101]
 const double *price_eof_table();          // [4][421]
 void interface_transmissivity_tables(const double **t12, const double **talf);   // [2101] each
+// ---- geometry (gort_geometry.hip).  n_members > 1: one launch for all members (blockIdx.z), canopy_dev[m],
+// records coef_dev[m][nA][GORT_COEF_STRIDE], outputs member-major.
 // layout 0: classic records (CoefSlot); 1: the stream family's LineTerms (gort_device.h), what the WIDE stream
-// expansions read (launch_expand_stream with a stream for which expand_stream_workspace() returns true)
+// expansions read (stream_is_wide)
+int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const double *angles_dev, long nA,
+                           double *coef_dev, double *K_dev, int layout, void *stream);
 // streams of few bands without component spectra: geometry and samples in ONE launch, no records (same bits as the
 // two-kernel path: the same functions on the same record, kept in registers)
 bool stream_fuses(int nw, bool want_scomp);
-int launch_geometry_stream_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
-                                 long nA, double *rsurf_dev, double *K_dev, void *stream);
-int launch_geometry_stream(const gort_canopy *canopy_dev, const double *angles_dev, long nA,
-                           double *coef_dev, double *K_dev, int layout, void *stream);
+int launch_geometry_stream_fused(const gort_canopy *canopy_dev, int n_members, const double *L_dev, int nw,
+                                 const double *angles_dev, long nA, double *rsurf_dev, double *K_dev, void *stream);
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream);
@@ -100,27 +103,21 @@ int selftest_index_math();
 // expand_wants_xcd_slots: does the flat expansion need the slot counters (GORT_EXPAND_XCD or the probe says so)
 int probe_xcd_dispatch(void *stream, int *round_robin);
 bool expand_wants_xcd_slots(bool dispatch_round_robin);
+// ---- stream expansion (gort_stream_expand.hip)
 // coef_dev: stream records (GORT_COEF_STRIDE doubles each) with ONE readable pad record in front and
 // expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the
-// call, or nullptr for the static XCD mapping
-long expand_stream_tail_pad_records(int nw, long nA);
-// Wide streams without component spectra are expanded line group by line group (gort_stream.hip): device
-// workspace of expand_stream_workspace() bytes (0 = that form does not apply), angles_dev = the lines themselves.
-// Without workspace (or GORT_STREAM_GROUP=0) every line gets its own sun terms.  Returns whether the stream is
-// wide enough for the flat forms at all (its records must then be in layout 1).  coef_ready_event (hipEvent_t or null):
-// the records are being written on another stream; `stream` waits for the event before its first kernel that reads
-// them.  grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's
+// call, or nullptr for the static XCD mapping.
+// Wide streams (stream_is_wide: >= 128 bands, >= 4M samples, no component spectra) have their records in layout 1 and
+// are expanded by one of two kernels that write the same bits: wide_form 1 = flat panels (expand_flat_stream_kernel),
+// 2 = LDS-resident (expand_stream_lds_kernel; stream_lds_applies() says whether the band table fits the 160 KB of LDS).
+// grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's
 // five-term sample, so that every LUT path writes the same bits.
-bool expand_stream_workspace(int nw, long nA, bool want_scomp, size_t *ws_bytes, size_t *sun_bytes);
-int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
-                         const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev,
-                         void *group_ws_dev, double *group_sun_dev, void *stream, void *coef_ready_event, bool grid_form);
-// gort_stream.hip
-bool stream_group_enabled();
-void stream_group_workspace(int nw, long nA, size_t *ws_bytes, size_t *sun_bytes);
-int launch_expand_stream_grouped(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
-                                 const double *coef_dev, long nA, double *rsurf_dev, void *ws_dev, double *sun_dev,
-                                 void *stream, void *coef_ready_event, const int **direct_flag_dev);
+long expand_stream_tail_pad_records(int nw, long nA);
+bool stream_is_wide(int nw, long nA, bool want_scomp);
+bool stream_lds_applies(int nw, long nA);
+int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
+                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, int wide_form, void *stream,
+                         bool grid_form);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);

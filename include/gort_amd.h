@@ -17,6 +17,8 @@
  *     view zenith, view azimuth, sun zenith, sun azimuth (gortt.c:234).
  *   - there is NO CPU fallback: device entry points fail with GORT_ENODEVICE when
  *     no HIP device is usable.
+ *   - measurement and tuning hooks (kernel timers, XCD duty weights, kernel-form overrides)
+ *     are NOT part of this interface: include/gort_amd_tuning.h.
  */
 #ifndef GORT_AMD_H
 #define GORT_AMD_H
@@ -214,25 +216,6 @@ int  gort_rsurf_stream(gort_engine *e, const double *angles, long nA,
 int  gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA,
                            double *rsurf_dev, double *scomp_dev, double *K_dev);
 
-/* Wide streams (>= 4M samples, >= 128 bands, no component spectra) are expanded in one of two forms that write the
- * same bits (and the same bits as the narrow-stream kernels): per line (every line forms p_df, t'_df of its own sun
- * zenith: ~24 instructions + a reciprocal per sample; the default, and the faster one up to ~1M lines) or with the
- * lines grouped by sun zenith on the device (few distinct sun zeniths: the two numbers are shared, 10 FMAs per
- * sample; falls back to per line on the device when a stream has too many).
- *   gort_engine_stream_form         form of the last gort_rsurf_stream[_dev] call: 0 = narrow stream (other
- *                                   kernels), 1 = grouped, 2 = per line; synchronises the engine's stream
- *   gort_engine_set_stream_grouping 0 = per line (default), 1 = group streams of >= 200 000 lines
- *                                   (GORT_STREAM_GROUP_MIN), 2 = group whenever the stream allows it; also
- *                                   GORT_STREAM_GROUP=0|1|2.  In modes 1 and 2, after a call whose lines had too many
- *                                   distinct sun zeniths the next 15 calls go per line without trying; calling this
- *                                   function forgets that history
- *   gort_engine_last_stream_ms      duration (ms, HIP events on the engine's stream) of the expansion stage of
- *                                   the last stream call - grouping, sun table and expansion kernels; <0 if none.
- * New surface for tests and bench tools, not reference surface. */
-int  gort_engine_stream_form(gort_engine *e);
-int  gort_engine_set_stream_grouping(gort_engine *e, int on);
-double gort_engine_last_stream_ms(gort_engine *e);
-
 /* Regular-grid LUT: every (sun zenith, view zenith, relative azimuth) node in integer
  * steps, equivalent to streaming the lines "vza phi sza 0" (SURVEY.md 8d, C3):
  *   sza = sza0 + i*dsza (i<nsza), vza = vza0 + j*dvza (j<nvza), phi = phi0 + l*dphi (l<nphi)
@@ -257,26 +240,6 @@ int  gort_rsurf_members_stream(gort_engine *e, const double *angles, long nA, in
                                double *rsurf);
 int  gort_rsurf_members_stream_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
                                    int member_end, double *rsurf_dev);
-
-/* kernel-only timing hook for bench.py: average duration (ms) of the LUT expansion
- * kernel over the launches since the last call, measured with HIP events on the
- * engine's stream; returns <0 if none. */
-double gort_engine_last_expand_ms(gort_engine *e);
-/* how the flat expansion kernels map workgroups to XCD-contiguous output ranges on this device: 1 = static
- * (workgroup dispatch probed to be round-robin over the XCDs), 2 = per-XCD slot counters; <0 = a GORT_E* code */
-int  gort_engine_xcd_mapping(gort_engine *e);
-/* duty weights of the eight XCDs in 32nds (static mapping): the XCDs of a part do not write equally fast, and
- * the slower ones get a smaller share of the LUT slab.  Calibrated on the first LUT slab of >= 1 GiB
- * (GORT_XCD_CALIBRATE=0 or GORT_XCD_WEIGHTS="w0,...,w7" override).  Returns 1 once calibrated or set, else 0. */
-int  gort_engine_xcd_weights(const gort_engine *e, int weights[8]);
-/* set the weights (each 8..32) instead of calibrating; NULL = forget them and calibrate on the next big slab */
-int  gort_engine_set_xcd_weights(gort_engine *e, const int weights[8]);
-/* GB/s of the calibration pass: the LUT kernel's store pattern without any arithmetic, equal XCD shares, over the
- * slab the weights were measured on - the write rate this device and placement give that pattern; 0 before */
-double gort_engine_store_pattern_gbs(const gort_engine *e);
-/* host-only self-test of the LUT kernel's index arithmetic (multiply-shift divisions, XCD duty mapping as a
- * bijection); 0 = ok.  Needs no GPU. */
-int  gort_selftest_index_math(void);
 
 /* Spectral albedo, vegetation and soil absorption per angle line.  Replaces
  * gortt_energy/gortt_albedo (gortt_albedo.c:7-138): 32x16 Gauss-Legendre nodes over the

@@ -1,0 +1,55 @@
+/*
+ * gort_amd_tuning.h -- measurement and tuning hooks of libgort_amd.so.
+ *
+ * NOT part of the drop-in boundary (include/gort_amd.h): nothing here changes a result, and no caller of the
+ * reference's path needs any of it.  bench.py reads the kernel timers; tests use the form overrides to compare
+ * kernels that must write the same bits; the XCD functions expose what the LUT kernel measured about the part.
+ * The environment knobs that belong to the same category are listed in DESIGN.md (section "Knobs").
+ */
+#ifndef GORT_AMD_TUNING_H
+#define GORT_AMD_TUNING_H
+
+#include "gort_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- kernel timers (HIP events on the engine's own stream) ---- */
+/* average duration (ms) of the LUT expansion kernel (expand_flat_kernel) over the launches since the last call
+ * (up to 512 are kept); <0 if none */
+double gort_engine_last_expand_ms(gort_engine *e);
+/* duration (ms) of the expansion stage of the last gort_rsurf_stream[_dev] call; <0 if none */
+double gort_engine_last_stream_ms(gort_engine *e);
+
+/* ---- kernel form of wide streams (>= 4M samples, >= 128 bands, no component spectra) ----
+ * Two kernels write the same bits: 1 = flat panels (expand_flat_stream_kernel: waves of 64 steps that derive their
+ * band constants from global memory), 2 = LDS-resident (expand_stream_lds_kernel: one persistent workgroup per CU
+ * with the band table of all bands in the 160 KB of LDS; needs nw <= ~2130).  0 = automatic (2 where it applies).
+ * Also GORT_STREAM_FORM=0|1|2.  gort_engine_stream_form: form of the last stream call, 0 = a narrow-stream kernel. */
+int  gort_engine_set_stream_form(gort_engine *e, int form);
+int  gort_engine_stream_form(gort_engine *e);
+
+/* ---- XCDs ---- */
+/* how the flat expansion kernels map workgroups to XCD-contiguous output ranges on this device: 1 = static
+ * (workgroup dispatch probed to be round-robin over the XCDs), 2 = per-XCD slot counters; <0 = a GORT_E* code */
+int  gort_engine_xcd_mapping(gort_engine *e);
+/* duty weights of the eight XCDs in 32nds (static mapping): the XCDs of a part do not write equally fast, and
+ * the slower ones get a smaller share of the LUT slab.  Measured with one pass of the bare store pattern over a
+ * buffer whose contents are about to be overwritten anyway: a fresh gort_lut_alloc buffer, or the output slab of a
+ * grid call of >= 1 GiB right before the call writes it (only bytes the call itself will write); once per engine
+ * and again when the slab's size class (power of two) changes.  GORT_XCD_CALIBRATE=0 or
+ * GORT_XCD_WEIGHTS="w0,...,w7" override.  Returns 1 once calibrated or set, else 0. */
+int  gort_engine_xcd_weights(const gort_engine *e, int weights[8]);
+/* set the weights (each 8..32) instead of calibrating; NULL = forget them and calibrate on the next big slab */
+int  gort_engine_set_xcd_weights(gort_engine *e, const int weights[8]);
+/* GB/s of the calibration pass: the LUT kernel's store pattern without any arithmetic, equal XCD shares; 0 before */
+double gort_engine_store_pattern_gbs(const gort_engine *e);
+/* host-only self-test of the flat kernels' index arithmetic (multiply-shift divisions, XCD duty mapping as a
+ * bijection); 0 = ok.  Needs no GPU. */
+int  gort_selftest_index_math(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GORT_AMD_TUNING_H */

@@ -685,9 +685,9 @@ def _wide_stream_lines(n, seed):
 
 def test_wide_stream_kernels_against_the_reference():
     """The WIDE stream kernels pinned to the real reference itself (not only to the restatement): 60 000 lines x 180
-    bands (as many bands as the reference's 999-character header takes; 1.08e7 samples: the per-line flat kernel, and
-    the grouped form for the half of the stream with 90 distinct sun zeniths) - 100 of the lines were computed by the
-    reference at %.17g (tests/golden/wide_stream.npz)."""
+    bands (as many bands as the reference's 999-character header takes; 1.08e7 samples), through the flat-panel kernel
+    and through the LDS-resident kernel - 100 of the lines were computed by the reference at %.17g
+    (tests/golden/wide_stream.npz)."""
     import torch
     g = np.load(os.path.join(GOLDEN, "wide_stream.npz"))
     wl, pick, ref = g["wl"], g["pick"], g["rsurf"]
@@ -698,10 +698,10 @@ def test_wide_stream_kernels_against_the_reference():
     eng.set_spectra(*api.spectra(wl))
     a = torch.as_tensor(ang, device="cuda")
     worst = {}
-    for name, mode, lines in (("per-line", 0, slice(None)), ("grouped", 2, slice(0, len(ang) // 2))):
-        sub = a[lines].contiguous()
+    for name in ("flat", "lds"):
+        sub = a
         out = torch.full((sub.shape[0], len(wl)), -7.0, dtype=torch.float64, device="cuda")
-        eng.set_stream_grouping(mode)
+        eng.set_stream_form(name)
         torch.cuda.synchronize()
         eng.rsurf_stream_dev(sub, out)
         eng.synchronize()
@@ -710,7 +710,7 @@ def test_wide_stream_kernels_against_the_reference():
         got = out[torch.as_tensor(idx, device="cuda")].cpu().numpy()
         worst[name] = err(got, ref[: len(idx)])
         assert worst[name] <= REGRESSION, (name, worst)
-    eng.set_stream_grouping(0)
+    eng.set_stream_form("auto")
     eng.close()
     print("wide stream vs reference:", worst)
 
@@ -749,7 +749,7 @@ def test_lut_kernel_against_the_reference():
 def test_full_spectrum_stream_against_the_reference_function():
     """2101 bands - more than the reference's CLI can read (999-character header) - against the reference's own
     gortt_rsurf at function level (oracle/_ref/libgortt_ref.so travels with the snapshot; skipped where it is absent):
-    40 of 65 536 random lines through the per-line flat kernel and, for the 91-zenith half, the grouped form."""
+    40 of 65 536 random lines through the LDS-resident kernel (the default) and through the flat-panel kernel."""
     import torch
     if not os.path.exists(O.REF_SO):
         pytest.skip("oracle/_ref/libgortt_ref.so did not travel")
@@ -770,20 +770,18 @@ def test_full_spectrum_stream_against_the_reference_function():
     torch.cuda.synchronize()
     eng.rsurf_stream_dev(a, out)
     eng.synchronize()
-    assert eng.stream_form() == "per-line"
+    assert eng.stream_form() == "lds"
     e1 = err(out[torch.as_tensor(pick, device="cuda")].cpu().numpy(), ref)
-    half = a[: n // 2].contiguous()
-    eng.set_stream_grouping(2)
+    eng.set_stream_form("flat")
     out.fill_(-7.0)
     torch.cuda.synchronize()
-    eng.rsurf_stream_dev(half, out[: n // 2])
+    eng.rsurf_stream_dev(a, out)
     eng.synchronize()
-    assert eng.stream_form() == "grouped"
-    lo = pick[pick < n // 2]
-    e2 = err(out[torch.as_tensor(lo, device="cuda")].cpu().numpy(), ref[: len(lo)])
-    eng.set_stream_grouping(0)
+    assert eng.stream_form() == "flat"
+    e2 = err(out[torch.as_tensor(pick, device="cuda")].cpu().numpy(), ref)
+    eng.set_stream_form("auto")
     eng.close()
-    print("2101-band stream vs the reference function: per-line %.2e, grouped %.2e" % (e1, e2))
+    print("2101-band stream vs the reference function: LDS-resident %.2e, flat panels %.2e" % (e1, e2))
     assert e1 <= REGRESSION and e2 <= REGRESSION
 
 
@@ -865,7 +863,6 @@ def test_lut_kernel_variants_bitwise_identical():
     store flavour) writes the same bytes: the knobs change speed only."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     envs = [{}, {"GORT_EXPAND_XCD": "0"}, {"GORT_EXPAND_XCD": "1"}, {"GORT_EXPAND_XCD": "2"},
-            {"GORT_EXPAND_VARIANT": "row"},
             {"GORT_EXPAND_DEPTH": "1", "GORT_EXPAND_WAVES": "500"}, {"GORT_EXPAND_DEPTH": "4", "GORT_EXPAND_NT": "0"},
             {"GORT_EXPAND_STEPS": "0", "GORT_EXPAND_WAVES": "33616"}, {"GORT_EXPAND_STEPS": "2"},
             {"GORT_EXPAND_STEPS": "10", "GORT_EXPAND_DEPTH": "4", "GORT_EXPAND_XCD": "2"}]

@@ -23,8 +23,14 @@ def test_header_symbols_exported():
     declared = set(re.findall(r"\b(gort_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     assert declared == set(api.DECLARED_SYMBOLS), declared ^ set(api.DECLARED_SYMBOLS)
+    # measurement and tuning hooks live in a header of their own, outside the drop-in boundary
+    tun = open(os.path.join(ROOT, "include", "gort_amd_tuning.h")).read()
+    tun = re.sub(r"/\*.*?\*/", "", tun, flags=re.S)
+    tuning = set(re.findall(r"\b(gort_[a-z0-9_]+)\s*\(", tun))
+    assert tuning == set(api.TUNING_SYMBOLS), tuning ^ set(api.TUNING_SYMBOLS)
+    assert not (tuning & declared)
     L = api.lib()
-    for name in sorted(declared):
+    for name in sorted(declared | tuning):
         assert hasattr(L, name), "libgort_amd.so does not export %s" % name
     assert b"gfx950" in L.gort_version()
 
@@ -200,7 +206,7 @@ def test_error_codes_are_negative_and_null_handles_fail_cleanly():
     L = api.lib()
     assert L.gort_engine_xcd_mapping(None) == api.EINVAL
     assert L.gort_engine_stream_form(None) == api.EINVAL
-    assert L.gort_engine_set_stream_grouping(None, 1) == api.EINVAL
+    assert L.gort_engine_set_stream_form(None, 1) == api.EINVAL
     assert L.gort_engine_last_stream_ms(None) < 0
     assert L.gort_engine_synchronize(None) == api.EINVAL
     w = (C.c_int * 8)()

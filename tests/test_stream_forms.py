@@ -1,6 +1,7 @@
-"""The two forms of the wide-stream expansion (gort_amd/csrc/gort_stream.hip): lines grouped by sun zenith and
-per-line sun terms must write the SAME BITS (as must the narrow stream kernels: tests/test_pipe_and_cli.py compares
-chunked with whole streams), agree with the LUT path on grid angles to rounding and with the oracle to 1e-9.
+"""The two kernels of the wide-stream expansion (gort_amd/csrc/gort_stream_expand.hip) - flat panels of long waves
+and the LDS-resident form (one persistent workgroup per CU, band table in LDS) - must write the SAME BITS (as must the
+narrow stream kernels: tests/test_pipe_and_cli.py compares chunked with whole streams), agree with the LUT path on grid
+angles to rounding and with the oracle to 1e-9.
 
 Reference interface: the per-line loop of main(), gortt.c:232-329 (+ gortt_rsurf, gortt.c:385-578)."""
 import os
@@ -33,16 +34,16 @@ def setup():
     eng.close()
 
 
-def _run(eng, torch, ang, nw, grouping, out=None):
+def _run(eng, torch, ang, nw, lds, out=None):
     a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
     if out is None:
         out = torch.full((ang.shape[0], nw), -7.0, dtype=torch.float64, device="cuda")
-    eng.set_stream_grouping(2 if grouping else 0)      # 2: group whenever possible (automatic mode has a size threshold)
+    eng.set_stream_form("lds" if lds else "flat")
     torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
     eng.rsurf_stream_dev(a, out)
     eng.synchronize()
     form = eng.stream_form()
-    eng.set_stream_grouping(0)
+    eng.set_stream_form("auto")
     return out, form
 
 
@@ -55,9 +56,9 @@ def _lines(rng, n, sza_pool):
     return np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), sza, rng.uniform(-400, 400, n)], 1)
 
 
-def test_grouped_equals_per_line_bitwise_and_oracle(setup):
-    """70 001 lines (ragged last tile) x 2101 bands, 91 integer sun zeniths in random order, some of them negative
-    (zenith -> |zenith|, azimuth + 180: same group)."""
+def test_lds_form_equals_flat_form_bitwise_and_oracle(setup):
+    """70 001 lines (ragged last task) x 2101 bands, 91 integer sun zeniths in random order, some of them negative
+    (zenith -> |zenith|, azimuth + 180)."""
     eng, c, torch = setup
     rng = np.random.default_rng(91)
     wl = np.arange(400.0, 2501.0)
@@ -66,10 +67,13 @@ def test_grouped_equals_per_line_bitwise_and_oracle(setup):
     pool = np.concatenate([np.arange(0.0, 90.0), -np.arange(1.0, 45.0)])
     ang = _lines(rng, 70001, pool)
     g, form_g = _run(eng, torch, ang, wl.size, True)
-    assert form_g == "grouped"
+    assert form_g == "lds"
     p, form_p = _run(eng, torch, ang, wl.size, False)
-    assert form_p == "per-line"
+    assert form_p == "flat"
     assert _bits_equal(g, p)
+    eng.rsurf_stream_dev(torch.as_tensor(np.ascontiguousarray(ang), device="cuda"), p)
+    eng.synchronize()
+    assert eng.stream_form() == "lds"                    # the default for a full spectrum
     idx = np.sort(rng.choice(ang.shape[0], 40, replace=False))
     idx[0], idx[-1] = 0, ang.shape[0] - 1
     ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[idx], rs, rl, tl, want_K=False)
@@ -77,10 +81,10 @@ def test_grouped_equals_per_line_bitwise_and_oracle(setup):
     assert relerr(got, ref, floor=1e-12) <= REGRESSION
 
 
-@pytest.mark.parametrize("nw", [128, 129, 143, 144, 1000, 1999, 2048, 3000])
-def test_grouped_band_counts_and_row_alignments(setup, nw):
-    """Rows of nw doubles start at every alignment class (nw odd) or only some (nw even); the last segment is
-    ragged; the output itself may start off a 128-B boundary."""
+@pytest.mark.parametrize("nw", [128, 129, 143, 144, 1000, 1999, 2048, 2101, 2130])
+def test_lds_form_band_counts_and_output_alignments(setup, nw):
+    """Band counts with every gcd(nw, 128) (columns of 1..128 chunk strides, 2..17 lines per 16-column step), the
+    last task ragged, the output itself starting off a 1-KiB chunk boundary (front and back edge handling)."""
     eng, c, torch = setup
     rng = np.random.default_rng(nw)
     wl = np.linspace(400.0, 2500.0, nw)
@@ -91,15 +95,16 @@ def test_grouped_band_counts_and_row_alignments(setup, nw):
         buf = torch.full((n * nw + 32,), -7.0, dtype=torch.float64, device="cuda")
         out = buf[offset:offset + n * nw].view(n, nw)
         g, form = _run(eng, torch, ang, nw, True, out)
-        assert form == "grouped"
-        p, _ = _run(eng, torch, ang, nw, False)
+        assert form == "lds"
+        p, form = _run(eng, torch, ang, nw, False)
+        assert form == "flat"
         assert _bits_equal(g, p), (nw, offset)
         assert float(buf[:offset].min() if offset else -7.0) == -7.0 and float(buf[offset + n * nw:].max()) == -7.0
 
 
 def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
-    """A principal-plane style stream (ONE sun zenith, 300 000 lines): the skewed case of the grouping.  Plus lines
-    beyond the horizon and NaN zeniths, which form groups of their own and give NaN rows in both forms."""
+    """A principal-plane style stream (ONE sun zenith, 300 000 lines), with lines beyond the horizon and NaN zeniths,
+    which give NaN rows in both forms."""
     eng, c, torch = setup
     rng = np.random.default_rng(7)
     wl = np.linspace(400.0, 2500.0, 300)
@@ -111,7 +116,7 @@ def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
     ang[rng.choice(n, 50, replace=False), 2] = np.nan
     ang[rng.choice(n, 50, replace=False), 0] = 90.0
     g, form = _run(eng, torch, ang, wl.size, True)
-    assert form == "grouped"
+    assert form == "lds"
     p, _ = _run(eng, torch, ang, wl.size, False)
     assert _bits_equal(g, p)
     bad = np.isnan(ang[:, 2]) | (np.abs(ang[:, 2]) > 90) | (np.abs(ang[:, 0]) >= 90)
@@ -122,34 +127,21 @@ def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
     assert relerr(g[torch.as_tensor(idx, device="cuda")].cpu().numpy(), ref, floor=1e-12) <= REGRESSION
 
 
-def test_too_many_sun_zeniths_fall_back_on_the_device(setup):
-    """129 distinct sun zeniths inside one tile, or 600 over the whole call with few per tile: the grouped form
-    gives the stream up (flag raised on the device) and the per-line kernel writes it."""
+def test_band_table_beyond_the_lds_falls_back_to_the_flat_form(setup):
+    """3000 bands x 9 constants do not fit a CU's 160 KB: the flat form runs whatever was asked for; streams below
+    4M samples take the narrow kernels."""
     eng, c, torch = setup
     rng = np.random.default_rng(3)
-    wl = np.arange(400.0, 2501.0)
-    eng.set_spectra(*api.spectra(wl))
-    n = 6000
-    ang = _lines(rng, n, np.linspace(0.0, 89.0, 129))
+    wl = np.linspace(400.0, 2500.0, 3000)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_spectra(rs, rl, tl)
+    ang = _lines(rng, 3000, np.linspace(0.0, 89.0, 129))
     g, form = _run(eng, torch, ang, wl.size, True)
-    assert form == "per-line"
-    p, _ = _run(eng, torch, ang, wl.size, False)
-    assert _bits_equal(g, p)
-    # 600 distinct zeniths, 100 per 2048-line tile
-    n = 6 * 2048
-    ang = _lines(rng, n, np.array([0.0]))
-    for t in range(6):
-        ang[t * 2048:(t + 1) * 2048, 2] = rng.choice(np.linspace(0.0 + t, 80.0 + t, 100) + 0.001 * t, 2048)
-    g, form = _run(eng, torch, ang, wl.size, True)
-    assert form == "per-line"
-    p, _ = _run(eng, torch, ang, wl.size, False)
-    assert _bits_equal(g, p)
-    # 128 in every tile and the same 128 everywhere: grouped
-    ang[:, 2] = rng.choice(np.linspace(0.0, 88.9, 128), n)
-    g, form = _run(eng, torch, ang, wl.size, True)
-    assert form == "grouped"
-    p, _ = _run(eng, torch, ang, wl.size, False)
-    assert _bits_equal(g, p)
+    assert form == "flat"
+    ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[:20], rs, rl, tl, want_K=False)
+    assert relerr(g[:20].cpu().numpy(), ref, floor=1e-12) <= REGRESSION
+    g, form = _run(eng, torch, ang[:1000], wl.size, True)
+    assert form == "narrow"
 
 
 def test_grid_lines_through_the_stream_equal_the_lut(setup):
@@ -166,9 +158,10 @@ def test_grid_lines_through_the_stream_equal_the_lut(setup):
     eng.synchronize()
     rows = np.arange(r0, r1)
     ang = np.array([[float(r % 91), float(l), float(r // 91), 0.0] for r in rows for l in range(361)])
-    s, form = _run(eng, torch, ang, wl.size, True)
-    assert form == "grouped"
-    assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13
+    for lds in (True, False):
+        s, form = _run(eng, torch, ang, wl.size, lds)
+        assert form == ("lds" if lds else "flat")
+        assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13
 
 
 @pytest.mark.parametrize("nw", [1, 4, 16, 17])

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """The arbitrary-angle stream (gortt.c:232-329) on device-resident buffers: N random lines x 2101 bands, with
-91 distinct sun zeniths, every line its own sun zenith, one sun zenith, ...; each in the per-line form (the default)
-and with the lines grouped by sun zenith on the device (mode 2; a stream with too many zeniths falls back per line).
-Prints, per case, the time of the expansion stage (HIP events on the engine's stream: grouping + sun table +
-expansion kernels), the whole call (geometry included, wall clock around a stream synchronisation), the samples/s
+91 distinct sun zeniths, every line its own sun zenith, one sun zenith, ...; each through the LDS-resident kernel (the
+default) and through the flat-panel kernel (include/gort_amd_tuning.h).
+Prints, per case, the time of the expansion stage (HIP events on the engine's stream), the whole call (geometry included, wall clock around a stream synchronisation), the samples/s
 and the fraction of the 8 TB/s HBM peak at 8 B per sample + 32 B per line."""
 import os, sys, time
 import numpy as np
@@ -34,13 +33,13 @@ while time.perf_counter() - _t < 0.3:
     eng.rsurf_stream_dev(_a, out)
     eng.synchronize()
 for name, sza in cases.items():
-    if only and only not in name:
+    if only and not any(o in name for o in only.split(",")):
         continue
     a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), sza, np.zeros(n)], 1), device="cuda")
-    for grouping in (0, 2):                                 # 0 = per line (the default), 2 = group whenever the stream allows it
+    for grouping in (2, 1):                                 # 2 = LDS-resident (the default), 1 = flat panels
         if os.environ.get("BENCH_STREAM_MODES") and str(grouping) not in os.environ["BENCH_STREAM_MODES"]:
             continue
-        eng.set_stream_grouping(grouping)
+        eng.set_stream_form(grouping)
         for _ in range(3):
             eng.rsurf_stream_dev(a, out)
         eng.synchronize()
@@ -54,7 +53,7 @@ for name, sza in cases.items():
         form = eng.stream_form()
         byts = n * wl.size * 8 + n * 32
         e, w = float(np.median(ex)), float(np.median(wall))
-        print("%-16s grouping=%d form=%-8s expansion %7.1f us (%5.0f GB/s, %.3f of 8 TB/s) | call %7.1f us  %.3e samples/s (%.3f)"
+        print("%-16s form=%d %-6s expansion %7.1f us (%5.0f GB/s, %.3f of 8 TB/s) | call %7.1f us  %.3e samples/s (%.3f)"
               % (name, grouping, form, e * 1e6, byts / e / 1e9, byts / e / 8e12, w * 1e6, n * wl.size / w, byts / w / 8e12), flush=True)
         if os.environ.get("BENCH_STREAM_JSON"):              # the same in the shape of bench.py's line, one object per case and form
             import json
@@ -67,4 +66,4 @@ for name, sza in cases.items():
                     "roofline": {"bound": "hbm", "kernel": "expansion stage (HIP events on the engine's stream)", "achieved": byts / e / 1e9,
                                  "peak": 8000.0, "unit": "GB/s", "frac": byts / e / 8e12, "kernel_ms": e * 1e3,
                                  "algorithmic_bytes_per_launch": byts, "traffic": None}}) + "\n")
-eng.set_stream_grouping(0)
+eng.set_stream_form(0)
