@@ -14,8 +14,11 @@ One step = one full evaluation of the grid into HBM: the per-angle geometry kern
 (sun zenith, band) table kernel and the LUT expansion kernel, all inside the timed
 region.  Inputs (gap tables, spectra) are resident in HBM before timing starts; the
 output stays in HBM.  With N ranks the 8281 (sun zenith, view zenith) rows are split into
-N contiguous slabs, total work fixed (strong scaling); no collective on the data path -
-see DESIGN.md "Multi-GPU" for why the 50 GB LUT is not all-gathered inside the step.
+N contiguous slabs, total work fixed (strong scaling), and every rank computes into ITS WINDOW of one gatherable
+LUT buffer; no collective inside the step.  After the timed steps the in-place RCCL all-gather that reassembles the
+LUT on every GPU runs once and is reported (`allgather`: ms, GB/s received per GPU against the xGMI bound, parity of
+rows that came from other ranks) - see DESIGN.md "Multi-GPU" for why it is not part of the step.  A `config5` block
+(the 1000-member ensemble, members sharded, its energy-table all-gather timed) follows.
 
 Prints ONE JSON line on rank 0.
 """
@@ -170,6 +173,100 @@ def cpu_baseline_grid(wl, procs, budget_s=12.0):
                       % (procs, n_each, len(wl), busy, wall, model)}
 
 
+XGMI_BOUND_GBS = 7 * 153.0   # receive bound of one GPU: seven xGMI links x ~153 GB/s (MI355X_MICROARCH.md)
+
+
+def reference_build_id():
+    """sha256 (first 16 hex digits) of the reference build this run can time and check against: oracle/_ref/libgortt_ref.so,
+    compiled from /root/reference by oracle/Makefile in the build container (oracle/_ref.MANIFEST holds the hashes of
+    record); 'absent' where it did not travel - cpu_baseline then falls back to the port and says so in `kind`."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libgortt_ref.so")
+    if not os.path.exists(so):
+        return "absent"
+    import hashlib
+    h = hashlib.sha256()
+    with open(so, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def oracle_rows(wl, grid, rows_idx, phi_idx):
+    """rsurf rows of grid nodes (global row = isza * nvza + ivza, azimuth index) from the CPU restatement."""
+    from oracle import oracle as O
+    O.AUTO_BUILD = False                  # the prebuilt checker or nothing: no compiler runs in a bench process
+    oc = O.make_canopy(lai=4.0)
+    ors, orl, otl = O.spectra(wl)
+    ang = np.stack([(rows_idx % grid.nvza).astype(float), phi_idx.astype(float),
+                    (rows_idx // grid.nvza).astype(float), np.zeros(rows_idx.size)], 1)
+    ref, _, _ = O.rsurf_stream(oc, ang, ors, orl, otl, want_K=False)
+    return ref
+
+
+def compare(got, ref, what):
+    m = np.isfinite(ref)
+    return {"max_rel_err": float(np.max(np.abs(got[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1e-12))) if m.any() else 0.0,
+            "nan_pattern_equal": bool(np.array_equal(np.isnan(got), np.isnan(ref))), "samples_checked": int(ref.size),
+            "tolerance": 1e-5, "rows": what}
+
+
+def config5_block(args, rank, world, dist, barrier):
+    """BASELINE config 5 as a block of its own: 1000 canopy-parameter members sharded over the ranks (row_slab), per
+    member gap probabilities + PROSPECT-D/Price + band tables + the hemisphere x 2101-band LUT (chunks, HBM resident)
+    + the albedo/fAPAR table, then the ONE exchange step of the path: the RCCL all-gather of energy[members][2101][3].
+    Strong scaling (the ensemble is fixed); value = samples of all members / slowest rank's time incl. the gather."""
+    import torch
+    from gort_amd.ensemble import sharded_albedo_table
+    wl = np.arange(400.0, 2501.0)
+    n = args.c5_members
+    table, t = sharded_albedo_table(n, wl, rank, world, lut_chunk=args.c5_chunk, gather_on_cpu=args.rehearse, barrier=barrier)
+    red_dev = "cpu" if args.rehearse else "cuda"
+    keys = ("setup_s", "lut_s", "energy_s", "gather_s", "total_s")
+    mine = torch.tensor([t[k] for k in keys], dtype=torch.float64, device=red_dev)
+    per_rank = None
+    if world > 1:
+        worst = mine.clone()
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {"rank": rank, "members": t["members"], "setup_ms": t["setup_s"] * 1e3,
+                                          "lut_ms": t["lut_s"] * 1e3, "lut_chunk_ms": t["lut_chunk_ms"],
+                                          "energy_ms": t["energy_s"] * 1e3, "gather_ms": t["gather_s"] * 1e3})
+    else:
+        worst = mine
+    worst = dict(zip(keys, (float(x) for x in worst)))
+    if rank != 0:
+        return None
+    samples = n * 91 * 361 * wl.size if args.c5_chunk else 0
+    out = {"workload": "EnKF ensemble: %d members (SURVEY 8d draw, seed 12345) x hemisphere 91x361 x %d bands + albedo/fAPAR table, "
+                       "members sharded over %d rank(s)" % (n, wl.size, world),
+           "members": n, "lut_chunk_members": args.c5_chunk, "samples": samples, "scaling": "strong",
+           "value": samples / worst["total_s"] if samples else None, "unit": "samples/s",
+           "ms": {k[:-2] + "_ms": worst[k] * 1e3 for k in keys}, "timing": "max over ranks of each stage; total = first setup call "
+           "to gathered table on every rank",
+           "allgather": {"what": "energy[members][2101][3] f64, in place (gort_amd.shard)", "ms": worst["gather_s"] * 1e3,
+                         "bytes_received_per_gpu": t["gather_bytes_received"],
+                         "gbs_received_per_gpu": t["gather_bytes_received"] / worst["gather_s"] / 1e9 if world > 1 else None,
+                         "xgmi_bound_gbs": XGMI_BOUND_GBS, "backend": "gloo (rehearsal)" if args.rehearse else ("nccl" if world > 1 else None)},
+           "per_rank": per_rank}
+    # parity of the exchanged product: one member of this rank and one that arrived through the all-gather
+    try:
+        from gort_amd.ensemble import draw_c5_members
+        from oracle import oracle as O
+        O.AUTO_BUILD = False
+        canopies, leaf = draw_c5_members(n)
+        errs = {}
+        for label, m in (("own_member", 0), ("foreign_member", n - 1)):
+            c, ls = canopies[m], leaf[m]
+            oc = O.make_canopy(favd=c.favd, r=c.r, b=c.b, h1=c.h1, h2=c.h2, lam=c.lambda_)
+            rs, rl, tl = O.spectra(wl, prospect=dict(N=ls.N, Cab=ls.Cab, Car=ls.Car, Cw=ls.Cw, Cm=ls.Cm), rsl=tuple(ls.rsl))
+            ref = O.energy_stream(oc, np.array([[0.0, 0.0, 30.0, 0.0]]), rs, rl, tl)[0]
+            errs[label] = dict(compare(table[m], ref, "member %d" % m))
+        out["parity"] = errs
+    except Exception as ex:
+        out["parity"] = {"error": repr(ex)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,16 +275,18 @@ def main():
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--slab-candidates", type=int, default=3,
-                    help="untimed setup: allocate this many LUT slabs, keep the one the expansion kernel writes fastest, "
-                         "verify it, redraw up to 3 times if it is a slow placement (1 = off)")
+    ap.add_argument("--lut-draws", type=int, default=3,
+                    help="max_draws of gort_lut_alloc, the C ABI's allocator for LUT buffers (1 = plain allocation); the "
+                         "first-draw timing is always measured and reported beside it")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")
     ap.add_argument("--sustain-s", type=float, default=3.0,
                     help="after the timed region, keep stepping for this many seconds and report the mean step ('sustained'); 0 = off")
     ap.add_argument("--rehearse", action="store_true",
                     help="multi-rank dry run on ONE GPU: every rank uses cuda:0, process group gloo (not a measurement)")
-    ap.add_argument("--gather", action="store_true",
-                    help="after the timed steps, all-gather the full LUT on every rank (RCCL) and report allgather_ms")
+    ap.add_argument("--no-gather", action="store_true", help="world > 1: skip the all-gather of the LUT after the timed steps")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (ensemble) block")
+    ap.add_argument("--c5-members", type=int, default=1000, help="members of the config-5 ensemble (1000 = BASELINE config 5)")
+    ap.add_argument("--c5-chunk", type=int, default=40, help="members per LUT chunk of the config-5 block (0 = no LUTs)")
     ap.add_argument("--traffic-gb", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (GB)")
     args = ap.parse_args()
@@ -201,10 +300,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     # --rehearse: all ranks share GPU 0 and talk over gloo (a 1-GPU box cannot run RCCL between two ranks);
-    # exercises sharding, slab sizing and the max-over-ranks timing exactly as the real multi-GPU run does.
+    # exercises sharding, window layout, gather and the max-over-ranks timing exactly as the real multi-GPU run does.
     dev_index = 0 if args.rehearse else local
     torch.cuda.set_device(dev_index)
     red_dev = "cpu" if args.rehearse else "cuda"
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if args.rehearse:
@@ -216,6 +316,13 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def reduce_max(values):
+        if world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor(list(values), dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
     # ---- untimed setup: canopy, gap probabilities (GPU), spectra, engine ----
     wl = np.arange(400.0, 2501.0, 1.0) if args.nw == 2101 else np.linspace(400.0, 2500.0, args.nw)
     nw = wl.size
@@ -226,115 +333,111 @@ def main():
     eng.set_spectra(rs, rl, tl)
     grid = api.hemisphere_grid(nsza=args.nsza)
     rows = grid.nsza * grid.nvza
-    from gort_amd.shard import all_gather_in_place, empty_gatherable, my_window, row_slab
+    from gort_amd.shard import all_gather_in_place, gatherable_rows, row_slab
     r0, r1 = row_slab(rank, world, rows)
-    my_samples = (r1 - r0) * grid.nphi * nw
-    total_samples = rows * grid.nphi * nw
-    slab_ms = []
-    if args.gather and world > 1:
-        # the whole LUT once (+ < world rows of padding): this rank computes straight into its window of it and
-        # the all-gather lands in place - no receive buffer, no second copy (gort_amd/shard.py)
-        full_padded = empty_gatherable(rows, grid.nphi * nw, world, torch.float64, "cuda")
-        lut = my_window(full_padded, rank, world, rows).view((r1 - r0) * grid.nphi, nw)
-    else:
-        # untimed setup: the slab is the fastest of a few allocations (physical placement decides +-5 % of the
-        # expansion kernel's write rate and a multi-GPU step ends with its slowest rank)
-        from gort_amd.shard import pick_fastest_slab
-        lut, slab_ms = pick_fastest_slab(eng, grid, r0, r1, nw, candidates=args.slab_candidates)
+    row_elems = grid.nphi * nw
+    my_samples = (r1 - r0) * row_elems
+    total_samples = rows * row_elems
+    # The layout that is timed IS the layout a reassembled LUT needs: every rank allocates the whole LUT (+ < world rows
+    # of padding) once and computes straight into its own window of it; the all-gather after the timed steps lands in
+    # place.  At world 1 the window is the buffer.
+    buf_rows = gatherable_rows(world, rows)
+    window = (r0 * row_elems, max(r1 - r0, 0) * row_elems)
 
-    def step():
-        if r1 > r0:
-            eng.rsurf_grid_dev(grid, r0, r1, lut)
-
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    eng.last_expand_ms()                      # drop warm-up launches from the kernel average
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = eng.last_expand_ms()          # mean duration of the LUT expansion kernel, HIP events on its stream
-    if kernel_ms < 0:
-        kernel_ms = 0.0                       # a rank without rows
-
-    # ---- sustained rate: the same step back to back for >= --sustain-s seconds (clocks and power settled) ----
-    sustained = None
-    if args.sustain_s > 0:
-        n_sus = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-4)) + 1)
+    def timed_steps(lut_ptr, warmup, steps):
+        """`warmup` untimed and `steps` timed steps into lut_ptr, bracketed as the contract says; (seconds, kernel ms)."""
+        for _ in range(warmup):
+            if r1 > r0:
+                eng.rsurf_grid_dev(grid, r0, r1, lut_ptr)
+        eng.synchronize()
+        eng.last_expand_ms()                      # drop warm-up launches from the kernel average
+        torch.cuda.synchronize()
         barrier()
-        ts = time.perf_counter()
-        for _ in range(n_sus):
-            step()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if r1 > r0:
+                eng.rsurf_grid_dev(grid, r0, r1, lut_ptr)
         eng.synchronize()
         torch.cuda.synchronize()
         barrier()
-        sus_dt = time.perf_counter() - ts
-        sus_kernel = eng.last_expand_ms()
-        if world > 1:
-            t = torch.tensor([sus_dt, max(sus_kernel, 0.0)], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sus_dt, sus_kernel = float(t[0]), float(t[1])
+        dt = time.perf_counter() - t0
+        k = eng.last_expand_ms()                  # mean duration of the LUT expansion kernel, HIP events on its stream
+        return dt, (k if k > 0 else 0.0)          # a rank without rows has no launches
+
+    # ---- (1) a plain first allocation, timed exactly like the record: what hipMalloc's first answer is worth ----
+    first = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1)
+    fd_dt, fd_kernel = timed_steps(first.at(window[0]), args.warmup, args.steps)
+    first.free()
+    # ---- (2) the product allocator of the C ABI (gort_lut_alloc: best of <= --lut-draws placements by a store-pattern
+    #          probe of the window this rank writes); the number of record is measured on its buffer ----
+    buf = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
+    lut_ptr = buf.at(window[0])
+    dt, kernel_ms = timed_steps(lut_ptr, args.warmup, args.steps)
+
+    # ---- sustained rate: the same step back to back for >= --sustain-s seconds (clocks and power settled) ----
+    dt, kernel_ms_max, fd_dt, fd_kernel_max = reduce_max([dt, kernel_ms, fd_dt, fd_kernel])
+    sustained = None
+    if args.sustain_s > 0:
+        n_sus = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-4)) + 1)     # from the reduced dt: equal on all ranks
+        sus_dt, sus_kernel = timed_steps(lut_ptr, 0, n_sus)
+        sus_dt, sus_kernel = reduce_max([sus_dt, sus_kernel])
         sustained = {"seconds": sus_dt, "steps": n_sus, "ms_per_step": sus_dt / n_sus * 1e3,
                      "value": total_samples * n_sus / sus_dt, "kernel_ms": sus_kernel}
 
+    # ---- every rank's own numbers, gathered to rank 0 ----
+    mine = {"rank": rank, "rows": [r0, r1], "samples": my_samples, "kernel_ms": kernel_ms,
+            "first_draw_kernel_ms": fd_kernel, "lut_alloc": buf.placement, "xcd_mapping": eng.xcd_mapping(),
+            "xcd_weights_32nds": eng.xcd_weights()[0], "store_pattern_gbs": eng.store_pattern_gbs()}
+    per_rank = [mine]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_ms = float(k.item())
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
-    # ---- optional, OUTSIDE the timed step: reassemble the LUT on every rank with one RCCL all-gather ----
-    allgather_ms = None
-    if args.gather and world > 1:
+    # ---- OUTSIDE the timed step: reassemble the LUT on every rank with one in-place RCCL all-gather ----
+    allgather = None
+    if world > 1 and not args.no_gather:
+        full_t = buf.tensor((buf_rows, row_elems))
         torch.cuda.synchronize(); barrier()
         tg = time.perf_counter()
-        try:
-            full = all_gather_in_place(full_padded, rows)
-            torch.cuda.synchronize(); barrier()
-            allgather_ms = (time.perf_counter() - tg) * 1e3
-            del full
-        except torch.OutOfMemoryError:
-            # only a rehearsal can end here: N full LUTs on ONE GPU, gathered through gloo's staging copies
-            if not args.rehearse:
-                raise
-            print("bench.py: --rehearse --gather does not fit one GPU at this size; gather skipped", file=sys.stderr)
-            allgather_ms = None
-            barrier()                                       # the ranks that got through are waiting in theirs
+        all_gather_in_place(full_t, rows)
+        torch.cuda.synchronize(); barrier()
+        ag_s = reduce_max([time.perf_counter() - tg])[0]
+        received = (buf_rows - buf_rows // world) * row_elems * 8            # bytes that arrive in this GPU's HBM
+        allgather = {"what": "the whole LUT, in place: each rank's window is its send buffer (gort_amd.shard.all_gather_in_place)",
+                     "ms": ag_s * 1e3, "bytes_received_per_gpu": received, "gbs_received_per_gpu": received / ag_s / 1e9,
+                     "xgmi_bound_gbs": XGMI_BOUND_GBS, "frac_of_xgmi_bound": received / ag_s / 1e9 / XGMI_BOUND_GBS,
+                     "backend": "gloo (rehearsal on one GPU: not a measurement)" if args.rehearse else "nccl (RCCL)",
+                     "inside_timed_region": False}
 
-    # ---- parity spot check (outside the timed region): sampled rows vs the CPU oracle ----
-    parity = None
+    # ---- parity spot checks (outside the timed region) against the CPU oracle: rows of this rank's window and, after
+    #      the gather, rows that other ranks computed (rank 1's and the last rank's windows) ----
+    parity, parity_foreign = None, None
     if rank == 0 and not args.no_parity:
         try:
-            from oracle import oracle as O
-            O.AUTO_BUILD = False                  # the prebuilt checker or nothing: no compiler runs in a bench process
-            oc = O.make_canopy(lai=4.0)
-            ors, orl, otl = O.spectra(wl)
             rng = np.random.default_rng(5)
             idx = np.sort(rng.choice((r1 - r0) * grid.nphi, size=64, replace=False))
-            got = lut[torch.as_tensor(idx, device="cuda")].cpu().numpy()
-            row = r0 + idx // grid.nphi
-            ang = np.stack([(row % grid.nvza).astype(float), (idx % grid.nphi).astype(float),
-                            (row // grid.nvza).astype(float), np.zeros(idx.size)], 1)
-            ref, _, _ = O.rsurf_stream(oc, ang, ors, orl, otl, want_K=False)
-            nan_ok = bool(np.array_equal(np.isnan(got), np.isnan(ref)))
-            m = np.isfinite(ref)
-            parity = {"max_rel_err": float(np.max(np.abs(got[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1e-12))),
-                      "nan_pattern_equal": nan_ok, "samples_checked": int(ref.size), "tolerance": 1e-5}
+            got = np.stack([buf.to_numpy(nw, window[0] + int(i) * nw) for i in idx])
+            parity = compare(got, oracle_rows(wl, grid, r0 + idx // grid.nphi, idx % grid.nphi), "64 nodes of rank 0's window")
+            if allgather is not None:
+                picks = []
+                for other in sorted({1, world - 1}):
+                    o0, o1 = row_slab(other, world, rows)
+                    if o1 > o0:
+                        picks += [(int(r), int(l)) for r, l in zip(rng.integers(o0, o1, 12), rng.integers(0, grid.nphi, 12))]
+                gr, gl = np.array([p[0] for p in picks]), np.array([p[1] for p in picks])
+                got = np.stack([buf.to_numpy(nw, (int(r) * grid.nphi + int(l)) * nw) for r, l in picks])
+                parity_foreign = compare(got, oracle_rows(wl, grid, gr, gl), "%d nodes from the windows of ranks %s, read on rank 0 "
+                                         "after the all-gather" % (len(picks), sorted({1, world - 1})))
         except Exception as ex:
-            parity = {"error": str(ex)}
+            parity = {"error": repr(ex)}
 
+    out = None
     if rank == 0:
         value = total_samples * args.steps / dt
+        # the roofline of the dominant kernel is per launch: rank 0's launch and its HIP-event duration; the slowest
+        # rank's duration is quoted beside it
         per_launch_bytes = my_samples * BYTES_PER_SAMPLE
-        achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms and kernel_ms > 0 else None
+        achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
         # HBM bytes per launch of the dominant kernel come from PMC counters, which a live bench run cannot collect
         # (rocprofv3 --pmc needs passes of its own): `traffic` is a measurement of THIS code only when it is handed in
         # with --traffic-gb by the profiling script; otherwise it is null and the last committed PMC figure is quoted
@@ -356,38 +459,61 @@ def main():
             "config": {"workload": "full-hemisphere x full-spectrum LUT: %dx%dx%d angles x %d bands, -LAI 4.0"
                                    % (grid.nsza, grid.nvza, grid.nphi, nw),
                        "samples_per_step": total_samples, "output_gb_per_step": total_samples * 8 / 1e9,
-                       "sharding": "rows of (sun zenith, view zenith) split in %d contiguous slabs" % world},
+                       "sharding": "rows of (sun zenith, view zenith) in %d contiguous slabs (ceil partition); every rank "
+                                   "computes into its window of ONE gatherable LUT buffer (%d rows, %.1f GB per GPU)"
+                                   % (world, buf_rows, buf_rows * row_elems * 8 / 1e9),
+                       "allocation": "gort_lut_alloc, max_draws %d (C ABI allocator; first_draw = plain allocation, same steps)"
+                                     % args.lut_draws},
+            "first_draw": {"value": total_samples * args.steps / fd_dt, "ms_per_step": fd_dt / args.steps * 1e3,
+                           "kernel_ms_slowest_rank": fd_kernel_max,
+                           "what": "the same warm-up + steps on a plain first allocation (gort_lut_alloc with max_draws 1), max over ranks"},
             "roofline": {"bound": "hbm", "kernel": "expand_flat_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "xcd_mapping": eng.xcd_mapping(), "xcd_weights_32nds": eng.xcd_weights()[0],
-                         "bare_store_pattern_gbs_equal_xcd_shares": eng.store_pattern_gbs(),
-                         "slab_selection_rank0": slab_ms,
+                         "kernel_ms": kernel_ms, "kernel_ms_slowest_rank": kernel_ms_max,
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "launch": "rank 0's slab",
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_replayed": replayed},
+            "per_rank": per_rank,
             "sustained": sustained,
             "parity": parity,
+            "reference_build": reference_build_id(),
         }
-        if allgather_ms is not None:
-            out["allgather_ms"] = allgather_ms
+        if allgather is not None:
+            out["allgather"] = allgather
+            out["parity_after_allgather"] = parity_foreign
+        elif world > 1:
+            out["allgather"] = None
+    buf.free()
+
+    # ---- BASELINE config 5 as a block of its own (after the LUT buffer is gone: its chunks want the HBM) ----
+    if not args.no_config5:
+        c5 = config5_block(args, rank, world, dist, barrier)
+        if rank == 0:
+            out["config5"] = c5
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            # the LUT of the timed region is gone (config 5 needed the memory): the check against the reference's own rows
+            # recomputes the few rows it compares, with the same entry point
             # all host cores of the box's share (16 per GPU on this pool), one reference process per core
             ncores = max(1, min(len(os.sched_getaffinity(0)), 16))
             # (1) the SAME workload shape through the reference's own gortt_rsurf (grid nodes x 2101 bands, no text)
             same = cpu_baseline_grid(wl, ncores, budget_s=12.0)
             if same is not None:
-                # the reference's own rows of 24 of its nodes, all 2101 bands, against the LUT this run wrote
+                # the reference's own rows of 24 of its nodes, all 2101 bands, against what expand_flat_kernel writes
                 cn, cr = np.array(same.pop("_check_nodes")), same.pop("_check_rows")
                 inside = cn[:, 0] < grid.nsza                 # reduced grids (--nsza, tests) hold only the first sun zeniths
                 cn, cr = cn[inside], cr[inside]
             if same is not None and len(cn):
-                at = (cn[:, 0] * grid.nvza + cn[:, 1]) * grid.nphi + cn[:, 2]
-                mine = lut[torch.as_tensor(at, device="cuda")].cpu().numpy()
-                fin = np.isfinite(cr)
-                out["parity_reference"] = {
-                    "max_rel_err": float(np.max(np.abs(mine[fin] - cr[fin]) / np.maximum(np.abs(cr[fin]), 1e-12))),
-                    "nan_pattern_equal": bool(np.array_equal(np.isnan(mine), np.isnan(cr))),
-                    "samples_checked": int(cr.size), "tolerance": 1e-5,
-                    "against": "the reference's gortt_rsurf itself (oracle/_ref/libgortt_ref.so), %d nodes x %d bands" % cr.shape}
+                mine_rows = []
+                one = eng.lut_alloc(row_elems, max_draws=1)
+                for isza, ivza, iphi in cn:
+                    row = int(isza) * grid.nvza + int(ivza)
+                    eng.rsurf_grid_dev(grid, row, row + 1, one)
+                    eng.synchronize()
+                    mine_rows.append(one.to_numpy(nw, int(iphi) * nw))
+                one.free()
+                out["parity_reference"] = dict(compare(np.stack(mine_rows), cr, "%d nodes x %d bands" % cr.shape),
+                                               against="the reference's gortt_rsurf itself (oracle/_ref/libgortt_ref.so)")
             # (2) the reference as a user runs it: the CLI with a -P LUT, random lines x 180 bands, text to /dev/null
             cli = cpu_baseline(wl, budget_s=10.0, procs=ncores)
             out["cpu_baseline"] = same if same is not None else cli
@@ -395,22 +521,26 @@ def main():
                 out["cpu_baseline_cli"] = cli
             # (3) our own hoisted scalar-C restatement (no text I/O), one core: the strongest per-core CPU number we have
             out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
-            out["gpu_over_cpu"] = {"vs_cpu_baseline_same_shape_all_cores": value / out["cpu_baseline"]["value"],
-                                   "vs_port_one_core": value / out["cpu_baseline_port"]["value"]}
+            out["gpu_over_cpu"] = {"vs_cpu_baseline_same_shape_all_cores": out["value"] / out["cpu_baseline"]["value"],
+                                   "vs_port_one_core": out["value"] / out["cpu_baseline_port"]["value"]}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
         dist.destroy_process_group()
     # a headline number without its parity check is not a result: fail the run
     if rank == 0 and not args.no_parity:
-        bad = parity is None or "error" in parity or not parity["nan_pattern_equal"] or not parity["max_rel_err"] <= parity["tolerance"]
-        pr = out.get("parity_reference")
-        if pr is not None and (not pr["nan_pattern_equal"] or not pr["max_rel_err"] <= pr["tolerance"]):
-            bad = True
-            parity = pr
-        if bad:
-            print("bench.py: parity check failed or missing: %r" % (parity,), file=sys.stderr)
-            sys.exit(3)
+        checks = [("parity", parity)]
+        if world > 1 and not args.no_gather:
+            checks.append(("parity_after_allgather", parity_foreign))
+        if "parity_reference" in out:
+            checks.append(("parity_reference", out["parity_reference"]))
+        if out.get("config5") and isinstance(out["config5"].get("parity"), dict):
+            for k, v in out["config5"]["parity"].items():
+                checks.append(("config5." + k, v) if isinstance(v, dict) else ("config5.parity", out["config5"]["parity"]))
+        for name, pr in checks:
+            if pr is None or "error" in pr or not pr["nan_pattern_equal"] or not pr["max_rel_err"] <= pr["tolerance"]:
+                print("bench.py: parity check %s failed or missing: %r" % (name, pr), file=sys.stderr)
+                sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -70,6 +70,7 @@ DECLARED_SYMBOLS = [
     "gort_canopy_newstyle", "gort_canopy_set_lai", "gort_canopy_init", "gort_price_soil",
     "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_format_f6", "gort_format_f6_row", "gort_lut_format", "gort_lut_read",
     "gort_device_count", "gort_dev_malloc", "gort_dev_free", "gort_memcpy_h2d", "gort_memcpy_d2h",
+    "gort_lut_alloc", "gort_lut_free",
     "gort_gap_probabilities", "gort_gap_probabilities_dev", "gort_gap_cache_stats", "gort_gap_cache_clear",
     "gort_canopy_check_geometry",
     "gort_canopy_key", "gort_lut_cache_store", "gort_lut_cache_load",
@@ -115,6 +116,9 @@ def lib():
         L.gort_dev_malloc.restype = C.c_void_p
         L.gort_dev_malloc.argtypes = [C.c_size_t]
         L.gort_dev_free.argtypes = [C.c_void_p]
+        L.gort_lut_alloc.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
+        L.gort_lut_free.argtypes = [C.c_void_p]
+        L.gort_lut_free.restype = None
         L.gort_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gort_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gort_engine_create.argtypes = [C.POINTER(C.c_void_p)]
@@ -190,8 +194,10 @@ def _ptr(a):
         return None
     if hasattr(a, "data_ptr"):
         return C.c_void_p(a.data_ptr())
-    if isinstance(a, DeviceBuffer):
+    if isinstance(a, (DeviceBuffer, LutBuffer)):
         return C.c_void_p(a.ptr)
+    if isinstance(a, C.c_void_p):
+        return a
     return a.ctypes.data_as(C.c_void_p)
 
 
@@ -215,6 +221,57 @@ class DeviceBuffer:
         if self.ptr:
             lib().gort_dev_free(C.c_void_p(self.ptr))
             self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class LutPlacement(C.Structure):
+    _fields_ = [("draws", C.c_int32), ("picked", C.c_int32), ("probe_gbs", D * 8), ("accept_gbs", D)]
+
+
+class LutBuffer:
+    """Device memory from gort_lut_alloc: float64, `doubles` elements, placement measured by the engine (include/gort_amd.h).
+    Speaks __cuda_array_interface__, so `torch.as_tensor(buf, device="cuda")` (or `.tensor()`) gives a zero-copy view for
+    torch.distributed collectives; the view keeps the buffer alive."""
+
+    def __init__(self, ptr, nbytes, placement, window=None):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+        self.shape = (self.nbytes // 8,)
+        self.placement = {"draws": int(placement.draws), "picked": int(placement.picked),
+                          "probe_gbs": [float(placement.probe_gbs[i]) for i in range(placement.draws)],
+                          "accept_gbs": float(placement.accept_gbs)}
+        self.window = window                 # (offset_doubles, doubles) this process writes, or None = everything
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": "<f8", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def tensor(self, shape=None):
+        import torch
+        t = torch.as_tensor(self, device="cuda")
+        if t.data_ptr() != self.ptr:
+            raise GortError(EINVAL, "LutBuffer.tensor(): torch copied the buffer instead of viewing it")
+        t._gort_owner = self                 # the view must not outlive the allocation
+        return t.view(*shape) if shape else t
+
+    def at(self, offset_doubles):
+        """void* `offset_doubles` into the buffer (for the *_dev entry points)."""
+        return C.c_void_p(self.ptr + 8 * int(offset_doubles))
+
+    def to_numpy(self, count=None, offset=0):
+        count = (self.nbytes // 8 - offset) if count is None else count
+        out = np.empty(count, dtype=np.float64)
+        _check(lib().gort_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + 8 * offset), 8 * count))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().gort_lut_free(C.c_void_p(self.ptr))
+            self.ptr = 0
 
     def __del__(self):
         try:
@@ -499,6 +556,15 @@ class Engine:
 
     def last_stream_ms(self):
         return lib().gort_engine_last_stream_ms(self.h)
+
+    def lut_alloc(self, doubles, window=None, max_draws=3):
+        """gort_lut_alloc: `doubles` float64 of HBM for a LUT; window = (offset, count) in doubles of the part this
+        process writes (a rank's slab of a gatherable LUT), default everything.  Returns a LutBuffer."""
+        off, cnt = window if window is not None else (0, 0)
+        out, info = C.c_void_p(), LutPlacement()
+        _check(lib().gort_lut_alloc(self.h, C.c_size_t(8 * int(doubles)), C.c_size_t(8 * int(off)), C.c_size_t(8 * int(cnt)),
+                                    int(max_draws), C.byref(out), C.byref(info)))
+        return LutBuffer(out.value, 8 * int(doubles), info, window)
 
     def rsurf_grid_dev(self, grid, row_begin, row_end, lut_t):
         _check(lib().gort_rsurf_grid_dev(self.h, C.byref(grid), row_begin, row_end, _ptr(lut_t)))

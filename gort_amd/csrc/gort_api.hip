@@ -69,6 +69,8 @@ struct gort_engine {
     size_t ev_used = 0;
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
+    DevBuf edup;                         // sun-direction table of the energy path (gort_energy.hip)
+    bool energy_dedup = true;            // GORT_ENERGY_DEDUP=0: every line evaluated (tests compare the two)
     int wide_form_pref = 0;              // wide streams: 0 automatic, 1 flat panels, 2 LDS-resident (gort_amd_tuning.h)
     int stream_form = 0;                 // form of the last stream call: 0 narrow, 1 flat panels, 2 LDS-resident
     hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call
@@ -88,6 +90,7 @@ struct gort_engine {
     bool xcd_weights_fixed = false;      // set by hand: never recalibrated
     int xcd_cal_class = -1;              // log2 size class of the slab the weights were measured on
     double xcd_pattern_gbs = 0.0;        // rate of the bare store pattern during the calibration pass
+    double best_pattern_gbs[64] = {0};   // per size class (log2 of the doubles probed): the best rate gort_lut_alloc has seen
     // Small LUT slabs (the per-rank slabs of a multi-GPU run) are pipelined over two streams: geometry and sun
     // table of call i+1 run on `aux` into the other half of a double buffer while the expansion of call i is
     // still writing.  Only while both halves stay in the 256 MB Infinity Cache (PIPELINE_MAX_BYTES per half):
@@ -306,6 +309,7 @@ extern "C" int gort_engine_create(gort_engine **out)
         return fail(GORT_ENODEVICE, "gort_engine_create: cannot create streams/events");
     }
     if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
+    if (const char *v = getenv("GORT_ENERGY_DEDUP")) e->energy_dedup = atoi(v) != 0;
     if (const char *v = getenv("GORT_STREAM_FORM")) { const int m = atoi(v); e->wide_form_pref = m < 0 ? 0 : (m > 2 ? 2 : m); }
     if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
     if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
@@ -332,7 +336,7 @@ extern "C" void gort_engine_destroy(gort_engine *e)
         if (ev) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
-                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots})
+                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots, &e->edup})
         b->release();
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_stream) if (ev) (void)hipEventDestroy(ev);
@@ -852,6 +856,13 @@ extern "C" int gort_rsurf_members_stream(gort_engine *e, const double *angles, l
 
 // ------------------------------------------------------------------ LUT (grid)
 
+static int size_class(long doubles)
+{
+    int cls = 0;
+    for (long v = doubles; v > 1; v >>= 1) ++cls;
+    return cls;
+}
+
 // rows are GLOBAL: member * (nsza*nvza) + isza * nvza + ivza
 static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long row_end, double *lut_dev)
 {
@@ -908,8 +919,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     // size class (power of two of the slab's size), since how unevenly the XCDs write depends on how far apart their
     // windows lie; weights set by hand (GORT_XCD_WEIGHTS, gort_engine_set_xcd_weights) are left alone
     if (!xcd_slots && !e->xcd_weights_fixed && nA * (long)nw >= (1L << 27)) {
-        int cls = 0;
-        for (long v = nA * (long)nw; v > 1; v >>= 1) ++cls;
+        const int cls = size_class(nA * (long)nw);
         if (!e->xcd_calibrated || cls != e->xcd_cal_class) {
             if ((rc = calibrate_xcd_weights(e->stream, lut_dev, nA * (long)nw, e->xcd_weights, &e->xcd_pattern_gbs))) return rc;
             e->xcd_calibrated = true;
@@ -938,6 +948,81 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         e->expand_recorded[half] = true;
     }
     return rc;
+}
+
+// ---- LUT buffers with a measured placement (include/gort_amd.h) ----
+
+extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, size_t win_bytes, int max_draws,
+                              void **out_dev, gort_lut_placement *info)
+{
+    if (out_dev) *out_dev = nullptr;
+    if (info) std::memset(info, 0, sizeof *info);
+    if (!e || !out_dev || bytes == 0 || win_offset % sizeof(double) || win_bytes % sizeof(double) || win_offset > bytes ||
+        win_bytes > bytes - win_offset)
+        return fail(GORT_EINVAL, "gort_lut_alloc: bad argument");
+    if (win_bytes == 0) { win_offset = 0; win_bytes = bytes / sizeof(double) * sizeof(double); }
+    if (max_draws < 1) max_draws = 1;
+    if (max_draws > GORT_LUT_MAX_DRAWS) max_draws = GORT_LUT_MAX_DRAWS;
+    const long doubles = (long)(win_bytes / sizeof(double));
+    // windows below 1 GiB have no stable rate to select on (and the pattern probe needs 64 panels): first draw
+    int *slots = nullptr;
+    int rc = xcd_slots_for_launch(e, &slots);          // also probes the dispatch order once
+    if (rc) return rc;
+    const bool select = max_draws > 1 && doubles >= (1L << 27) && !slots;
+    const int cls = size_class(doubles);
+    const double accept = select ? 0.985 * e->best_pattern_gbs[cls] : 0.0;
+    void *cand[GORT_LUT_MAX_DRAWS] = {nullptr};
+    int weights[GORT_LUT_MAX_DRAWS][8];
+    double gbs[GORT_LUT_MAX_DRAWS] = {0.0};
+    int n = 0, best = 0;
+    for (; n < (select ? max_draws : 1); ++n) {
+        if (hipMalloc(&cand[n], bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            cand[n] = nullptr;
+            if (n == 0) return fail(GORT_ENOMEM, "gort_lut_alloc: cannot allocate %zu bytes", bytes);
+            break;                                      // make do with the draws we have
+        }
+        if (!select) continue;
+        double *win = reinterpret_cast<double *>(static_cast<char *>(cand[n]) + win_offset);
+        // three passes of the LUT kernel's bare store pattern over the window (the first one touches the pages)
+        for (int pass = 0; pass < 3 && rc == GORT_OK; ++pass) {
+            double g = 0.0;
+            int w[8];
+            rc = calibrate_xcd_weights(e->stream, win, doubles, w, &g);
+            if (pass > 0 && g > gbs[n]) { gbs[n] = g; std::memcpy(weights[n], w, sizeof w); }
+        }
+        if (rc) break;
+        if (gbs[n] > gbs[best]) best = n;
+        if (accept > 0.0 && gbs[n] >= accept) { ++n; break; }      // as good as anything this engine has seen
+    }
+    if (rc) {
+        for (int i = 0; i < GORT_LUT_MAX_DRAWS; ++i) if (cand[i]) (void)hipFree(cand[i]);
+        return rc;
+    }
+    for (int i = 0; i < n; ++i)
+        if (i != best && cand[i]) (void)hipFree(cand[i]);
+    if (select) {
+        if (gbs[best] > e->best_pattern_gbs[cls]) e->best_pattern_gbs[cls] = gbs[best];
+        if (!e->xcd_weights_fixed && gbs[best] > 0.0) {        // the XCD duty weights of this size class come with the probe
+            std::memcpy(e->xcd_weights, weights[best], sizeof e->xcd_weights);
+            e->xcd_calibrated = true;
+            e->xcd_cal_class = cls;
+            e->xcd_pattern_gbs = gbs[best];
+        }
+    }
+    if (info) {
+        info->draws = n;
+        info->picked = best;
+        info->accept_gbs = accept;
+        for (int i = 0; i < n; ++i) info->probe_gbs[i] = gbs[i];
+    }
+    *out_dev = cand[best];
+    return GORT_OK;
+}
+
+extern "C" void gort_lut_free(void *lut_dev)
+{
+    if (lut_dev) (void)hipFree(lut_dev);
 }
 
 static int check_grid(const gort_grid *g, const char *who)
@@ -1020,6 +1105,18 @@ static int ensure_nodes(gort_engine *e)
     return GORT_OK;
 }
 
+// scratch of the sun-direction table for nA lines (nullptr: few lines, or switched off)
+static int energy_workspace(gort_engine *e, long nA, void **ws)
+{
+    *ws = nullptr;
+    const size_t bytes = e->energy_dedup ? energy_dedup_workspace(nA) : 0;
+    if (!bytes) return GORT_OK;
+    const int rc = e->edup.reserve(bytes);
+    if (rc) return rc;
+    *ws = e->edup.p;
+    return GORT_OK;
+}
+
 extern "C" int gort_energy_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *energy_dev)
 {
     int rc = require_ready(e, "gort_energy_stream_dev");
@@ -1027,8 +1124,10 @@ extern "C" int gort_energy_stream_dev(gort_engine *e, const double *angles_dev, 
     if (nA < 0 || (nA > 0 && (!angles_dev || !energy_dev))) return fail(GORT_EINVAL, "gort_energy_stream_dev: bad argument");
     if (nA == 0) return GORT_OK;
     if ((rc = ensure_nodes(e))) return rc;
+    void *ws = nullptr;
+    if ((rc = energy_workspace(e, nA, &ws))) return rc;
     return launch_energy(e->canopy.as<gort_canopy>(), 1, e->L.as<double>(), e->nw, angles_dev, nA,
-                         e->nodes.as<double>(), energy_dev, e->stream);
+                         e->nodes.as<double>(), energy_dev, ws, e->stream);
 }
 
 extern "C" int gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
@@ -1043,9 +1142,11 @@ extern "C" int gort_energy_members_dev(gort_engine *e, const double *angles_dev,
         return fail(GORT_EINVAL, "gort_energy_members_dev: bad argument");
     if (nA == 0 || member_begin == member_end) return GORT_OK;
     if ((rc = ensure_nodes(e))) return rc;
+    void *ws = nullptr;
+    if ((rc = energy_workspace(e, nA, &ws))) return rc;
     return launch_energy(e->canopy.as<gort_canopy>() + member_begin, member_end - member_begin,
                          e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw, e->nw, angles_dev, nA,
-                         e->nodes.as<double>(), energy_dev, e->stream);
+                         e->nodes.as<double>(), energy_dev, ws, e->stream);
 }
 
 extern "C" int gort_energy_stream(gort_engine *e, const double *angles, long nA, double *energy)

@@ -2,6 +2,8 @@
 // (replaces gortt_energy / gortt_albedo, gortt_albedo.c:7-138).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "gort_geometry.h"
 
 namespace gort {
@@ -13,6 +15,7 @@ namespace {
 // (wavefront shuffle + LDS reduction), then every band costs 5 FMAs:
 //   albedo(band) = sum_k [sum_nodes w_node a_k(node)] b_k(sun zenith, band).
 constexpr int ENERGY_THREADS = 512;
+constexpr long ENERGY_DEDUP_MIN_LINES = 128;      // below: one workgroup per line, no table (BASELINE config 4 has 91 lines, all distinct)
 
 __device__ inline double wave_sum(double v)
 {
@@ -21,13 +24,74 @@ __device__ inline double wave_sum(double v)
     return v;
 }
 
+// ---- lines that share a sun direction share their row ----
+// The hemispherical integral depends on the line's SUN direction only: the view angles are the quadrature nodes
+// (gortt_albedo.c:62-138 overwrites g->vza / g->vaa; what it keeps of the line is g->sza and g->saa - the sun azimuth
+// too, because 32 Gauss-Legendre nodes in azimuth do not integrate the hot-spot cusp exactly and the result moves with
+// saa in the 4th digit).  A stream of a million lines with 91 sun zeniths asked for 11 000 x the necessary geometry
+// (512 evaluations per line).  So: key = the bits of the normalised (sza, saa) - the very values the kernel uses -,
+// a hash table on the device names ONE owner line per key (the lowest line index), energy_kernel evaluates the owners
+// only, and a store-bound copy kernel broadcasts their rows.  Bitwise equal to the per-line evaluation by construction.
+struct SunKey { unsigned long long z, a; };
+
+__device__ inline SunKey sun_key(const double *__restrict__ angles, long line)
+{
+    double vza, sza, saa, raa;
+    normalise_angles(angles[4 * line], angles[4 * line + 1], angles[4 * line + 2], angles[4 * line + 3], vza, sza, saa, raa);
+    SunKey k;
+    k.z = (unsigned long long)__double_as_longlong(sza);
+    k.a = (unsigned long long)__double_as_longlong(saa);
+    return k;
+}
+
+__device__ inline unsigned long long sun_hash(SunKey k)
+{
+    unsigned long long h = k.z * 0x9E3779B97F4A7C15ull ^ (k.a + 0xD1B54A32D192ED03ull + (k.z << 6) + (k.z >> 2));
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h ? h : 1ull;                                 // 0 marks an empty slot
+}
+
+// one thread per line: claim / find the slot of the line's key hash, lowest line index becomes the slot's owner
+__global__ __launch_bounds__(256) void energy_key_kernel(const double *__restrict__ angles, long nA,
+                                                          unsigned long long *__restrict__ tab, unsigned *__restrict__ owner,
+                                                          unsigned mask, unsigned *__restrict__ slot_of)
+{
+    const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= nA) return;
+    const unsigned long long h = sun_hash(sun_key(angles, line));
+    unsigned idx = (unsigned)h & mask;
+    for (unsigned tries = 0; tries <= mask; ++tries) {       // the table has >= 2 nA slots: ends long before
+        const unsigned long long old = atomicCAS(&tab[idx], 0ull, h);
+        if (old == 0ull || old == h) break;
+        idx = (idx + 1) & mask;
+    }
+    atomicMin(&owner[idx], (unsigned)line);
+    slot_of[line] = idx;
+}
+
+// the line whose row `line` shares: the owner of its slot if that one has the same key (two keys with one hash share a
+// slot; the one that is not the owner's stands for itself), else the line itself
+__device__ inline long energy_rep(const double *__restrict__ angles, long line, const unsigned *__restrict__ owner,
+                                  const unsigned *__restrict__ slot_of)
+{
+    const long o = owner[slot_of[line]];
+    if (o == line) return line;
+    const SunKey a = sun_key(angles, line), b = sun_key(angles, o);
+    return (a.z == b.z && a.a == b.a) ? o : line;
+}
+
 // blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by the members;
-// energy[member][nA][nw][3]
+// energy[member][nA][nw][3].  DEDUP: workgroups stride over the lines and evaluate only those that stand for themselves.
+template <bool DEDUP>
 __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopies,
                                                                  const double *__restrict__ Lall, int nw,
-                                                                 const double *__restrict__ angles,
+                                                                 const double *__restrict__ angles, long nA,
                                                                  const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
-                                                                 double *__restrict__ energy_all)
+                                                                 double *__restrict__ energy_all,
+                                                                 const unsigned *__restrict__ owner,
+                                                                 const unsigned *__restrict__ slot_of)
 {
     __shared__ double s_part[5][ENERGY_THREADS / 64];
     __shared__ double s_abar[5];
@@ -35,9 +99,11 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
     const long member = blockIdx.y;
     const gort_canopy &c = canopies[member];
     const double *__restrict__ L = Lall + member * L_NSLOT * nw;
-    double *__restrict__ energy = energy_all + member * (long)gridDim.x * nw * 3;
-    const long a = blockIdx.x;
+    double *__restrict__ energy = energy_all + member * nA * nw * 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (long a = blockIdx.x; a < nA; a += gridDim.x) {
+    if (DEDUP && energy_rep(angles, a, owner, slot_of) != a) continue;       // uniform: the whole workgroup
+    if (DEDUP) __syncthreads();                                              // the shared arrays of the previous line are done with
 
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
@@ -86,18 +152,103 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
         o[1] = 1. - albedo - Fd2 + Fu2;
         o[2] = Fd2 - Fu2;
     }
+  }
+}
+
+// rows of the lines that share another line's sun direction: energy[line] = energy[rep(line)].  The output is walked as
+// ONE flat array in 1-KiB chunks aligned in absolute address (rows of 3 nw doubles start on 8-byte boundaries only, and
+// HBM wants whole lines per wave store: DESIGN.md 5.1 step 2); the few source rows stay in L2.
+__global__ __launch_bounds__(256) void energy_broadcast_kernel(const double *__restrict__ angles, long nA, int row,
+                                                                double *__restrict__ energy_all,
+                                                                const unsigned *__restrict__ owner,
+                                                                const unsigned *__restrict__ slot_of, int shift,
+                                                                long chunks)
+{
+    double *__restrict__ energy = energy_all + (long)blockIdx.y * nA * row;
+    const long n_total = nA * (long)row;
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long ch = wave0; ch < chunks; ch += nwaves) {
+        const long e0 = ch * CHUNK - shift + EPL * lane;             // first of this lane's two elements
+        double v[EPL];
+        bool put[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const long e = e0 + j;
+            put[j] = false;
+            v[j] = 0.0;
+            if (e >= 0 && e < n_total) {
+                const long line = e / row;
+                const long rep = energy_rep(angles, line, owner, slot_of);
+                if (rep != line) {
+                    v[j] = energy[rep * row + (e - line * row)];
+                    put[j] = true;
+                }
+            }
+        }
+        if (put[0] && put[1]) {
+            dbl2 x;
+            x.x = v[0];
+            x.y = v[1];
+            __builtin_nontemporal_store(x, reinterpret_cast<dbl2 *>(energy + e0));
+        } else {
+            if (put[0]) energy[e0] = v[0];
+            if (put[1]) energy[e0 + 1] = v[1];
+        }
+    }
 }
 
 }  // namespace
 
+// dedup workspace (bytes) for nA lines: hash table [cap] u64 + owner [cap] u32 + slot_of [nA] u32, cap = 2^k >= 2 nA
+size_t energy_dedup_workspace(long nA)
+{
+    if (nA < ENERGY_DEDUP_MIN_LINES) return 0;
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)nA) cap <<= 1;
+    return cap * (sizeof(unsigned long long) + sizeof(unsigned)) + (size_t)nA * sizeof(unsigned);
+}
+
+// ws_dev: energy_dedup_workspace(nA) bytes, or nullptr = every line evaluated (few lines; tests compare the two)
 int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
-                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *stream)
+                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *ws_dev, void *stream)
 {
     if (nA <= 0 || nw <= 0 || n_members <= 0) return GORT_OK;
     if (n_members > 65535) return fail(GORT_EINVAL, "energy: %d members in one launch (max 65535)", n_members);
-    hipLaunchKernelGGL(energy_kernel, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0,
-                       (hipStream_t)stream, canopies_dev, L_dev, nw, angles_dev, nodes_dev, energy_dev);
-    return check_launch("energy_kernel");
+    hipStream_t s = (hipStream_t)stream;
+    if (!ws_dev || nA < ENERGY_DEDUP_MIN_LINES) {
+        if (nA >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld lines in one launch", nA);
+        hipLaunchKernelGGL(energy_kernel<false>, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
+                           canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)nullptr,
+                           (const unsigned *)nullptr);
+        return check_launch("energy_kernel");
+    }
+    if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
+    size_t cap = 1024;
+    while (cap < 2 * (size_t)nA) cap <<= 1;
+    unsigned long long *tab = static_cast<unsigned long long *>(ws_dev);
+    unsigned *owner = reinterpret_cast<unsigned *>(tab + cap);
+    unsigned *slot_of = owner + cap;
+    if (hipMemsetAsync(tab, 0, cap * sizeof(unsigned long long), s) != hipSuccess ||
+        hipMemsetAsync(owner, 0xff, cap * sizeof(unsigned), s) != hipSuccess)
+        return fail(GORT_ENODEVICE, "energy: cannot clear the sun-direction table");
+    hipLaunchKernelGGL(energy_key_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, angles_dev, nA, tab, owner,
+                       (unsigned)(cap - 1), slot_of);
+    int rc = check_launch("energy_key_kernel");
+    if (rc) return rc;
+    const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
+    hipLaunchKernelGGL(energy_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
+                       angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)owner, (const unsigned *)slot_of);
+    if ((rc = check_launch("energy_kernel"))) return rc;
+    const int row = 3 * nw;
+    const int shift = (int)((reinterpret_cast<uintptr_t>(energy_dev) / sizeof(double)) % CHUNK);
+    // member m's slab starts nA*row doubles further: the same shift only if that is a multiple of CHUNK; the kernel's
+    // alignment is a matter of speed, not of correctness, and the member-batched call is the small one
+    const long chunks = (nA * (long)row + shift + CHUNK - 1) / CHUNK;
+    const long want = (chunks + 3) / 4;
+    hipLaunchKernelGGL(energy_broadcast_kernel, dim3((unsigned)(want < 16384 ? want : 16384), (unsigned)n_members), dim3(256), 0, s,
+                       angles_dev, nA, row, energy_dev, (const unsigned *)owner, (const unsigned *)slot_of, shift, chunks);
+    return check_launch("energy_broadcast_kernel");
 }
 
 }  // namespace gort

@@ -132,9 +132,12 @@ long expand_grid_tail_pad_records(int nw, long n_total);
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,
                        long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, const int *xcd_weights,
                        void *stream);
-// energy_dev[n_members][nA][nw][3]; members are canopies_dev[0..n) with L_dev[m][L_NSLOT][nw]
+// energy_dev[n_members][nA][nw][3]; members are canopies_dev[0..n) with L_dev[m][L_NSLOT][nw].
+// ws_dev: energy_dedup_workspace(nA) bytes of device scratch (0 for few lines) - lines with the same normalised sun
+// direction are evaluated once and their row is copied; nullptr = every line evaluated (same bits)
+size_t energy_dedup_workspace(long nA);
 int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
-                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *stream);
+                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *ws_dev, void *stream);
 
 }  // namespace gort
 #endif

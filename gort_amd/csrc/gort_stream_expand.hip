@@ -252,10 +252,50 @@ constexpr int LDS_TAB_SLOTS = 9;
 constexpr int LDS_REC = 14;              // doubles per staged record: 13 LineTerms + 1 pad (rows stay 16-B aligned)
 constexpr size_t LDS_MAX_BYTES = 160u * 1024u;
 
-// The K steps of a wave's task.  The line terms come out of the LDS ring: in waves whose chunk lies inside one line a
+// One step of a wave's task.  The line terms come out of the LDS ring: in waves whose chunk lies inside one line a
 // broadcast of that line's record; in the ~6 % of waves whose band index wraps inside the chunk each element reads the
 // record of ITS line (a per-lane LDS address: two distinct rows, no bank conflict) - no second sample, no select.
-template <bool NT, bool WRAP>
+// MODE (experiments only, GORT_STREAM_LDS_MODE): 0 = the kernel; 1 = arithmetic without stores; 2 = stores of a trivial value;
+// 3 = no workgroup barrier between tasks (races on the record ring: wrong results, timing only)
+template <bool NT, bool WRAP, int MODE>
+__device__ __forceinline__ void lds_step(const StreamBand (&t)[EPL], const bool (&second)[EPL], const double *ring, bool front,
+                                         bool back, int first_off, int last_off, double *__restrict__ o, int lane)
+{
+    double v[EPL];
+    if (MODE == 2) {
+        v[0] = ring[0] + t[0].B;
+        v[1] = ring[0] + t[1].B;
+    } else if (!WRAP) {
+        double r[LINE_NTERMS];
+#pragma unroll
+        for (int q = 0; q < LINE_NTERMS; ++q) r[q] = ring[q];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            double pdf, tpdf;
+            sun_pair(t[j], r[9], r[10], r[11], r[12], pdf, tpdf);
+            v[j] = stream_sample(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], t[j], pdf, tpdf);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const double *rj = ring + (second[j] ? LDS_REC : 0);
+            double r[LINE_NTERMS];
+#pragma unroll
+            for (int q = 0; q < LINE_NTERMS; ++q) r[q] = rj[q];
+            double pdf, tpdf;
+            sun_pair(t[j], r[9], r[10], r[11], r[12], pdf, tpdf);
+            v[j] = stream_sample(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], t[j], pdf, tpdf);
+        }
+    }
+    if (MODE == 1) {
+        if (v[0] == -12345.678 && v[1] == 9.87e300) o[0] = v[0];      // never true: keeps the arithmetic alive
+    } else {
+        store_chunk_pair<NT>(v, front, back, first_off, last_off, o, lane);
+    }
+}
+
+// the steps of a task at the edges of the output, or cut short by its end: any count, edge handling per step
+template <bool NT, bool WRAP, int MODE>
 __device__ __forceinline__ void lds_task_steps(const StreamBand (&t)[EPL], const bool (&second)[EPL], int first_off,
                                                int last_step, int last_off, long step, int k_wave,
                                                const double *ring, int ring_step, double *__restrict__ out_w, int lane)
@@ -263,36 +303,31 @@ __device__ __forceinline__ void lds_task_steps(const StreamBand (&t)[EPL], const
     double *o = out_w + EPL * lane;
 #pragma unroll 1
     for (int kk = 0; kk < k_wave; ++kk) {
-        double v[EPL];
-        if (!WRAP) {
-            double r[LINE_NTERMS];
-#pragma unroll
-            for (int q = 0; q < LINE_NTERMS; ++q) r[q] = ring[q];
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                double pdf, tpdf;
-                sun_pair(t[j], r[9], r[10], r[11], r[12], pdf, tpdf);
-                v[j] = stream_sample(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], t[j], pdf, tpdf);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                const double *rj = ring + (second[j] ? LDS_REC : 0);
-                double r[LINE_NTERMS];
-#pragma unroll
-                for (int q = 0; q < LINE_NTERMS; ++q) r[q] = rj[q];
-                double pdf, tpdf;
-                sun_pair(t[j], r[9], r[10], r[11], r[12], pdf, tpdf);
-                v[j] = stream_sample(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], t[j], pdf, tpdf);
-            }
-        }
+        lds_step<NT, WRAP, MODE>(t, second, ring, kk == 0 && first_off > 0, kk == last_step, first_off, last_off, o, lane);
         ring += ring_step;
-        store_chunk_pair<NT>(v, kk == 0 && first_off > 0, kk == last_step, first_off, last_off, o, lane);
         o += step;
     }
 }
 
-template <bool NT>
+// the steps of an interior task: exactly KFULL steps of exactly one vector store each, unrolled - straight-line code in
+// which the compiler can COUNT the stores.  That matters for more than loop overhead: the staged records of the next
+// task are a vector load issued in front of these stores, loads and stores share one in-order counter on gfx9, and
+// behind a loop of unknown length the compiler can only wait for `vmcnt(0)` before the value is used - i.e. for
+// every store of the task to be acknowledged by memory (~2 us, once per task and wave); here it waits for vmcnt(KFULL).
+template <bool NT, bool WRAP, int MODE, int KFULL>
+__device__ __forceinline__ void lds_task_full(const StreamBand (&t)[EPL], const bool (&second)[EPL], long step, const double *ring,
+                                              int ring_step, double *__restrict__ out_w, int lane)
+{
+    double *o = out_w + EPL * lane;
+#pragma unroll
+    for (int kk = 0; kk < KFULL; ++kk) {
+        lds_step<NT, WRAP, MODE>(t, second, ring, false, false, 0, 0, o, lane);
+        ring += ring_step;
+        o += step;
+    }
+}
+
+template <bool NT, int MODE, int KFULL>
 __global__ __launch_bounds__(LDS_THREADS) void expand_stream_lds_kernel(
     const gort_canopy *__restrict__ canopy, const double *__restrict__ L, int nw, const double *__restrict__ coef, long nA,
     long n_total, int shift, long stride_chunks, int da, int K, int npl, int groups, long n_tasks,
@@ -316,7 +351,7 @@ __global__ __launch_bounds__(LDS_THREADS) void expand_stream_lds_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tab_doubles = (LDS_TAB_SLOTS * nw + 1) & ~1;
     double *s_tab = s_mem;                              // [9][nw]
-    double *s_ring = s_mem + tab_doubles;               // [2][K][npl][LDS_REC]
+    double *s_ring = s_mem + tab_doubles;               // [2][K][npl][LDS_REC] + a dump row of 64
     const int ring_doubles = K * npl * LDS_REC;
     for (int i = tid; i < 8 * nw; i += LDS_THREADS) s_tab[i] = L[i];                       // L slots 0..7 = gam .. mgk
     for (int i = tid; i < nw; i += LDS_THREADS) s_tab[8 * nw + i] = L[L_B * nw + i];
@@ -328,7 +363,10 @@ __global__ __launch_bounds__(LDS_THREADS) void expand_stream_lds_kernel(
     const long last_chunk = last / CHUNK;
     const int last_off = (int)(last % CHUNK);
 
-    // this thread's share of a task's records: double q of the record of line a_min + k da + p
+    // this thread's share of a task's records: double q of the record of line a_min + k da + p.  EVERY thread loads
+    // and parks a value for every task (threads beyond the K npl 13 needed ones re-read element 0 and park it in a
+    // dump row behind the ring; a workgroup without a next task re-reads its last one): unconditional, so that the
+    // compiler sees one load and one use per task on every path and never has to guess what is still pending
     const int n_stage = K * npl * LINE_NTERMS;
     const bool stages = tid < n_stage;
     int st_line = 0, st_q = 0, st_ring = 0;
@@ -346,41 +384,45 @@ __global__ __launch_bounds__(LDS_THREADS) void expand_stream_lds_kernel(
         return (long)jb * K * da + fast_div(local0, div_nw) - da;
     };
     auto fetch = [&](long tk) -> double {
-        if (!stages) return 0.0;
         unsigned jb, cg;
         long line = task_first_line(tk, jb, cg) + st_line;
         if (line > nA) line = nA;                       // beyond the stream: a pad record, never used by a stored element
         return coef[line * GORT_COEF_STRIDE + st_q];
     };
-    {
-        const double v = fetch(task);
-        if (stages) s_ring[st_ring] = v;
-    }
+    // ring offset of this thread's value in buffer b: staging threads into the ring, the others into the dump row
+    auto park_at = [&](int b) -> int { return stages ? b * ring_doubles + st_ring : 2 * ring_doubles + lane; };
+    s_ring[park_at(0)] = fetch(task);
     __syncthreads();
 
     int buf = 0;
     for (; task < task_end; task += task_step, buf ^= 1) {
         const bool more = task + task_step < task_end;
-        const double nxt = more ? fetch(task + task_step) : 0.0;          // in flight while this task is worked on
+        const double nxt = fetch(more ? task + task_step : task);         // in flight while this task is worked on
+        const int park = park_at(buf ^ 1);
+        bool parked = false;
         unsigned jb, cg;
         const long a_min = task_first_line(task, jb, cg);
         const unsigned w = cg * LDS_WAVES + (unsigned)wave;               // this wave's column
         const long c0 = (long)jb * K * stride_chunks + w;
-        if (w < stride && c0 <= last_chunk) {
+        if (__builtin_amdgcn_readfirstlane((int)(w < stride && c0 <= last_chunk))) {
             // index arithmetic of expand_flat_stream_kernel with panel = jb, steps_per_wave = K
             const long e0 = c0 * CHUNK - shift;
             const unsigned local = w * CHUNK + (unsigned)step - (unsigned)shift;
             const unsigned a_loc = fast_div(local, div_nw);
-            const int band_w = (int)(local - a_loc * (unsigned)nw);
+            // (everything here is wave-uniform; the readfirstlanes say so to the compiler, which otherwise predicates the
+            // branches below instead of jumping - and then cannot count the stores between a load and its use)
+            const int band_w = __builtin_amdgcn_readfirstlane((int)(local - a_loc * (unsigned)nw));
             const long a_w = (long)jb * K * da + a_loc - da;
             const long rel = last_chunk - c0;
             int k_wave = K, last_step = -1;
-            if (rel < (long)K * stride_chunks) {
+            if (rel < (long)K * stride_chunks) {             // only the last row block's waves run out of stream
                 const unsigned k_last = (unsigned)(rel / stride_chunks);
                 k_wave = (int)k_last + 1;
                 if ((unsigned long)rel == (unsigned long)k_last * stride) last_step = (int)k_last;
             }
-            const int first_off = c0 == 0 ? shift : 0;
+            k_wave = __builtin_amdgcn_readfirstlane(k_wave);
+            last_step = __builtin_amdgcn_readfirstlane(last_step);
+            const int first_off = __builtin_amdgcn_readfirstlane(c0 == 0 ? shift : 0);
             StreamBand t[EPL];
             bool second[EPL];
 #pragma unroll
@@ -398,15 +440,34 @@ __global__ __launch_bounds__(LDS_THREADS) void expand_stream_lds_kernel(
                 bt.Tf = tpff * bt.mgk;
                 t[j] = stream_band(bt);
             }
-            const double *ring = s_ring + buf * ring_doubles + (int)(a_w - a_min) * LDS_REC;
+            const double *ring = s_ring + buf * ring_doubles + __builtin_amdgcn_readfirstlane((int)(a_w - a_min)) * LDS_REC;
             double *out_w = out + e0;
-            if (band_w + CHUNK - 1 >= nw)
-                lds_task_steps<NT, true>(t, second, first_off, last_step, last_off, step, k_wave, ring, npl * LDS_REC, out_w, lane);
-            else
-                lds_task_steps<NT, false>(t, second, first_off, last_step, last_off, step, k_wave, ring, npl * LDS_REC, out_w, lane);
+            const bool wraps = band_w + CHUNK - 1 >= nw;
+            if (K == KFULL && k_wave == KFULL && first_off == 0 && last_step < 0) {
+                // the next task's records are parked in the ring right behind the stores, in the same block of
+                // straight-line code: a counted wait (vmcnt(KFULL)), not a wait for the stores themselves
+                // (the asm comments keep the three identical ring writes from being merged into one block, which would be
+                // entered from the counted and the uncounted paths alike)
+                if (wraps) {
+                    lds_task_full<NT, true, MODE, KFULL>(t, second, step, ring, npl * LDS_REC, out_w, lane);
+                    asm volatile("; records of the next task parked behind KFULL counted stores (wrap)" ::: "memory");
+                    s_ring[park] = nxt;
+                    asm volatile("; parked (wrap)" ::: "memory");
+                } else {
+                    lds_task_full<NT, false, MODE, KFULL>(t, second, step, ring, npl * LDS_REC, out_w, lane);
+                    asm volatile("; records of the next task parked behind KFULL counted stores" ::: "memory");
+                    s_ring[park] = nxt;
+                    asm volatile("; parked" ::: "memory");
+                }
+                parked = true;
+            } else if (wraps) {
+                lds_task_steps<NT, true, MODE>(t, second, first_off, last_step, last_off, step, k_wave, ring, npl * LDS_REC, out_w, lane);
+            } else {
+                lds_task_steps<NT, false, MODE>(t, second, first_off, last_step, last_off, step, k_wave, ring, npl * LDS_REC, out_w, lane);
+            }
         }
-        if (more && stages) s_ring[(buf ^ 1) * ring_doubles + st_ring] = nxt;
-        __syncthreads();
+        if (!parked) s_ring[park] = nxt;
+        if (MODE != 3) __syncthreads();                 // MODE 3 (experiment, WRONG results): how much the lockstep costs
     }
 }
 
@@ -471,8 +532,8 @@ static bool stream_lds_shape(int nw, long chunks, LdsShape *s)
     s->K = K;
     s->groups = (int)((s->stride + LDS_WAVES - 1) / LDS_WAVES);
     s->n_tasks = ((rows + K - 1) / K) * s->groups;
-    s->lds_bytes = sizeof(double) * (size_t)(((LDS_TAB_SLOTS * nw + 1) & ~1) + 2 * K * s->npl * LDS_REC);
-    const size_t worst = sizeof(double) * (size_t)(((LDS_TAB_SLOTS * nw + 1) & ~1) + 2 * k_max * s->npl * LDS_REC);
+    s->lds_bytes = sizeof(double) * (size_t)(((LDS_TAB_SLOTS * nw + 1) & ~1) + 2 * K * s->npl * LDS_REC + 64);
+    const size_t worst = sizeof(double) * (size_t)(((LDS_TAB_SLOTS * nw + 1) & ~1) + 2 * k_max * s->npl * LDS_REC + 64);
     return worst <= LDS_MAX_BYTES && s->n_tasks < (1L << 31) && (long)s->groups * LDS_WAVES * CHUNK < (1L << 30);
 }
 
@@ -552,27 +613,25 @@ static int launch_expand_stream_lds(const gort_canopy *canopy_dev, const double 
     if (!stream_lds_shape(nw, chunks, &sh)) return fail(GORT_EINVAL, "stream expansion: %d bands do not fit the LDS-resident form", nw);
     if (chunks >= (1L << 31) || sh.stride * CHUNK >= (1L << 30))
         return fail(GORT_EINVAL, "stream expansion: %ld chunks are beyond the kernel's 32-bit indices", chunks);
-    static bool attr_set[2] = {false, false};
+    static const int mode = getenv("GORT_STREAM_LDS_MODE") ? atoi(getenv("GORT_STREAM_LDS_MODE")) : 0;     // experiments
     const bool nt = tuning().nt;
-    const void *fn = nt ? (const void *)expand_stream_lds_kernel<true> : (const void *)expand_stream_lds_kernel<false>;
-    if (!attr_set[nt ? 1 : 0]) {
-        // the full 160 KB of a CU for one workgroup (harmless where the default limit already allows it)
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX_BYTES);
-        (void)hipGetLastError();
-        attr_set[nt ? 1 : 0] = true;
-    }
+    typedef void (*kern_t)(const gort_canopy *, const double *, int, const double *, long, long, int, long, int, int, int, int, long,
+                           FastDiv, FastDiv, double *, int);
+    const bool k8 = sh.K == 8;                                // interior tasks unrolled for K = 16 (default) or 8 (short streams)
+    const kern_t fn = mode == 1 ? (kern_t)expand_stream_lds_kernel<true, 1, 16>
+                      : mode == 2 ? (kern_t)expand_stream_lds_kernel<true, 2, 16>
+                      : mode == 3 ? (kern_t)expand_stream_lds_kernel<true, 3, 16>
+                      : nt ? (k8 ? (kern_t)expand_stream_lds_kernel<true, 0, 8> : (kern_t)expand_stream_lds_kernel<true, 0, 16>)
+                           : (k8 ? (kern_t)expand_stream_lds_kernel<false, 0, 8> : (kern_t)expand_stream_lds_kernel<false, 0, 16>);
+    // the full 160 KB of a CU for one workgroup (harmless where the default limit already allows it)
+    (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX_BYTES);
+    (void)hipGetLastError();
     long wgs = lds_workgroups();
     const bool split = xcd_split && sh.n_tasks >= 8 * wgs;
     if (!split && sh.n_tasks < wgs) wgs = sh.n_tasks;
-    const dim3 grid((unsigned)wgs);
-    if (nt)
-        hipLaunchKernelGGL(expand_stream_lds_kernel<true>, grid, dim3(LDS_THREADS), sh.lds_bytes, s, canopy_dev, L_dev, nw, coef_dev,
-                           nA, n_total, shift, sh.stride, sh.da, sh.K, sh.npl, sh.groups, sh.n_tasks, make_fast_div((unsigned)nw),
-                           make_fast_div((unsigned)sh.groups), rsurf_dev, split ? 1 : 0);
-    else
-        hipLaunchKernelGGL(expand_stream_lds_kernel<false>, grid, dim3(LDS_THREADS), sh.lds_bytes, s, canopy_dev, L_dev, nw, coef_dev,
-                           nA, n_total, shift, sh.stride, sh.da, sh.K, sh.npl, sh.groups, sh.n_tasks, make_fast_div((unsigned)nw),
-                           make_fast_div((unsigned)sh.groups), rsurf_dev, split ? 1 : 0);
+    hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(LDS_THREADS), sh.lds_bytes, s, canopy_dev, L_dev, nw, coef_dev, nA, n_total,
+                       shift, sh.stride, sh.da, sh.K, sh.npl, sh.groups, sh.n_tasks, make_fast_div((unsigned)nw),
+                       make_fast_div((unsigned)sh.groups), rsurf_dev, split ? 1 : 0);
     return check_launch("expand_stream_lds_kernel");
 }
 

@@ -128,41 +128,55 @@ def gather_member_tables(local, n_members, group=None):
 
 
 def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, group=None, lut_chunk=0, seed=12345,
-                         gather_on_cpu=False):
+                         gather_on_cpu=False, barrier=None):
     """Config 5 on `world` ranks, one GPU each: rank r draws the whole ensemble (same seed everywhere), keeps the
     members row_slab(r, world, n) on its GPU - gap probabilities, PROSPECT-D/Price, band tables on the device,
-    optionally every member's hemisphere LUT in chunks of `lut_chunk` members - and all ranks end with the
-    ensemble's albedo/fAPAR table energy[n_members][nw][3].  Returns (table as numpy, timings dict).
-    gather_on_cpu: exchange through host memory (gloo rehearsals on one GPU)."""
+    optionally every member's hemisphere LUT in chunks of `lut_chunk` members (into a gort_lut_alloc buffer) - and all
+    ranks end with the ensemble's albedo/fAPAR table energy[n_members][nw][3] after ONE all-gather (RCCL over xGMI with
+    the `nccl` backend).  Returns (table as numpy, timings dict: setup_s = gap + spectra + band tables, lut_s and
+    lut_chunk_ms per chunk, energy_s, gather_s, total_s from the first setup call to the gathered table; rank-local).
+    gather_on_cpu: exchange through host memory (gloo rehearsals on one GPU).  barrier: called before the clock
+    starts and around the gather, so that the all-gather's time is not another rank's lateness."""
     import time
     import torch
     wl = np.ascontiguousarray(wavelengths, dtype=np.float64)
     canopies, leaf = draw_c5_members(n_members, seed)
     m0, m1 = row_slab(rank, world, n_members)
     eng = api.Engine()
-    t = {}
-    t0 = time.perf_counter()
+    sync = barrier or (lambda: None)
+    t = {"members": [m0, m1]}
+    torch.cuda.synchronize()
+    sync()
+    t_start = t0 = time.perf_counter()
     if m1 > m0:
         eng.set_members_leaf(canopies[m0:m1], leaf[m0:m1], wl, compute_gaps=True)
         eng.synchronize()
     t["setup_s"] = time.perf_counter() - t0
-    t["lut_s"] = 0.0
+    t["lut_s"], t["lut_chunk_ms"], t["lut_samples"] = 0.0, [], 0
     if lut_chunk and m1 > m0:
         g = c5_grid()
         chunk = min(lut_chunk, m1 - m0)
-        lut = torch.empty((chunk, g.nvza * g.nphi, wl.size), dtype=torch.float64, device="cuda")
+        per_member = g.nvza * g.nphi * wl.size
+        lut = eng.lut_alloc(chunk * per_member, max_draws=1)
         t0 = time.perf_counter()
         for a in range(0, m1 - m0, chunk):
+            tc = time.perf_counter()
             eng.rsurf_members_grid_dev(g, a, min(m1 - m0, a + chunk), lut)
-        eng.synchronize()
+            eng.synchronize()
+            t["lut_chunk_ms"].append((time.perf_counter() - tc) * 1e3)
         t["lut_s"] = time.perf_counter() - t0
-        del lut
+        t["lut_samples"] = (m1 - m0) * per_member
+        lut.free()
+    t0 = time.perf_counter()
     energy = torch.empty((m1 - m0, 1, wl.size, 3), dtype=torch.float64, device="cuda")
     if m1 > m0:
         sun = torch.tensor([[0.0, 0.0, float(sun_zenith), 0.0]], dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()                 # torch fills on its stream, the engine reads on its own
         eng.energy_members_dev(sun, 0, m1 - m0, energy)
         eng.synchronize()
     torch.cuda.synchronize()
+    t["energy_s"] = time.perf_counter() - t0
+    sync()
     t0 = time.perf_counter()
     local = energy.view(m1 - m0, wl.size, 3)
     if world > 1:
@@ -170,7 +184,10 @@ def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, g
     else:
         full = local
     torch.cuda.synchronize()
+    sync()
     t["gather_s"] = time.perf_counter() - t0
+    t["gather_bytes_received"] = int((n_members - (m1 - m0)) * wl.size * 3 * 8) if world > 1 else 0
+    t["total_s"] = time.perf_counter() - t_start
     out = full.cpu().numpy()
     eng.close()
     return out, t

@@ -75,6 +75,8 @@ typedef struct gort_leaf_soil {
     double alb_leaf, alb_soil;
 } gort_leaf_soil;
 
+typedef struct gort_engine gort_engine;      /* opaque, see below */
+
 const char *gort_last_error(void);
 const char *gort_version(void);
 
@@ -149,6 +151,26 @@ void  gort_dev_free(void *p_dev);
 int   gort_memcpy_h2d(void *dst_dev, const void *src, size_t bytes);
 int   gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
 
+/* Device memory for a LUT with a MEASURED placement.  Which physical pages a buffer of several GB lands on decides up
+ * to 12 % of the rate at which the LUT kernel can write it (HBM channel balance; the same buffer is fast or slow for its
+ * whole life), and a multi-GPU step ends with its slowest rank.  gort_lut_alloc draws up to max_draws
+ * allocations (alive together, hence distinct placements), writes the window [win_offset, win_offset + win_bytes) of
+ * each with the LUT kernel's store pattern (no arithmetic, ~1 ms per 6 GB), keeps the fastest and frees the rest;
+ * it stops drawing early at 0.985 x the best rate this engine has measured for the size class.  Windows below 1 GiB
+ * and max_draws = 1 are plain allocations.  The window is what this process will write: the whole buffer (win_bytes
+ * = 0), or a rank's slab of a gatherable LUT.  Contents are undefined.  Release with gort_lut_free.
+ * New surface (the reference keeps ONE row of nw doubles, malloc in main(): gortt.c:188). */
+#define GORT_LUT_MAX_DRAWS 8
+typedef struct gort_lut_placement {
+    int32_t draws;                               /* allocations made */
+    int32_t picked;                              /* index of the one kept */
+    double probe_gbs[GORT_LUT_MAX_DRAWS];        /* store-pattern rate over the window per draw, GB/s (0 = not probed) */
+    double accept_gbs;                           /* early-stop rate used for this call (0 = no history yet) */
+} gort_lut_placement;
+int   gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, size_t win_bytes, int max_draws,
+                     void **lut_dev, gort_lut_placement *info);
+void  gort_lut_free(void *lut_dev);
+
 /* Pinned (page-locked) host memory: buffers from here travel over PCIe by DMA at the link rate, and
  * gort_rsurf_stream / gort_energy_stream copy straight into them; results written into ordinary pageable memory
  * are staged through pinned chunks and copied once more by the host.  gort_host_malloc returns NULL on failure. */
@@ -172,7 +194,6 @@ int  gort_gap_probabilities_dev(gort_canopy *members_dev, int n_members, void *s
  * the wavelength-only tables derived from them.  NOT thread-safe: one thread at a time per engine (the
  * reference's functions are not re-entrant on their structs either); use one engine per thread,
  * or a gort_pipe, whose producer and consumer sides may live on two threads. */
-typedef struct gort_engine gort_engine;
 int  gort_engine_create(gort_engine **out);
 void gort_engine_destroy(gort_engine *e);
 void *gort_engine_stream(gort_engine *e);           /* hipStream_t */

@@ -399,6 +399,60 @@ def test_energy_depends_on_sun_only(eng):
     assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])
 
 
+def test_energy_stream_shares_rows_of_equal_sun_directions(golden):
+    """`-energy` on a stream (gortt.c:321-325 calls gortt_energy per line; the hemispherical integral of
+    gortt_albedo.c:62-138 keeps only the line's sun zenith and sun azimuth): 100 000 lines with 91 sun zeniths - some
+    given as negative zeniths, a few sun azimuths, random view angles - are evaluated once per distinct normalised
+    sun direction and copied.  Bitwise equal to the evaluation of every line (GORT_ENERGY_DEDUP=0), equal to the
+    reference's goldens (c4_albedo.npz, 21 bands x 91 sun zeniths), and the time follows the distinct directions."""
+    import time
+    import torch
+    g = golden("c4_albedo.npz")
+    wl = g["wl_b"]
+    rng = np.random.default_rng(4)
+    n = 100000
+    sza = rng.integers(0, 91, n).astype(float)
+    saa = rng.choice(np.array([0.0, 0.0, 0.0, 77.5, 180.0, 365.0]), n)
+    flip = rng.random(n) < 0.2                                   # -sza, saa + 180: the same sun direction after normalisation ...
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), np.where(flip, -sza, sza), saa], 1)
+    ang[:91, 2] = np.arange(91.0); ang[:91, 3] = 0.0; ang[:91, :2] = 0.0     # ... and the golden lines themselves
+    res = {}
+    for dedup in ("1", "0"):
+        os.environ["GORT_ENERGY_DEDUP"] = dedup
+        e = api.Engine()
+        os.environ.pop("GORT_ENERGY_DEDUP")
+        e.set_canopy(gpu_canopy(lai=4.0))
+        e.set_spectra(*api.spectra(wl))
+        a = torch.as_tensor(ang, device="cuda")
+        out = torch.full((n, len(wl), 3), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        e.energy_stream_dev(a, out); e.synchronize()
+        t0 = time.perf_counter()
+        e.energy_stream_dev(a, out); e.synchronize()
+        dt = time.perf_counter() - t0
+        res[dedup] = (out.cpu().numpy(), dt)
+        # a stream where every line has a sun direction of its own: nothing to share, same answer
+        if dedup == "1":
+            uniq = ang[:3000].copy(); uniq[:, 2] = rng.uniform(0, 89, 3000)
+            au = torch.as_tensor(uniq, device="cuda")
+            o1 = torch.empty((3000, len(wl), 3), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            e.energy_stream_dev(au, o1); e.synchronize()
+            res["uniq"] = o1.cpu().numpy()
+        else:
+            o0 = torch.empty((3000, len(wl), 3), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            e.energy_stream_dev(au, o0); e.synchronize()
+            assert np.array_equal(res["uniq"].view(np.int64), o0.cpu().numpy().view(np.int64))
+        e.close()
+    shared, every = res["1"][0], res["0"][0]
+    assert not (shared == -7.0).any()
+    assert np.array_equal(shared.view(np.int64), every.view(np.int64))
+    assert err(shared[:91], g["energy_b"]) <= REGRESSION
+    print("energy stream, %d lines x %d bands: shared rows %.2f ms, every line %.2f ms" % (n, len(wl), res["1"][1] * 1e3, res["0"][1] * 1e3))
+    assert res["1"][1] < 0.2 * res["0"][1]
+
+
 # ------------------------------------------------------------------------ C5
 @pytest.mark.parametrize("i", range(8))
 def test_c5_member_spectrum(eng, i, golden):
@@ -876,34 +930,59 @@ def test_lut_kernel_variants_bitwise_identical():
 
 
 def test_bench_two_ranks_rehearsal():
-    """The N>1 code path of bench.py (row slabs, max-over-ranks timing, optional all-gather) with two ranks
-    sharing this GPU over gloo - everything of the multi-GPU run except RCCL itself."""
+    """The N>1 code path of bench.py exactly as the driver launches it but for the backend: two ranks sharing this GPU
+    over gloo.  Every rank computes into ITS WINDOW of one gatherable LUT buffer (gort_lut_alloc), the timed region runs
+    there, the in-place all-gather runs once outside it and is reported, rows that the other rank computed are checked
+    against the oracle on rank 0, every rank's own numbers arrive on rank 0, and the config-5 block shards its members
+    and times its energy-table all-gather."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--nsza", "3", "--rehearse", "--gather",
-                          "--no-cpu-baseline"], capture_output=True, timeout=600)
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--nsza", "3", "--rehearse",
+                          "--c5-members", "12", "--c5-chunk", "3", "--no-cpu-baseline"], capture_output=True, timeout=900)
     assert run.returncode == 0, run.stderr.decode()[-3000:]
     lines = [l for l in run.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 1e8
-    assert "2 contiguous slabs" in d["config"]["sharding"] and d["allgather_ms"] > 0
+    assert "2 contiguous slabs" in d["config"]["sharding"] and "gatherable" in d["config"]["sharding"]
     assert d["parity"]["nan_pattern_equal"] and d["parity"]["max_rel_err"] <= 1e-9
-    assert "cpu_baseline" not in d
+    ag = d["allgather"]
+    assert ag["ms"] > 0 and ag["inside_timed_region"] is False and ag["xgmi_bound_gbs"] == 7 * 153.0
+    rows = 3 * 91
+    per = -(-rows // 2)
+    assert ag["bytes_received_per_gpu"] == per * 361 * 2101 * 8 and ag["gbs_received_per_gpu"] > 0
+    pf = d["parity_after_allgather"]
+    assert pf["nan_pattern_equal"] and pf["max_rel_err"] <= 1e-9 and pf["samples_checked"] == 12 * 2101
+    assert d["first_draw"]["value"] > 1e8 and d["first_draw"]["ms_per_step"] > 0
+    pr = d["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and pr[0]["rows"] == [0, per] and pr[1]["rows"] == [per, rows]
+    for r in pr:
+        assert r["kernel_ms"] > 0 and r["first_draw_kernel_ms"] > 0 and len(r["xcd_weights_32nds"]) == 8
+        assert r["lut_alloc"]["draws"] >= 1 and r["xcd_mapping"] in (1, 2)
+    assert d["sustained"]["steps"] >= 2
+    c5 = d["config5"]
+    assert c5["members"] == 12 and c5["scaling"] == "strong" and c5["value"] > 0 and len(c5["per_rank"]) == 2
+    assert c5["per_rank"][0]["members"] == [0, 6] and c5["per_rank"][1]["members"] == [6, 12]
+    assert c5["allgather"]["ms"] > 0 and c5["allgather"]["bytes_received_per_gpu"] == 6 * 2101 * 3 * 8
+    assert len(c5["per_rank"][1]["lut_chunk_ms"]) == 2
+    for k in ("own_member", "foreign_member"):
+        assert c5["parity"][k]["nan_pattern_equal"] and c5["parity"][k]["max_rel_err"] <= 1e-9
+    assert "cpu_baseline" not in d and "reference_build" in d
 
 
 def test_bench_json_contract():
     """bench.py prints ONE JSON line with the driver's keys plus roofline/parity (reduced grid, 2 steps)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run(["python3", os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--nsza", "3",
-                          "--no-cpu-baseline"], capture_output=True, timeout=600)
+                          "--c5-members", "8", "--c5-chunk", "4", "--no-cpu-baseline"], capture_output=True, timeout=600)
     assert run.returncode == 0, run.stderr.decode()
     lines = [l for l in run.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "parity"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "parity", "first_draw", "per_rank", "config5",
+              "reference_build"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["unit"] == "samples/s" and d["value"] > 1e8 and "workload" in d["config"] and "model" not in d["config"]
@@ -911,6 +990,8 @@ def test_bench_json_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert d["parity"]["nan_pattern_equal"] and d["parity"]["max_rel_err"] <= 1e-9
+    assert "allgather" not in d and d["config5"]["allgather"]["gbs_received_per_gpu"] is None
+    assert d["config5"]["parity"]["foreign_member"]["max_rel_err"] <= 1e-9
 
 
 # ------------------------------------------------- BASELINE.json full sizes
@@ -1257,20 +1338,33 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))        # RCCL, the calls bench.py makes at N > 1
 from gort_amd import api
-from gort_amd.shard import all_gather_lut, row_slab
+from gort_amd.shard import all_gather_in_place, all_gather_lut, gatherable_rows, row_slab
 wl = np.linspace(400.0, 2500.0, 140)
 e = api.Engine(); e.set_canopy(api.gap_probabilities(api.make_canopy(lai=3.0))); e.set_spectra(*api.spectra(wl))
 g = api.hemisphere_grid(6, 8, 361)
 rows = g.nsza * g.nvza
 r0, r1 = row_slab(0, 1, rows)
-lut = torch.empty(((r1 - r0) * g.nphi, wl.size), dtype=torch.float64, device="cuda")
-e.rsurf_grid_dev(g, r0, r1, lut); e.synchronize(); torch.cuda.synchronize()
+row_elems = g.nphi * wl.size
+# bench.py's layout: the gatherable buffer from the C ABI's allocator, this rank's window, a zero-copy tensor view
+buf = e.lut_alloc(gatherable_rows(1, rows) * row_elems, window=(r0 * row_elems, (r1 - r0) * row_elems), max_draws=2)
+e.rsurf_grid_dev(g, r0, r1, buf.at(r0 * row_elems)); e.synchronize(); torch.cuda.synchronize()
+before = buf.to_numpy().view(np.int64).copy()
 dist.barrier()
 t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-full = all_gather_lut(lut.view(r1 - r0, g.nphi * wl.size), rows)
+view = buf.tensor((gatherable_rows(1, rows), row_elems))
+assert view.data_ptr() == buf.ptr
+full = all_gather_in_place(view, rows)                      # all_gather_into_tensor, send buffer = own window
 torch.cuda.synchronize()
-assert float(t.item()) == 1.25 and torch.equal(full.view(torch.int64), lut.view(r1 - r0, -1).view(torch.int64))
+objs = [None]
+dist.all_gather_object(objs, {"rank": 0, "placement": buf.placement})
+assert objs[0]["placement"]["draws"] >= 1
+assert float(t.item()) == 1.25 and np.array_equal(full.cpu().numpy().view(np.int64).ravel(), before)
+lut = full.clone()
+again = all_gather_lut(lut, rows)                           # the convenience form (own buffer, copy, gather)
+assert torch.equal(again.view(torch.int64), lut.view(torch.int64))
+del view, full
+buf.free()
 dist.destroy_process_group()
 print("rccl ok")
 """
@@ -1278,7 +1372,8 @@ print("rccl ok")
 
 def test_rccl_calls_of_the_multi_gpu_path_on_one_rank():
     """The RCCL side of bench.py (nccl process group bound to the device, barrier, MAX all-reduce of a device
-    scalar, all_gather_into_tensor of the LUT slab) executed for real - with the one rank a 1-GPU box allows."""
+    scalar, all_gather_object, in-place all_gather_into_tensor on a tensor view of a gort_lut_alloc buffer) executed for
+    real - with the one rank a 1-GPU box allows."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run(["python3", "-c", _RCCL_SCRIPT % root], capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode()[-3000:]

@@ -65,7 +65,22 @@ def _worker(rank, world, port, rows, row_elems, q):
         from gort_amd.ensemble import gather_member_tables
         tab = _pattern(r0, r1, 2 * 3).view(r1 - r0, 2, 3)
         ok3 = bool(torch.equal(gather_member_tables(tab, rows), _pattern(0, rows, 6).view(rows, 2, 3)))
-        q.put((rank, ok1, ok2, ok3))
+        # (4) bench.py's bookkeeping around it: buffer row == global row (so rows of ANOTHER rank's window can be read
+        # by their global index after the gather), every rank's record on every rank, MAX over ranks of a timing
+        from gort_amd.shard import gatherable_rows
+        ok4 = full.shape[0] == gatherable_rows(world, rows)
+        for other in sorted({min(1, world - 1), world - 1}):
+            o0, o1 = row_slab(other, world, rows)
+            ok4 = ok4 and bool(torch.equal(full[o0:o1], want[o0:o1]))
+        recs = [None] * world
+        dist.all_gather_object(recs, {"rank": rank, "rows": [r0, r1]})
+        ok4 = ok4 and [r["rank"] for r in recs] == list(range(world))
+        ok4 = ok4 and recs[0]["rows"][0] == 0 and recs[-1]["rows"][1] == rows
+        ok4 = ok4 and all(recs[i]["rows"][1] == recs[i + 1]["rows"][0] for i in range(world - 1))
+        t = torch.tensor([1.0 + rank, 5.0 - rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok4 = ok4 and t.tolist() == [float(world), 5.0]
+        q.put((rank, ok1, ok2, ok3 and ok4))
     finally:
         dist.destroy_process_group()
 
