@@ -86,7 +86,7 @@ DECLARED_SYMBOLS = [
 
 #: include/gort_amd_tuning.h: measurement and tuning hooks, not part of the drop-in boundary
 TUNING_SYMBOLS = [
-    "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_set_stream_form", "gort_engine_stream_form",
+    "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_stream_form",
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
     "gort_selftest_index_math",
 ]
@@ -136,7 +136,6 @@ def lib():
         L.gort_pipe_destroy.argtypes = [C.c_void_p]
         L.gort_pipe_destroy.restype = None
         L.gort_engine_stream_form.argtypes = [C.c_void_p]
-        L.gort_engine_set_stream_form.argtypes = [C.c_void_p, C.c_int]
         L.gort_engine_last_stream_ms.argtypes = [C.c_void_p]
         L.gort_engine_last_stream_ms.restype = D
         L.gort_engine_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -543,16 +542,11 @@ class Engine:
                                            _ptr(scomp_t), _ptr(K_t)))
 
     def stream_form(self):
-        """'narrow' | 'flat' | 'lds': which kernel expanded the last stream call (include/gort_amd_tuning.h)."""
+        """'narrow' | 'flat': which kernel family expanded the last stream call (include/gort_amd_tuning.h)."""
         m = lib().gort_engine_stream_form(self.h)
         if m < 0:
             _check(m)
-        return {0: "narrow", 1: "flat", 2: "lds"}[m]
-
-    def set_stream_form(self, form):
-        """Wide streams: 0 / 'auto', 1 / 'flat' (panels of long waves), 2 / 'lds' (LDS-resident band table)."""
-        form = {"auto": 0, "flat": 1, "lds": 2}.get(form, form)
-        _check(lib().gort_engine_set_stream_form(self.h, int(form)))
+        return {0: "narrow", 1: "flat"}[m]
 
     def last_stream_ms(self):
         return lib().gort_engine_last_stream_ms(self.h)

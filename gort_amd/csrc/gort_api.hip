@@ -71,8 +71,7 @@ struct gort_engine {
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
     DevBuf edup;                         // sun-direction table of the energy path (gort_energy.hip)
     bool energy_dedup = true;            // GORT_ENERGY_DEDUP=0: every line evaluated (tests compare the two)
-    int wide_form_pref = 0;              // wide streams: 0 automatic, 1 flat panels, 2 LDS-resident (gort_amd_tuning.h)
-    int stream_form = 0;                 // form of the last stream call: 0 narrow, 1 flat panels, 2 LDS-resident
+    int stream_form = 0;                 // kernel family of the last stream call: 0 narrow, 1 flat panels (gort_amd_tuning.h)
     hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call
     char *stage = nullptr;               // pinned staging of the setters' small uploads (stage_begin / stage_h2d)
     size_t stage_cap = 0, stage_off = 0;
@@ -310,7 +309,6 @@ extern "C" int gort_engine_create(gort_engine **out)
     }
     if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GORT_ENERGY_DEDUP")) e->energy_dedup = atoi(v) != 0;
-    if (const char *v = getenv("GORT_STREAM_FORM")) { const int m = atoi(v); e->wide_form_pref = m < 0 ? 0 : (m > 2 ? 2 : m); }
     if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
     if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
         int w[8];
@@ -635,12 +633,6 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
     const bool wide = stream_is_wide(e->nw, nA, scomp_dev != nullptr);
-    // wide streams: the LDS-resident kernel where the band table fits a CU's LDS (nw <= ~2130), else flat panels
-    int wide_form = 0;
-    if (wide) {
-        wide_form = e->wide_form_pref ? e->wide_form_pref : 2;
-        if (wide_form == 2 && !stream_lds_applies(e->nw, nA)) wide_form = 1;
-    }
     for (int i = 0; i < 2; ++i)
         if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
     if (stream_fuses(e->nw, scomp_dev != nullptr)) {
@@ -652,9 +644,9 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     }
     if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, wide ? 1 : 0, e->stream))) return rc;
     GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
-    rc = launch_expand_stream(c, e->L.as<double>(), e->nw, coef, nA, rsurf_dev, scomp_dev, xcd_slots, wide_form, e->stream, false);
+    rc = launch_expand_stream(c, e->L.as<double>(), e->nw, coef, nA, rsurf_dev, scomp_dev, xcd_slots, e->stream, false);
     GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
-    e->stream_form = wide_form;
+    e->stream_form = wide ? 1 : 0;
     return rc;
 }
 
@@ -792,13 +784,6 @@ extern "C" int gort_rsurf_stream(gort_engine *e, const double *angles, long nA, 
     return GORT_OK;
 }
 
-extern "C" int gort_engine_set_stream_form(gort_engine *e, int form)
-{
-    if (!e || form < 0 || form > 2) return fail(GORT_EINVAL, "gort_engine_set_stream_form: bad argument");
-    e->wide_form_pref = form;
-    return GORT_OK;
-}
-
 extern "C" int gort_engine_stream_form(gort_engine *e)
 {
     if (!e) return fail(GORT_EINVAL, "gort_engine_stream_form: null engine");
@@ -879,8 +864,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         if (nw <= 8 && fuse) return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream);
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
-        return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr, 0,
-                                    e->stream, true);
+        return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr, e->stream, true);
     }
     // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).
     // Full-size slabs: ONE buffer, reused by every call - the 191 MB of records the geometry kernel writes are

@@ -82,6 +82,15 @@ __device__ inline long energy_rep(const double *__restrict__ angles, long line, 
     return (a.z == b.z && a.a == b.a) ? o : line;
 }
 
+// one thread per line, behind energy_key_kernel: slot_of[line] becomes rep[line] (in place: a line reads its own slot only)
+__global__ __launch_bounds__(256) void energy_rep_kernel(const double *__restrict__ angles, long nA,
+                                                          const unsigned *__restrict__ owner, unsigned *__restrict__ slot_of)
+{
+    const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (line >= nA) return;
+    slot_of[line] = (unsigned)energy_rep(angles, line, owner, slot_of);
+}
+
 // blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by the members;
 // energy[member][nA][nw][3].  DEDUP: workgroups stride over the lines and evaluate only those that stand for themselves.
 template <bool DEDUP>
@@ -90,8 +99,7 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
                                                                  const double *__restrict__ angles, long nA,
                                                                  const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
                                                                  double *__restrict__ energy_all,
-                                                                 const unsigned *__restrict__ owner,
-                                                                 const unsigned *__restrict__ slot_of)
+                                                                 const unsigned *__restrict__ rep)
 {
     __shared__ double s_part[5][ENERGY_THREADS / 64];
     __shared__ double s_abar[5];
@@ -102,7 +110,7 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
     double *__restrict__ energy = energy_all + member * nA * nw * 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (long a = blockIdx.x; a < nA; a += gridDim.x) {
-    if (DEDUP && energy_rep(angles, a, owner, slot_of) != a) continue;       // uniform: the whole workgroup
+    if (DEDUP && (long)rep[a] != a) continue;                                // uniform: the whole workgroup
     if (DEDUP) __syncthreads();                                              // the shared arrays of the previous line are done with
 
     double vza, sza, saa, raa;
@@ -155,34 +163,51 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
   }
 }
 
-// rows of the lines that share another line's sun direction: energy[line] = energy[rep(line)].  The output is walked as
+// rows of the lines that share another line's sun direction: energy[line] = energy[rep[line]].  The output is walked as
 // ONE flat array in 1-KiB chunks aligned in absolute address (rows of 3 nw doubles start on 8-byte boundaries only, and
-// HBM wants whole lines per wave store: DESIGN.md 5.1 step 2); the few source rows stay in L2.
-__global__ __launch_bounds__(256) void energy_broadcast_kernel(const double *__restrict__ angles, long nA, int row,
-                                                                double *__restrict__ energy_all,
-                                                                const unsigned *__restrict__ owner,
-                                                                const unsigned *__restrict__ slot_of, int shift,
-                                                                long chunks)
+// HBM wants whole lines per wave store: DESIGN.md 5.1 step 2); the few source rows stay in L2.  A chunk of 128 doubles
+// lies in at most two rows when a row has >= 128 doubles (ROWS2: their representatives are two wave-uniform loads);
+// shorter rows (a handful of bands) take the per-element form.
+template <bool ROWS2>
+__global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row, double *__restrict__ energy_all,
+                                                                const unsigned *__restrict__ rep, int shift, long chunks)
 {
     double *__restrict__ energy = energy_all + (long)blockIdx.y * nA * row;
     const long n_total = nA * (long)row;
     const int lane = threadIdx.x & 63;
-    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const long wave0 = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (long)gridDim.x * 4;
     for (long ch = wave0; ch < chunks; ch += nwaves) {
-        const long e0 = ch * CHUNK - shift + EPL * lane;             // first of this lane's two elements
+        const long c0 = ch * CHUNK - shift;                           // element of the chunk's first double (< 0 only for chunk 0)
+        const long e0 = c0 + EPL * lane;                              // first of this lane's two elements
         double v[EPL];
         bool put[EPL];
+        if (ROWS2) {
+            const long first = c0 < 0 ? 0 : c0;
+            const long line0 = first / row;                           // wave-uniform
+            const long edge = (line0 + 1) * row;                      // first element of the next row
+            const long rep0 = rep[line0], rep1 = line0 + 1 < nA ? (long)rep[line0 + 1] : line0 + 1;
+            if (rep0 == line0 && (edge >= c0 + CHUNK || rep1 == line0 + 1)) continue;        // nothing to copy in this chunk
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const long e = e0 + j;
-            put[j] = false;
-            v[j] = 0.0;
-            if (e >= 0 && e < n_total) {
-                const long line = e / row;
-                const long rep = energy_rep(angles, line, owner, slot_of);
-                if (rep != line) {
-                    v[j] = energy[rep * row + (e - line * row)];
-                    put[j] = true;
+            for (int j = 0; j < EPL; ++j) {
+                const long e = e0 + j;
+                const bool second = e >= edge;
+                const long line = second ? line0 + 1 : line0, r = second ? rep1 : rep0;
+                put[j] = e >= 0 && e < n_total && r != line;
+                v[j] = put[j] ? energy[r * row + (e - line * row)] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const long e = e0 + j;
+                put[j] = false;
+                v[j] = 0.0;
+                if (e >= 0 && e < n_total) {
+                    const long line = e / row;
+                    const long r = rep[line];
+                    if (r != line) {
+                        v[j] = energy[r * row + (e - line * row)];
+                        put[j] = true;
+                    }
                 }
             }
         }
@@ -219,8 +244,7 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     if (!ws_dev || nA < ENERGY_DEDUP_MIN_LINES) {
         if (nA >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld lines in one launch", nA);
         hipLaunchKernelGGL(energy_kernel<false>, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
-                           canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)nullptr,
-                           (const unsigned *)nullptr);
+                           canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)nullptr);
         return check_launch("energy_kernel");
     }
     if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
@@ -236,9 +260,13 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
                        (unsigned)(cap - 1), slot_of);
     int rc = check_launch("energy_key_kernel");
     if (rc) return rc;
+    hipLaunchKernelGGL(energy_rep_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, angles_dev, nA, (const unsigned *)owner,
+                       slot_of);
+    if ((rc = check_launch("energy_rep_kernel"))) return rc;
+    const unsigned *rep = slot_of;
     const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
     hipLaunchKernelGGL(energy_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
-                       angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)owner, (const unsigned *)slot_of);
+                       angles_dev, nA, nodes_dev, energy_dev, rep);
     if ((rc = check_launch("energy_kernel"))) return rc;
     const int row = 3 * nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(energy_dev) / sizeof(double)) % CHUNK);
@@ -246,8 +274,11 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     // alignment is a matter of speed, not of correctness, and the member-batched call is the small one
     const long chunks = (nA * (long)row + shift + CHUNK - 1) / CHUNK;
     const long want = (chunks + 3) / 4;
-    hipLaunchKernelGGL(energy_broadcast_kernel, dim3((unsigned)(want < 16384 ? want : 16384), (unsigned)n_members), dim3(256), 0, s,
-                       angles_dev, nA, row, energy_dev, (const unsigned *)owner, (const unsigned *)slot_of, shift, chunks);
+    const dim3 grid((unsigned)(want < 65536 ? want : 65536), (unsigned)n_members);
+    if (row >= CHUNK)
+        hipLaunchKernelGGL(energy_broadcast_kernel<true>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks);
+    else
+        hipLaunchKernelGGL(energy_broadcast_kernel<false>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks);
     return check_launch("energy_broadcast_kernel");
 }
 

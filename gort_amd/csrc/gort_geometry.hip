@@ -83,7 +83,7 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
                                                                           double *__restrict__ coef, int compact,
                                                                           const double *__restrict__ Lall, int nw,
-                                                                          double *__restrict__ rsurf)
+                                                                          double *__restrict__ rsurf, int mirror)
 {
     __shared__ RowTerms s_row[GEOM_ROWS];
     __shared__ int s_member[GEOM_ROWS];
@@ -105,15 +105,23 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         s_sza_deg[threadIdx.x] = sza_deg;
     }
     __syncthreads();
-    const int nodes = rows_here * g.nphi;
+    // mirror: the azimuth nodes run once round the full circle from phi0 = 0, and everything below depends on the
+    // relative azimuth through cos(raa), sin^2(raa) and the folded raa / pi only (overlap, ph_r, frac, cos xi:
+    // gortt_brdf.c:23-100, 118-169, 650-666): node l' = nphi - 1 - l is the mirror image of node l.  Half the nodes
+    // are evaluated and each result is written twice (the device's cos of 2 pi - x and of x differ in the last place,
+    // as the reference's do: the images agree with their own evaluation to rounding, 1e-15).
+    const int per_row = mirror ? (g.nphi + 1) / 2 : g.nphi;
+    const int nodes = rows_here * per_row;
     for (int n = threadIdx.x; n < nodes; n += GEOM_ROW_THREADS) {
-        const int r = n / g.nphi, l = n - r * g.nphi;
+        const int r = n / per_row, l = n - r * per_row;
         const gort_canopy &c = canopies[s_member[r]];
         double vza, sza, saa, raa;
         normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
         GeomOut o;
         finish_angle(c, s_row[r], raa, o);
-        const long i = first * g.nphi + n;
+        const long i = (first + r) * g.nphi + l;
+        const int l2 = g.nphi - 1 - l;
+        const long i2 = (mirror && l2 != l) ? (first + r) * g.nphi + l2 : -1;       // the image, if the node has one
         if (compact == 2) {
             double rec[GORT_COEF_STRIDE];
             store_coef(rec, c, o);
@@ -121,19 +129,26 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
             const SunScalars sun = load_sun(rec);
             for (int b = 0; b < nw; ++b) {
                 const SunTerms t = sun_terms(L, nw, b, sun, c.k_open, c.k_openep);
-                rsurf[i * nw + b] = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t.C0, t.B, t.Z, t.G, t.T);
+                const double v = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t.C0, t.B, t.Z, t.G, t.T);
+                rsurf[i * nw + b] = v;
+                if (i2 >= 0) rsurf[i2 * nw + b] = v;
             }
         } else if (compact) {
             // LUT path: only the five expansion coefficients, one 64-B record per node
             double rec[GORT_COEF_STRIDE];
             store_coef(rec, c, o);
-            double2 *dst = reinterpret_cast<double2 *>(coef + i * 8);
-            dst[0] = make_double2(rec[A_C], rec[A_B]);
-            dst[1] = make_double2(rec[A_Z], rec[A_G]);
-            dst[2] = make_double2(rec[A_T], 0.0);
-            dst[3] = make_double2(0.0, 0.0);
+            for (int k = 0; k < 2; ++k) {
+                const long at = k ? i2 : i;
+                if (at < 0) break;
+                double2 *dst = reinterpret_cast<double2 *>(coef + at * 8);
+                dst[0] = make_double2(rec[A_C], rec[A_B]);
+                dst[1] = make_double2(rec[A_Z], rec[A_G]);
+                dst[2] = make_double2(rec[A_T], 0.0);
+                dst[3] = make_double2(0.0, 0.0);
+            }
         } else {
             store_coef(coef + i * GORT_COEF_STRIDE, c, o);
+            if (i2 >= 0) store_coef(coef + i2 * GORT_COEF_STRIDE, c, o);
         }
     }
 }
@@ -172,6 +187,15 @@ int launch_geometry_stream_fused(const gort_canopy *canopy_dev, int n_members, c
     return check_launch("geometry_stream_kernel<fused>");
 }
 
+// do the azimuth nodes of this grid run exactly once round the circle from 0 (node nphi-1-l mirrors node l)?
+// Only for grids of non-negative zeniths, where the sun azimuth of every node is the 0 of the grid's lines.
+static bool grid_mirrors(const gort_grid &g)
+{
+    static const bool on = !(getenv("GORT_GRID_MIRROR") && atoi(getenv("GORT_GRID_MIRROR")) == 0);
+    return on && g.nphi >= 3 && g.phi0 == 0.0 && g.dphi > 0.0 && g.dphi * (g.nphi - 1) == 360.0 && g.sza0 >= 0.0 && g.dsza >= 0.0 &&
+           g.vza0 >= 0.0 && g.dvza >= 0.0;
+}
+
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream)
 {
@@ -179,7 +203,7 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
     if (rows <= 0) return GORT_OK;
     hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
                        (hipStream_t)stream, canopy_dev, g, row_begin, rows, coef_dev, compact ? 1 : 0,
-                       (const double *)nullptr, 0, (double *)nullptr);
+                       (const double *)nullptr, 0, (double *)nullptr, grid_mirrors(g) ? 1 : 0);
     return check_launch("geometry_grid_kernel");
 }
 
@@ -189,7 +213,8 @@ int launch_geometry_grid_fused(const gort_canopy *canopy_dev, const double *L_de
     const long rows = row_end - row_begin;
     if (rows <= 0 || nw <= 0) return GORT_OK;
     hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
-                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, (double *)nullptr, 2, L_dev, nw, rsurf_dev);
+                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, (double *)nullptr, 2, L_dev, nw, rsurf_dev,
+                       grid_mirrors(g) ? 1 : 0);
     return check_launch("geometry_grid_kernel (fused)");
 }
 

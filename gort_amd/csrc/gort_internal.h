@@ -108,16 +108,13 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin);
 // expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the
 // call, or nullptr for the static XCD mapping.
 // Wide streams (stream_is_wide: >= 128 bands, >= 4M samples, no component spectra) have their records in layout 1 and
-// are expanded by one of two kernels that write the same bits: wide_form 1 = flat panels (expand_flat_stream_kernel),
-// 2 = LDS-resident (expand_stream_lds_kernel; stream_lds_applies() says whether the band table fits the 160 KB of LDS).
+// are expanded by expand_flat_stream_kernel (aligned flat panels).
 // grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's
 // five-term sample, so that every LUT path writes the same bits.
 long expand_stream_tail_pad_records(int nw, long nA);
 bool stream_is_wide(int nw, long nA, bool want_scomp);
-bool stream_lds_applies(int nw, long nA);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
-                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, int wide_form, void *stream,
-                         bool grid_form);
+                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream, bool grid_form);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);

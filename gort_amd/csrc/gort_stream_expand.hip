@@ -2,7 +2,9 @@
 // sun/view geometry in any order, gortt.c:232-329) from the per-line records of the geometry kernel into
 // rsurf[line][band].  Every kernel here evaluates the stream family's sample (gort_device.h: sun_pair +
 // stream_sample), so all of them write the same bits; narrow spectra take the per-sample / band-major kernels,
-// wide ones the aligned flat kernels.
+// wide ones the aligned flat-panel kernel.  (Round 3 built a second wide form - one persistent 1024-thread workgroup per
+// CU with the band constants of all 2101 bands resident in the 160 KB of LDS, short row-major tasks, records staged
+// through an LDS ring - bitwise equal and 8 % SLOWER at a million lines: profiles/r03/experiments/lds_resident_stream_kernel.md.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -228,249 +230,6 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const double *_
         flat_stream_loop<NT, false>(t, second, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
 }
 
-// ---- the LDS-resident form ------------------------------------------------------------------------------------
-// What limits expand_flat_stream_kernel is the shape of its waves, not its arithmetic: a wave must live for ~64 steps
-// to pay for deriving 24 band constants from global memory (a ~3 us dependent chain during which its slot stores
-// nothing), and 64-step panels write 13 % slower than the 6-step panels of the LUT kernel even as bare stores
-// (DESIGN.md 5.5).  gfx950 has 160 KB of LDS per CU - enough for the band constants of ALL 2101 bands - so here
-//   * ONE 1024-thread workgroup per CU stays resident for the whole launch and keeps the band table
-//     tab[9][nw] (gam, omega, Rff, Tff, tff, pff, rs, mgk, B: 151 KB for nw = 2101) in LDS;
-//   * work is cut into TASKS of 16 adjacent columns (the 16 waves of the workgroup: 16 KiB contiguous per step)
-//     x K steps (K = 16), handed out in row-major order of the output, so that the machine sweeps a compact window
-//     as the LUT kernel's short panels do; a task switch costs 18 LDS reads + ~10 instructions per lane instead of
-//     a round trip to L2/HBM;
-//   * the line records of a task (2 lines per step for nw = 2101: 16 columns span 2048 elements) are staged by the
-//     whole workgroup - one double per thread, fetched one task ahead into a register, parked in an LDS ring - and
-//     reach the lanes as LDS broadcasts: no scalar loads in the loop, and the line terms arrive in VGPRs, which
-//     lifts the one-SGPR-per-VOP3 limit off the sample's FMAs;
-//   * one workgroup barrier per task keeps the 16 waves - the 16 KiB they write per step - together.
-// The arithmetic is flat_stream_step() of the flat kernel on the same records and the same band constants (Zf, Tf
-// re-derived from tff and mgk exactly as lambda_table_kernel forms them): the same bits.
-constexpr int LDS_THREADS = 1024;
-constexpr int LDS_WAVES = LDS_THREADS / 64;
-constexpr int LDS_TAB_SLOTS = 9;
-constexpr int LDS_REC = 14;              // doubles per staged record: 13 LineTerms + 1 pad (rows stay 16-B aligned)
-constexpr size_t LDS_MAX_BYTES = 160u * 1024u;
-
-// One step of a wave's task.  The line terms come out of the LDS ring: in waves whose chunk lies inside one line a
-// broadcast of that line's record; in the ~6 % of waves whose band index wraps inside the chunk each element reads the
-// record of ITS line (a per-lane LDS address: two distinct rows, no bank conflict) - no second sample, no select.
-// MODE (experiments only, GORT_STREAM_LDS_MODE): 0 = the kernel; 1 = arithmetic without stores; 2 = stores of a trivial value;
-// 3 = no workgroup barrier between tasks (races on the record ring: wrong results, timing only)
-template <bool NT, bool WRAP, int MODE>
-__device__ __forceinline__ void lds_step(const StreamBand (&t)[EPL], const bool (&second)[EPL], const double *ring, bool front,
-                                         bool back, int first_off, int last_off, double *__restrict__ o, int lane)
-{
-    double v[EPL];
-    if (MODE == 2) {
-        v[0] = ring[0] + t[0].B;
-        v[1] = ring[0] + t[1].B;
-    } else if (!WRAP) {
-        double r[LINE_NTERMS];
-#pragma unroll
-        for (int q = 0; q < LINE_NTERMS; ++q) r[q] = ring[q];
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            double pdf, tpdf;
-            sun_pair(t[j], r[9], r[10], r[11], r[12], pdf, tpdf);
-            v[j] = stream_sample(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], t[j], pdf, tpdf);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const double *rj = ring + (second[j] ? LDS_REC : 0);
-            double r[LINE_NTERMS];
-#pragma unroll
-            for (int q = 0; q < LINE_NTERMS; ++q) r[q] = rj[q];
-            double pdf, tpdf;
-            sun_pair(t[j], r[9], r[10], r[11], r[12], pdf, tpdf);
-            v[j] = stream_sample(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], t[j], pdf, tpdf);
-        }
-    }
-    if (MODE == 1) {
-        if (v[0] == -12345.678 && v[1] == 9.87e300) o[0] = v[0];      // never true: keeps the arithmetic alive
-    } else {
-        store_chunk_pair<NT>(v, front, back, first_off, last_off, o, lane);
-    }
-}
-
-// the steps of a task at the edges of the output, or cut short by its end: any count, edge handling per step
-template <bool NT, bool WRAP, int MODE>
-__device__ __forceinline__ void lds_task_steps(const StreamBand (&t)[EPL], const bool (&second)[EPL], int first_off,
-                                               int last_step, int last_off, long step, int k_wave,
-                                               const double *ring, int ring_step, double *__restrict__ out_w, int lane)
-{
-    double *o = out_w + EPL * lane;
-#pragma unroll 1
-    for (int kk = 0; kk < k_wave; ++kk) {
-        lds_step<NT, WRAP, MODE>(t, second, ring, kk == 0 && first_off > 0, kk == last_step, first_off, last_off, o, lane);
-        ring += ring_step;
-        o += step;
-    }
-}
-
-// the steps of an interior task: exactly KFULL steps of exactly one vector store each, unrolled - straight-line code in
-// which the compiler can COUNT the stores.  That matters for more than loop overhead: the staged records of the next
-// task are a vector load issued in front of these stores, loads and stores share one in-order counter on gfx9, and
-// behind a loop of unknown length the compiler can only wait for `vmcnt(0)` before the value is used - i.e. for
-// every store of the task to be acknowledged by memory (~2 us, once per task and wave); here it waits for vmcnt(KFULL).
-template <bool NT, bool WRAP, int MODE, int KFULL>
-__device__ __forceinline__ void lds_task_full(const StreamBand (&t)[EPL], const bool (&second)[EPL], long step, const double *ring,
-                                              int ring_step, double *__restrict__ out_w, int lane)
-{
-    double *o = out_w + EPL * lane;
-#pragma unroll
-    for (int kk = 0; kk < KFULL; ++kk) {
-        lds_step<NT, WRAP, MODE>(t, second, ring, false, false, 0, 0, o, lane);
-        ring += ring_step;
-        o += step;
-    }
-}
-
-template <bool NT, int MODE, int KFULL>
-__global__ __launch_bounds__(LDS_THREADS) void expand_stream_lds_kernel(
-    const gort_canopy *__restrict__ canopy, const double *__restrict__ L, int nw, const double *__restrict__ coef, long nA,
-    long n_total, int shift, long stride_chunks, int da, int K, int npl, int groups, long n_tasks,
-    FastDiv div_nw, FastDiv div_groups, double *__restrict__ out, int xcd_split)
-{
-    extern __shared__ double s_mem[];
-    // the tasks of this workgroup: task = (row block jb, column group cg), jb-major
-    long task, task_end, task_step;
-    if (xcd_split) {                 // every XCD one contiguous eighth of the tasks, dealt round-robin to its workgroups
-        const long x = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
-        task = n_tasks * x / 8 + q;
-        task_end = n_tasks * (x + 1) / 8;
-        task_step = nq;
-    } else {
-        task = blockIdx.x;
-        task_end = n_tasks;
-        task_step = gridDim.x;
-    }
-    if (task >= task_end) return;                       // the whole workgroup
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tab_doubles = (LDS_TAB_SLOTS * nw + 1) & ~1;
-    double *s_tab = s_mem;                              // [9][nw]
-    double *s_ring = s_mem + tab_doubles;               // [2][K][npl][LDS_REC] + a dump row of 64
-    const int ring_doubles = K * npl * LDS_REC;
-    for (int i = tid; i < 8 * nw; i += LDS_THREADS) s_tab[i] = L[i];                       // L slots 0..7 = gam .. mgk
-    for (int i = tid; i < nw; i += LDS_THREADS) s_tab[8 * nw + i] = L[L_B * nw + i];
-    const double kep = canopy->k_openep, kopen = canopy->k_open + canopy->k_openep;       // as lambda_table_kernel
-
-    const unsigned stride = (unsigned)stride_chunks;
-    const long step = stride_chunks * CHUNK;            // elements per step = da * nw
-    const long last = n_total - 1 + shift;
-    const long last_chunk = last / CHUNK;
-    const int last_off = (int)(last % CHUNK);
-
-    // this thread's share of a task's records: double q of the record of line a_min + k da + p.  EVERY thread loads
-    // and parks a value for every task (threads beyond the K npl 13 needed ones re-read element 0 and park it in a
-    // dump row behind the ring; a workgroup without a next task re-reads its last one): unconditional, so that the
-    // compiler sees one load and one use per task on every path and never has to guess what is still pending
-    const int n_stage = K * npl * LINE_NTERMS;
-    const bool stages = tid < n_stage;
-    int st_line = 0, st_q = 0, st_ring = 0;
-    if (stages) {
-        const int k = tid / (npl * LINE_NTERMS), r = tid - k * (npl * LINE_NTERMS), p = r / LINE_NTERMS;
-        st_q = r - p * LINE_NTERMS;
-        st_line = k * da + p;
-        st_ring = (k * npl + p) * LDS_REC + st_q;
-    }
-    // first line of a task: that of its first column's chunk at step 0 (>= -1: the pad record in front)
-    auto task_first_line = [&](long tk, unsigned &jb, unsigned &cg) -> long {
-        jb = fast_div((unsigned)tk, div_groups);
-        cg = (unsigned)tk - jb * (unsigned)groups;
-        const unsigned local0 = cg * LDS_WAVES * CHUNK + (unsigned)step - (unsigned)shift;
-        return (long)jb * K * da + fast_div(local0, div_nw) - da;
-    };
-    auto fetch = [&](long tk) -> double {
-        unsigned jb, cg;
-        long line = task_first_line(tk, jb, cg) + st_line;
-        if (line > nA) line = nA;                       // beyond the stream: a pad record, never used by a stored element
-        return coef[line * GORT_COEF_STRIDE + st_q];
-    };
-    // ring offset of this thread's value in buffer b: staging threads into the ring, the others into the dump row
-    auto park_at = [&](int b) -> int { return stages ? b * ring_doubles + st_ring : 2 * ring_doubles + lane; };
-    s_ring[park_at(0)] = fetch(task);
-    __syncthreads();
-
-    int buf = 0;
-    for (; task < task_end; task += task_step, buf ^= 1) {
-        const bool more = task + task_step < task_end;
-        const double nxt = fetch(more ? task + task_step : task);         // in flight while this task is worked on
-        const int park = park_at(buf ^ 1);
-        bool parked = false;
-        unsigned jb, cg;
-        const long a_min = task_first_line(task, jb, cg);
-        const unsigned w = cg * LDS_WAVES + (unsigned)wave;               // this wave's column
-        const long c0 = (long)jb * K * stride_chunks + w;
-        if (__builtin_amdgcn_readfirstlane((int)(w < stride && c0 <= last_chunk))) {
-            // index arithmetic of expand_flat_stream_kernel with panel = jb, steps_per_wave = K
-            const long e0 = c0 * CHUNK - shift;
-            const unsigned local = w * CHUNK + (unsigned)step - (unsigned)shift;
-            const unsigned a_loc = fast_div(local, div_nw);
-            // (everything here is wave-uniform; the readfirstlanes say so to the compiler, which otherwise predicates the
-            // branches below instead of jumping - and then cannot count the stores between a load and its use)
-            const int band_w = __builtin_amdgcn_readfirstlane((int)(local - a_loc * (unsigned)nw));
-            const long a_w = (long)jb * K * da + a_loc - da;
-            const long rel = last_chunk - c0;
-            int k_wave = K, last_step = -1;
-            if (rel < (long)K * stride_chunks) {             // only the last row block's waves run out of stream
-                const unsigned k_last = (unsigned)(rel / stride_chunks);
-                k_wave = (int)k_last + 1;
-                if ((unsigned long)rel == (unsigned long)k_last * stride) last_step = (int)k_last;
-            }
-            k_wave = __builtin_amdgcn_readfirstlane(k_wave);
-            last_step = __builtin_amdgcn_readfirstlane(last_step);
-            const int first_off = __builtin_amdgcn_readfirstlane(c0 == 0 ? shift : 0);
-            StreamBand t[EPL];
-            bool second[EPL];
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-#pragma clang fp contract(off)
-                int band = band_w + EPL * lane + j;
-                second[j] = band >= nw;
-                if (second[j]) band -= nw;
-                BandTerms bt;
-                bt.gam = s_tab[band];            bt.omega = s_tab[nw + band];      bt.Rff = s_tab[2 * nw + band];
-                bt.Tff = s_tab[3 * nw + band];   bt.tff = s_tab[4 * nw + band];    bt.pff = s_tab[5 * nw + band];
-                bt.rs = s_tab[6 * nw + band];    bt.mgk = s_tab[7 * nw + band];    bt.B = s_tab[8 * nw + band];
-                const double tpff = tpff_of(bt.tff, kopen);
-                bt.Zf = (tpff - kep) * bt.rs;
-                bt.Tf = tpff * bt.mgk;
-                t[j] = stream_band(bt);
-            }
-            const double *ring = s_ring + buf * ring_doubles + __builtin_amdgcn_readfirstlane((int)(a_w - a_min)) * LDS_REC;
-            double *out_w = out + e0;
-            const bool wraps = band_w + CHUNK - 1 >= nw;
-            if (K == KFULL && k_wave == KFULL && first_off == 0 && last_step < 0) {
-                // the next task's records are parked in the ring right behind the stores, in the same block of
-                // straight-line code: a counted wait (vmcnt(KFULL)), not a wait for the stores themselves
-                // (the asm comments keep the three identical ring writes from being merged into one block, which would be
-                // entered from the counted and the uncounted paths alike)
-                if (wraps) {
-                    lds_task_full<NT, true, MODE, KFULL>(t, second, step, ring, npl * LDS_REC, out_w, lane);
-                    asm volatile("; records of the next task parked behind KFULL counted stores (wrap)" ::: "memory");
-                    s_ring[park] = nxt;
-                    asm volatile("; parked (wrap)" ::: "memory");
-                } else {
-                    lds_task_full<NT, false, MODE, KFULL>(t, second, step, ring, npl * LDS_REC, out_w, lane);
-                    asm volatile("; records of the next task parked behind KFULL counted stores" ::: "memory");
-                    s_ring[park] = nxt;
-                    asm volatile("; parked" ::: "memory");
-                }
-                parked = true;
-            } else if (wraps) {
-                lds_task_steps<NT, true, MODE>(t, second, first_off, last_step, last_off, step, k_wave, ring, npl * LDS_REC, out_w, lane);
-            } else {
-                lds_task_steps<NT, false, MODE>(t, second, first_off, last_step, last_off, step, k_wave, ring, npl * LDS_REC, out_w, lane);
-            }
-        }
-        if (!parked) s_ring[park] = nxt;
-        if (MODE != 3) __syncthreads();                 // MODE 3 (experiment, WRONG results): how much the lockstep costs
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------- launchers
@@ -507,40 +266,6 @@ static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
     if (chunks / 6 < target) target = chunks / 6 < 4202 ? 4202 : chunks / 6;
     *stride = flat_stride(nw, chunks, target);
     *steps = tune.stream_steps;
-}
-
-// shape of the LDS-resident form: 16-column groups of a ~2048-chunk stride, K steps per task; false = not applicable
-// (band table + record ring beyond the 160 KB of LDS: nw > ~2130)
-struct LdsShape {
-    long stride, n_tasks;
-    int K, npl, groups, da;
-    size_t lds_bytes;
-};
-static bool stream_lds_shape(int nw, long chunks, LdsShape *s)
-{
-    static const int env_k = getenv("GORT_STREAM_LDS_STEPS") ? atoi(getenv("GORT_STREAM_LDS_STEPS")) : 0;
-    s->stride = flat_stride(nw, chunks, 2048);
-    s->da = (int)(s->stride * CHUNK / nw);
-    s->npl = 2 + (LDS_WAVES * CHUNK - 2) / nw;           // lines a 16-column step can touch
-    const long rows = (chunks + s->stride - 1) / s->stride;      // steps per column over the whole stream
-    int K = env_k > 0 ? env_k : 16;
-    const int k_max = K;                                 // what the LDS budget is checked with: the verdict must not depend on the stream's length
-    // short streams: smaller tasks, so that every workgroup still gets a few dozen of them
-    while (!env_k && K > 4 && (rows / K) * ((s->stride + LDS_WAVES - 1) / LDS_WAVES) < 24 * 256) K /= 2;
-    while (K > 1 && K * s->npl * LINE_NTERMS > LDS_THREADS) --K;
-    if (K * s->npl * LINE_NTERMS > LDS_THREADS) return false;
-    s->K = K;
-    s->groups = (int)((s->stride + LDS_WAVES - 1) / LDS_WAVES);
-    s->n_tasks = ((rows + K - 1) / K) * s->groups;
-    s->lds_bytes = sizeof(double) * (size_t)(((LDS_TAB_SLOTS * nw + 1) & ~1) + 2 * K * s->npl * LDS_REC + 64);
-    const size_t worst = sizeof(double) * (size_t)(((LDS_TAB_SLOTS * nw + 1) & ~1) + 2 * k_max * s->npl * LDS_REC + 64);
-    return worst <= LDS_MAX_BYTES && s->n_tasks < (1L << 31) && (long)s->groups * LDS_WAVES * CHUNK < (1L << 30);
-}
-
-bool stream_lds_applies(int nw, long nA)
-{
-    LdsShape s;
-    return stream_lds_shape(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK, &s);
 }
 
 // readable records the wide expansions may touch behind the last line (the caller also keeps ONE in front)
@@ -587,68 +312,17 @@ static int launch_expand_stream_flat(const double *L_dev, int nw, const double *
     return check_launch("expand_flat_stream_kernel");
 }
 
-// workgroups of the persistent form: one per CU (a workgroup owns a CU's LDS), a multiple of 8 for the XCD split
-static int lds_workgroups()
-{
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus < 8)
-            cus = 8;
-        if (const char *v = getenv("GORT_STREAM_LDS_WGS")) cus = atoi(v) >= 8 ? atoi(v) : cus;
-        n = cus / 8 * 8;
-    }
-    return n;
-}
-
-static int launch_expand_stream_lds(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev,
-                                    long nA, double *rsurf_dev, hipStream_t s)
-{
-    static const bool xcd_split = !(getenv("GORT_STREAM_LDS_SPLIT") && atoi(getenv("GORT_STREAM_LDS_SPLIT")) == 0);
-    const long n_total = nA * (long)nw;
-    const int shift = (int)((reinterpret_cast<uintptr_t>(rsurf_dev) / sizeof(double)) % CHUNK);
-    const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
-    LdsShape sh;
-    if (!stream_lds_shape(nw, chunks, &sh)) return fail(GORT_EINVAL, "stream expansion: %d bands do not fit the LDS-resident form", nw);
-    if (chunks >= (1L << 31) || sh.stride * CHUNK >= (1L << 30))
-        return fail(GORT_EINVAL, "stream expansion: %ld chunks are beyond the kernel's 32-bit indices", chunks);
-    static const int mode = getenv("GORT_STREAM_LDS_MODE") ? atoi(getenv("GORT_STREAM_LDS_MODE")) : 0;     // experiments
-    const bool nt = tuning().nt;
-    typedef void (*kern_t)(const gort_canopy *, const double *, int, const double *, long, long, int, long, int, int, int, int, long,
-                           FastDiv, FastDiv, double *, int);
-    const bool k8 = sh.K == 8;                                // interior tasks unrolled for K = 16 (default) or 8 (short streams)
-    const kern_t fn = mode == 1 ? (kern_t)expand_stream_lds_kernel<true, 1, 16>
-                      : mode == 2 ? (kern_t)expand_stream_lds_kernel<true, 2, 16>
-                      : mode == 3 ? (kern_t)expand_stream_lds_kernel<true, 3, 16>
-                      : nt ? (k8 ? (kern_t)expand_stream_lds_kernel<true, 0, 8> : (kern_t)expand_stream_lds_kernel<true, 0, 16>)
-                           : (k8 ? (kern_t)expand_stream_lds_kernel<false, 0, 8> : (kern_t)expand_stream_lds_kernel<false, 0, 16>);
-    // the full 160 KB of a CU for one workgroup (harmless where the default limit already allows it)
-    (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX_BYTES);
-    (void)hipGetLastError();
-    long wgs = lds_workgroups();
-    const bool split = xcd_split && sh.n_tasks >= 8 * wgs;
-    if (!split && sh.n_tasks < wgs) wgs = sh.n_tasks;
-    hipLaunchKernelGGL(fn, dim3((unsigned)wgs), dim3(LDS_THREADS), sh.lds_bytes, s, canopy_dev, L_dev, nw, coef_dev, nA, n_total,
-                       shift, sh.stride, sh.da, sh.K, sh.npl, sh.groups, sh.n_tasks, make_fast_div((unsigned)nw),
-                       make_fast_div((unsigned)sh.groups), rsurf_dev, split ? 1 : 0);
-    return check_launch("expand_stream_lds_kernel");
-}
-
 // coef_dev: stream records with ONE readable pad record in front and expand_stream_tail_pad_records() behind the last
-// line; wide streams (stream_is_wide): records in layout 1, wide_form 1 = flat panels, 2 = LDS-resident.
+// line; wide streams (stream_is_wide): records in layout 1, the flat-panel kernel.
 // grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's sample.
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
-                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, int wide_form, void *stream,
-                         bool grid_form)
+                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream, bool grid_form)
 {
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (!grid_form && stream_is_wide(nw, nA, scomp_dev != nullptr)) {
-        if (wide_form == 2) return launch_expand_stream_lds(canopy_dev, L_dev, nw, coef_dev, nA, rsurf_dev, s);
+    if (!grid_form && stream_is_wide(nw, nA, scomp_dev != nullptr))
         return launch_expand_stream_flat(L_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, s);
-    }
     const long groups = (nA + STREAM_LINES - 1) / STREAM_LINES;
     if (nw >= 64 && groups <= 65535) {
         const dim3 grid((unsigned)((nw + 255) / 256), (unsigned)groups), block(256);

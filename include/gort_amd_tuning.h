@@ -22,12 +22,10 @@ double gort_engine_last_expand_ms(gort_engine *e);
 /* duration (ms) of the expansion stage of the last gort_rsurf_stream[_dev] call; <0 if none */
 double gort_engine_last_stream_ms(gort_engine *e);
 
-/* ---- kernel form of wide streams (>= 4M samples, >= 128 bands, no component spectra) ----
- * Two kernels write the same bits: 1 = flat panels (expand_flat_stream_kernel: waves of 64 steps that derive their
- * band constants from global memory), 2 = LDS-resident (expand_stream_lds_kernel: one persistent workgroup per CU
- * with the band table of all bands in the 160 KB of LDS; needs nw <= ~2130).  0 = automatic (2 where it applies).
- * Also GORT_STREAM_FORM=0|1|2.  gort_engine_stream_form: form of the last stream call, 0 = a narrow-stream kernel. */
-int  gort_engine_set_stream_form(gort_engine *e, int form);
+/* ---- which kernel family expanded the last gort_rsurf_stream[_dev] call ----
+ * 0 = a narrow-stream kernel (per sample / band-major / fused with the geometry), 1 = the aligned flat-panel kernel
+ * (expand_flat_stream_kernel: >= 4M samples, >= 128 bands, no component spectra).  All of them write the same bits;
+ * tests use this to know which one they have compared. */
 int  gort_engine_stream_form(gort_engine *e);
 
 /* ---- XCDs ---- */

@@ -206,7 +206,6 @@ def test_error_codes_are_negative_and_null_handles_fail_cleanly():
     L = api.lib()
     assert L.gort_engine_xcd_mapping(None) == api.EINVAL
     assert L.gort_engine_stream_form(None) == api.EINVAL
-    assert L.gort_engine_set_stream_form(None, 1) == api.EINVAL
     assert L.gort_engine_last_stream_ms(None) < 0
     assert L.gort_engine_synchronize(None) == api.EINVAL
     w = (C.c_int * 8)()

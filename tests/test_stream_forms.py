@@ -1,7 +1,7 @@
-"""The two kernels of the wide-stream expansion (gort_amd/csrc/gort_stream_expand.hip) - flat panels of long waves
-and the LDS-resident form (one persistent workgroup per CU, band table in LDS) - must write the SAME BITS (as must the
-narrow stream kernels: tests/test_pipe_and_cli.py compares chunked with whole streams), agree with the LUT path on grid
-angles to rounding and with the oracle to 1e-9.
+"""The kernels of the stream expansion (gort_amd/csrc/gort_stream_expand.hip) - the aligned flat-panel kernel of wide
+streams, the band-major and per-sample kernels of narrow ones, the launch fused with the geometry for a few bands -
+must write the SAME BITS for the same lines, agree with the LUT path on grid angles to rounding and with the oracle to
+1e-9.  A wide stream cut into pieces of less than 4M samples goes through the narrow kernels: that is the comparison.
 
 Reference interface: the per-line loop of main(), gortt.c:232-329 (+ gortt_rsurf, gortt.c:385-578)."""
 import os
@@ -34,17 +34,21 @@ def setup():
     eng.close()
 
 
-def _run(eng, torch, ang, nw, lds, out=None):
+def _run(eng, torch, ang, nw, pieces=False, out=None):
+    """The stream in ONE call (wide kernel where it applies), or cut into pieces below the wide kernel's threshold."""
     a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
+    n = ang.shape[0]
     if out is None:
-        out = torch.full((ang.shape[0], nw), -7.0, dtype=torch.float64, device="cuda")
-    eng.set_stream_form("lds" if lds else "flat")
+        out = torch.full((n, nw), -7.0, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
-    eng.rsurf_stream_dev(a, out)
+    forms = set()
+    step = n if not pieces else max(1, ((1 << 22) - 1) // nw)
+    for i in range(0, n, step):
+        eng.rsurf_stream_dev(a[i:i + step], out[i:i + step])
+        forms.add(eng.stream_form())
     eng.synchronize()
-    form = eng.stream_form()
-    eng.set_stream_form("auto")
-    return out, form
+    assert len(forms) == 1, forms
+    return out, forms.pop()
 
 
 def _bits_equal(x, y):
@@ -56,8 +60,8 @@ def _lines(rng, n, sza_pool):
     return np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), sza, rng.uniform(-400, 400, n)], 1)
 
 
-def test_lds_form_equals_flat_form_bitwise_and_oracle(setup):
-    """70 001 lines (ragged last task) x 2101 bands, 91 integer sun zeniths in random order, some of them negative
+def test_flat_kernel_equals_narrow_kernels_bitwise_and_oracle(setup):
+    """70 001 lines (ragged last panel) x 2101 bands, 91 integer sun zeniths in random order, some of them negative
     (zenith -> |zenith|, azimuth + 180)."""
     eng, c, torch = setup
     rng = np.random.default_rng(91)
@@ -66,14 +70,11 @@ def test_lds_form_equals_flat_form_bitwise_and_oracle(setup):
     eng.set_spectra(rs, rl, tl)
     pool = np.concatenate([np.arange(0.0, 90.0), -np.arange(1.0, 45.0)])
     ang = _lines(rng, 70001, pool)
-    g, form_g = _run(eng, torch, ang, wl.size, True)
-    assert form_g == "lds"
-    p, form_p = _run(eng, torch, ang, wl.size, False)
-    assert form_p == "flat"
+    g, form_g = _run(eng, torch, ang, wl.size)
+    assert form_g == "flat"
+    p, form_p = _run(eng, torch, ang, wl.size, pieces=True)
+    assert form_p == "narrow"
     assert _bits_equal(g, p)
-    eng.rsurf_stream_dev(torch.as_tensor(np.ascontiguousarray(ang), device="cuda"), p)
-    eng.synchronize()
-    assert eng.stream_form() == "lds"                    # the default for a full spectrum
     idx = np.sort(rng.choice(ang.shape[0], 40, replace=False))
     idx[0], idx[-1] = 0, ang.shape[0] - 1
     ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[idx], rs, rl, tl, want_K=False)
@@ -81,22 +82,22 @@ def test_lds_form_equals_flat_form_bitwise_and_oracle(setup):
     assert relerr(got, ref, floor=1e-12) <= REGRESSION
 
 
-@pytest.mark.parametrize("nw", [128, 129, 143, 144, 1000, 1999, 2048, 2101, 2130])
-def test_lds_form_band_counts_and_output_alignments(setup, nw):
-    """Band counts with every gcd(nw, 128) (columns of 1..128 chunk strides, 2..17 lines per 16-column step), the
-    last task ragged, the output itself starting off a 1-KiB chunk boundary (front and back edge handling)."""
+@pytest.mark.parametrize("nw", [128, 129, 143, 144, 1000, 1999, 2048, 3000])
+def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
+    """Band counts with every gcd(nw, 128) (wave strides of 1..128 chunk columns), the last panel ragged, the output
+    itself starting off a 1-KiB chunk boundary (front and back edge handling)."""
     eng, c, torch = setup
     rng = np.random.default_rng(nw)
     wl = np.linspace(400.0, 2500.0, nw)
     eng.set_spectra(*api.spectra(wl))
     n = (1 << 22) // nw + 4097
     ang = _lines(rng, n, np.array([0.0, 12.5, 30.0, 47.25, 60.0, 75.0, 88.0]))
+    p, form = _run(eng, torch, ang, nw, pieces=True)
+    assert form == "narrow"
     for offset in (0, 1, 5, 16):                         # doubles in front of the output
         buf = torch.full((n * nw + 32,), -7.0, dtype=torch.float64, device="cuda")
         out = buf[offset:offset + n * nw].view(n, nw)
-        g, form = _run(eng, torch, ang, nw, True, out)
-        assert form == "lds"
-        p, form = _run(eng, torch, ang, nw, False)
+        g, form = _run(eng, torch, ang, nw, out=out)
         assert form == "flat"
         assert _bits_equal(g, p), (nw, offset)
         assert float(buf[:offset].min() if offset else -7.0) == -7.0 and float(buf[offset + n * nw:].max()) == -7.0
@@ -104,7 +105,7 @@ def test_lds_form_band_counts_and_output_alignments(setup, nw):
 
 def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
     """A principal-plane style stream (ONE sun zenith, 300 000 lines), with lines beyond the horizon and NaN zeniths,
-    which give NaN rows in both forms."""
+    which give NaN rows whatever the kernel."""
     eng, c, torch = setup
     rng = np.random.default_rng(7)
     wl = np.linspace(400.0, 2500.0, 300)
@@ -115,9 +116,9 @@ def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
     ang[rng.choice(n, 50, replace=False), 2] = 95.0
     ang[rng.choice(n, 50, replace=False), 2] = np.nan
     ang[rng.choice(n, 50, replace=False), 0] = 90.0
-    g, form = _run(eng, torch, ang, wl.size, True)
-    assert form == "lds"
-    p, _ = _run(eng, torch, ang, wl.size, False)
+    g, form = _run(eng, torch, ang, wl.size)
+    assert form == "flat"
+    p, _ = _run(eng, torch, ang, wl.size, pieces=True)
     assert _bits_equal(g, p)
     bad = np.isnan(ang[:, 2]) | (np.abs(ang[:, 2]) > 90) | (np.abs(ang[:, 0]) >= 90)
     nan_rows = torch.isnan(g).all(dim=1).cpu().numpy()
@@ -125,23 +126,6 @@ def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
     idx = np.flatnonzero(~bad)[:25]
     ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[idx], rs, rl, tl, want_K=False)
     assert relerr(g[torch.as_tensor(idx, device="cuda")].cpu().numpy(), ref, floor=1e-12) <= REGRESSION
-
-
-def test_band_table_beyond_the_lds_falls_back_to_the_flat_form(setup):
-    """3000 bands x 9 constants do not fit a CU's 160 KB: the flat form runs whatever was asked for; streams below
-    4M samples take the narrow kernels."""
-    eng, c, torch = setup
-    rng = np.random.default_rng(3)
-    wl = np.linspace(400.0, 2500.0, 3000)
-    rs, rl, tl = api.spectra(wl)
-    eng.set_spectra(rs, rl, tl)
-    ang = _lines(rng, 3000, np.linspace(0.0, 89.0, 129))
-    g, form = _run(eng, torch, ang, wl.size, True)
-    assert form == "flat"
-    ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[:20], rs, rl, tl, want_K=False)
-    assert relerr(g[:20].cpu().numpy(), ref, floor=1e-12) <= REGRESSION
-    g, form = _run(eng, torch, ang[:1000], wl.size, True)
-    assert form == "narrow"
 
 
 def test_grid_lines_through_the_stream_equal_the_lut(setup):
@@ -158,10 +142,9 @@ def test_grid_lines_through_the_stream_equal_the_lut(setup):
     eng.synchronize()
     rows = np.arange(r0, r1)
     ang = np.array([[float(r % 91), float(l), float(r // 91), 0.0] for r in rows for l in range(361)])
-    for lds in (True, False):
-        s, form = _run(eng, torch, ang, wl.size, lds)
-        assert form == ("lds" if lds else "flat")
-        assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13
+    s, form = _run(eng, torch, ang, wl.size)
+    assert form == "flat"
+    assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13
 
 
 @pytest.mark.parametrize("nw", [1, 4, 16, 17])

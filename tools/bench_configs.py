@@ -45,8 +45,8 @@ t = best(lambda: eng.energy_stream_dev(sza, en), eng)
 print("C4  91 sun zeniths x 2101 bands  : %8.1f us  = %.3e BRDF evaluations/s equivalent (91 x 512 nodes x 2101 bands); "
       "the reference needs 512 rsurf calls per (sun zenith, band)" % (t * 1e6, 91 * 512 * wl.size / t))
 
-# stream entry point at full spectrum: 65 536 random lines x 2101 bands, (a) 91 distinct sun zeniths (lines grouped by
-# sun zenith on the device), (b) every line its own sun zenith (per-line sun terms)
+# stream entry point at full spectrum: 65 536 random lines x 2101 bands, (a) 91 distinct sun zeniths, (b) every line
+# its own sun zenith (the same kernel either way: per-line sun terms)
 rng = np.random.default_rng(0)
 n = 65536
 o2 = torch.empty((n, wl.size), dtype=torch.float64, device="cuda")

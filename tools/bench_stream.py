@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """The arbitrary-angle stream (gortt.c:232-329) on device-resident buffers: N random lines x 2101 bands, with
-91 distinct sun zeniths, every line its own sun zenith, one sun zenith, ...; each through the LDS-resident kernel (the
-default) and through the flat-panel kernel (include/gort_amd_tuning.h).
+91 distinct sun zeniths, every line its own sun zenith, one sun zenith, ... (the flat-panel kernel, include/gort_amd_tuning.h).
 Prints, per case, the time of the expansion stage (HIP events on the engine's stream), the whole call (geometry included, wall clock around a stream synchronisation), the samples/s
 and the fraction of the 8 TB/s HBM peak at 8 B per sample + 32 B per line."""
 import os, sys, time
@@ -36,10 +35,8 @@ for name, sza in cases.items():
     if only and not any(o in name for o in only.split(",")):
         continue
     a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), sza, np.zeros(n)], 1), device="cuda")
-    for grouping in (2, 1):                                 # 2 = LDS-resident (the default), 1 = flat panels
-        if os.environ.get("BENCH_STREAM_MODES") and str(grouping) not in os.environ["BENCH_STREAM_MODES"]:
-            continue
-        eng.set_stream_form(grouping)
+    for grouping in (1,):
+
         for _ in range(3):
             eng.rsurf_stream_dev(a, out)
         eng.synchronize()
@@ -66,4 +63,3 @@ for name, sza in cases.items():
                     "roofline": {"bound": "hbm", "kernel": "expansion stage (HIP events on the engine's stream)", "achieved": byts / e / 1e9,
                                  "peak": 8000.0, "unit": "GB/s", "frac": byts / e / 8e12, "kernel_ms": e * 1e3,
                                  "algorithmic_bytes_per_launch": byts, "traffic": None}}) + "\n")
-eng.set_stream_form(0)

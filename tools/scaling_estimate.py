@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """What one rank of an N-way strong-scaling run does, measured on ONE GPU: the metric grid's rows are cut with
-gort_amd.shard.row_slab exactly as bench.py does, rank 0's and the last rank's slabs are stepped back to back
-(no per-step sync, as in bench.py) and the implied efficiency t(1) / (N t(N)) is printed.  No communication is
-involved in the timed step of bench.py, so this is the whole per-rank cost bar the RCCL barrier."""
+gort_amd.shard.row_slab exactly as bench.py does, the slabs of rank 0, N/2 and N-1 are stepped back to back INTO THEIR
+WINDOW OF THE GATHERABLE BUFFER (gort_lut_alloc, window = the slab: bench.py's layout), once on a plain first
+allocation (max_draws 1) and once on the allocator's pick (max_draws 3), and the implied efficiency t(1) / (N t(N)) is
+printed for both.  No communication is involved in the timed step of bench.py, so this is the whole per-rank cost bar
+the RCCL barrier.  An ESTIMATE from one GPU, not a scaling measurement."""
 import os
 import sys
 import time
@@ -10,9 +12,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch  # noqa: E402
 from gort_amd import api  # noqa: E402
-from gort_amd.shard import pick_fastest_slab, row_slab  # noqa: E402
+from gort_amd.shard import gatherable_rows, row_slab  # noqa: E402
 
 
 def main():
@@ -25,33 +26,37 @@ def main():
     eng.set_spectra(rs, rl, tl)
     grid = api.hemisphere_grid()
     rows = grid.nsza * grid.nvza
-    t1 = None
+    t1 = {}
+    row_elems = grid.nphi * wl.size
     for world in (1, 2, 4, 8):
-        worst = 0.0
+        worst = {1: 0.0, 3: 0.0}
         for rank in sorted({0, world // 2, world - 1}):
             r0, r1 = row_slab(rank, world, rows)
-            cands = int(os.environ.get("CANDIDATES", "3"))
-            lut, cand_ms = pick_fastest_slab(eng, grid, r0, r1, wl.size, candidates=cands)
-            for _ in range(5):
-                eng.rsurf_grid_dev(grid, r0, r1, lut)
-            eng.synchronize()
-            eng.last_expand_ms()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                eng.rsurf_grid_dev(grid, r0, r1, lut)
-            eng.synchronize()
-            ms = (time.perf_counter() - t0) * 1e3 / steps
-            k = eng.last_expand_ms()
-            gb = (r1 - r0) * grid.nphi * wl.size * 8 / 1e9
-            print("N=%d rank %d rows [%d,%d) %.2f GB: %.3f ms/step, expand kernel %.3f ms (%.0f GB/s), other %.3f ms; candidates %s"
-                  % (world, rank, r0, r1, gb, ms, k, gb / k * 1e3, ms - k, " | ".join("%s -> %.3f" % (" ".join("%.3f" % x for x in a["probe_ms"]), a["verified_ms"]) for a in cand_ms)), flush=True)
-            worst = max(worst, ms)
-            del lut
-            torch.cuda.empty_cache()
-        if world == 1:
-            t1 = worst
-        print("  -> N=%d: slowest rank %.3f ms/step, implied strong-scaling efficiency %.3f" % (world, worst, t1 / (world * worst)),
-              flush=True)
+            win = (r0 * row_elems, (r1 - r0) * row_elems)
+            for draws in (1, 3):
+                buf = eng.lut_alloc(gatherable_rows(world, rows) * row_elems, window=win, max_draws=draws)
+                ptr = buf.at(win[0])
+                for _ in range(5):
+                    eng.rsurf_grid_dev(grid, r0, r1, ptr)
+                eng.synchronize()
+                eng.last_expand_ms()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    eng.rsurf_grid_dev(grid, r0, r1, ptr)
+                eng.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3 / steps
+                k = eng.last_expand_ms()
+                gb = win[1] * 8 / 1e9
+                print("N=%d rank %d rows [%d,%d) %.2f GB, max_draws %d: %.3f ms/step, expand kernel %.3f ms (%.0f GB/s), other %.3f ms; probe GB/s %s picked %d"
+                      % (world, rank, r0, r1, gb, draws, ms, k, gb / k * 1e3, ms - k,
+                         " ".join("%.0f" % x for x in buf.placement["probe_gbs"]), buf.placement["picked"]), flush=True)
+                worst[draws] = max(worst[draws], ms)
+                buf.free()
+        for draws in (1, 3):
+            if world == 1:
+                t1[draws] = worst[draws]
+            print("  -> N=%d, max_draws %d: slowest rank %.3f ms/step, implied strong-scaling efficiency %.3f"
+                  % (world, draws, worst[draws], t1[draws] / (world * worst[draws])), flush=True)
     eng.close()
 
 
