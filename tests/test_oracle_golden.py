@@ -290,3 +290,21 @@ def test_reference_branch_coverage_table_is_complete():
     for line in (582, 589, 679, 683, 690, 697, 725, 736, 752):
         row = re.search(r"^\| %d \| (\d+) \| (\d+) / (\d+) \|" % line, text, re.M)
         assert row and int(row.group(2)) > 0 and int(row.group(3)) > 0, line
+
+
+def test_reference_build_manifest_matches_what_is_on_disk():
+    """oracle/_ref.MANIFEST (tracked) names the reference build the goldens, the parity_reference check and the CPU baseline
+    of bench.py come from; where the build itself is present (build container, gpurun snapshot) its hashes must be the
+    manifest's - a stale manifest or a foreign build would make BENCH's `reference_build` meaningless."""
+    import hashlib
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    man = json.load(open(os.path.join(root, "oracle", "_ref.MANIFEST")))
+    assert set(man["artefacts_sha256"]) == {"gortt", "gortt_fp", "libgortt_ref.so"}
+    assert man["reference_build"] == man["artefacts_sha256"]["libgortt_ref.so"][:16]
+    ref = os.path.join(root, "oracle", "_ref")
+    if not os.path.exists(os.path.join(ref, "libgortt_ref.so")):
+        pytest.skip("oracle/_ref is not built here (clean clone without /root/reference)")
+    for name, want in man["artefacts_sha256"].items():
+        got = hashlib.sha256(open(os.path.join(ref, name), "rb").read()).hexdigest()
+        assert got == want, "oracle/_ref/%s is not the build of oracle/_ref.MANIFEST: run `make -C oracle ref`" % name
