@@ -82,24 +82,29 @@ __device__ inline long energy_rep(const double *__restrict__ angles, long line, 
     return (a.z == b.z && a.a == b.a) ? o : line;
 }
 
-// one thread per line, behind energy_key_kernel: slot_of[line] becomes rep[line] (in place: a line reads its own slot only)
+// one thread per line, behind energy_key_kernel: slot_of[line] becomes rep[line] (in place: a line reads its own slot
+// only), and the lines that stand for themselves enter the list the evaluation walks (uniq[0] = their number; the order
+// of the list depends on the run, what is computed for a line does not)
 __global__ __launch_bounds__(256) void energy_rep_kernel(const double *__restrict__ angles, long nA,
-                                                          const unsigned *__restrict__ owner, unsigned *__restrict__ slot_of)
+                                                          const unsigned *__restrict__ owner, unsigned *__restrict__ slot_of,
+                                                          unsigned *__restrict__ uniq)
 {
     const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nA) return;
-    slot_of[line] = (unsigned)energy_rep(angles, line, owner, slot_of);
+    const long rep = energy_rep(angles, line, owner, slot_of);
+    slot_of[line] = (unsigned)rep;
+    if (rep == line) uniq[1 + atomicAdd(&uniq[0], 1u)] = (unsigned)line;
 }
 
 // blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by the members;
-// energy[member][nA][nw][3].  DEDUP: workgroups stride over the lines and evaluate only those that stand for themselves.
+// energy[member][nA][nw][3].  DEDUP: workgroups stride over the list of the lines that stand for themselves (uniq).
 template <bool DEDUP>
 __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopies,
                                                                  const double *__restrict__ Lall, int nw,
                                                                  const double *__restrict__ angles, long nA,
                                                                  const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
                                                                  double *__restrict__ energy_all,
-                                                                 const unsigned *__restrict__ rep)
+                                                                 const unsigned *__restrict__ uniq)
 {
     __shared__ double s_part[5][ENERGY_THREADS / 64];
     __shared__ double s_abar[5];
@@ -109,8 +114,9 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
     const double *__restrict__ L = Lall + member * L_NSLOT * nw;
     double *__restrict__ energy = energy_all + member * nA * nw * 3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (long a = blockIdx.x; a < nA; a += gridDim.x) {
-    if (DEDUP && (long)rep[a] != a) continue;                                // uniform: the whole workgroup
+  const long n_lines = DEDUP ? (long)uniq[0] : nA;
+  for (long u = blockIdx.x; u < n_lines; u += gridDim.x) {
+    const long a = DEDUP ? (long)uniq[1 + u] : u;
     if (DEDUP) __syncthreads();                                              // the shared arrays of the previous line are done with
 
     double vza, sza, saa, raa;
@@ -225,13 +231,14 @@ __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row,
 
 }  // namespace
 
-// dedup workspace (bytes) for nA lines: hash table [cap] u64 + owner [cap] u32 + slot_of [nA] u32, cap = 2^k >= 2 nA
+// dedup workspace (bytes) for nA lines: hash table [cap] u64 + owner [cap] u32 + slot_of / rep [nA] u32 + the list of
+// self-standing lines [1 + nA] u32, cap = 2^k >= 2 nA
 size_t energy_dedup_workspace(long nA)
 {
     if (nA < ENERGY_DEDUP_MIN_LINES) return 0;
     size_t cap = 1024;
     while (cap < 2 * (size_t)nA) cap <<= 1;
-    return cap * (sizeof(unsigned long long) + sizeof(unsigned)) + (size_t)nA * sizeof(unsigned);
+    return cap * (sizeof(unsigned long long) + sizeof(unsigned)) + (2 * (size_t)nA + 1) * sizeof(unsigned);
 }
 
 // ws_dev: energy_dedup_workspace(nA) bytes, or nullptr = every line evaluated (few lines; tests compare the two)
@@ -253,20 +260,22 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     unsigned long long *tab = static_cast<unsigned long long *>(ws_dev);
     unsigned *owner = reinterpret_cast<unsigned *>(tab + cap);
     unsigned *slot_of = owner + cap;
+    unsigned *uniq = slot_of + nA;
     if (hipMemsetAsync(tab, 0, cap * sizeof(unsigned long long), s) != hipSuccess ||
-        hipMemsetAsync(owner, 0xff, cap * sizeof(unsigned), s) != hipSuccess)
+        hipMemsetAsync(owner, 0xff, cap * sizeof(unsigned), s) != hipSuccess ||
+        hipMemsetAsync(uniq, 0, sizeof(unsigned), s) != hipSuccess)
         return fail(GORT_ENODEVICE, "energy: cannot clear the sun-direction table");
     hipLaunchKernelGGL(energy_key_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, angles_dev, nA, tab, owner,
                        (unsigned)(cap - 1), slot_of);
     int rc = check_launch("energy_key_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(energy_rep_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, angles_dev, nA, (const unsigned *)owner,
-                       slot_of);
+                       slot_of, uniq);
     if ((rc = check_launch("energy_rep_kernel"))) return rc;
     const unsigned *rep = slot_of;
     const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
     hipLaunchKernelGGL(energy_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
-                       angles_dev, nA, nodes_dev, energy_dev, rep);
+                       angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
     if ((rc = check_launch("energy_kernel"))) return rc;
     const int row = 3 * nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(energy_dev) / sizeof(double)) % CHUNK);

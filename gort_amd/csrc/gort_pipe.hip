@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "gort_internal.h"
@@ -39,6 +40,7 @@ struct Slot {
     hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
     long n = 0;
     int rc = GORT_OK;            // error raised while the chunk was submitted; reported by gort_pipe_wait
+    std::string err;             // its message
 };
 
 }  // namespace
@@ -162,9 +164,22 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
         sp = &p->slots[(size_t)(p->submitted % p->depth)];
     }
     Slot &s = *sp;
-    if (n < 0 || n > p->max_lines) return fail(GORT_EINVAL, "gort_pipe_submit: %ld lines in a slot of %ld", n, p->max_lines);
+    if (n < 0 || n > p->max_lines) {
+        // recorded as a failed, empty chunk: every acquired slot is submitted, so a consumer that counts chunks
+        // (the CLI does) meets the error in gort_pipe_wait instead of waiting for a chunk that never comes
+        s.n = 0;
+        s.rc = fail(GORT_EINVAL, "gort_pipe_submit: %ld lines in a slot of %ld", n, p->max_lines);
+        s.err = gort_last_error();
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            ++p->submitted;
+        }
+        p->cv.notify_all();
+        return s.rc;
+    }
     s.n = n;
     s.rc = GORT_OK;
+    s.err.clear();
     (void)hipSetDevice(p->device);
     hipStream_t ks = (hipStream_t)gort_engine_stream(p->e);
     const size_t nn = (size_t)n, nw = (size_t)p->nw, D = sizeof(double);
@@ -196,6 +211,7 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
         return GORT_OK;
     };
     s.rc = enqueue();
+    if (s.rc) s.err = gort_last_error();         // the cause, for gort_pipe_wait (another thread, another last-error slot)
     {
         std::lock_guard<std::mutex> lk(p->mu);
         ++p->submitted;
@@ -222,8 +238,16 @@ extern "C" int gort_pipe_wait(gort_pipe *p, gort_pipe_chunk *out)
     out->scomp = s.h_scomp;
     out->K = s.h_K;
     out->energy = s.h_energy;
-    if (s.rc) return fail(s.rc, "gort_pipe_wait: the chunk failed when it was submitted (code %d)", s.rc);
     (void)hipSetDevice(p->device);
+    if (s.rc) {
+        // part of the chunk may have been queued before the failure (the copy in, some kernels): nothing of it may
+        // still be running when the caller releases the slot and its pinned and device buffers are handed out again
+        (void)hipStreamSynchronize(p->s_in);
+        (void)gort_engine_synchronize(p->e);
+        (void)hipStreamSynchronize(p->s_out);
+        (void)hipGetLastError();
+        return fail(s.rc, "gort_pipe_wait: the chunk failed when it was submitted: %s", s.err.c_str());
+    }
     PIPE_HIP(hipEventSynchronize(s.ev_out));
     return GORT_OK;
 }

@@ -296,26 +296,42 @@ struct LineReader {
     }
 };
 
-// "%lf %lf %lf %lf" of the reference's sscanf (gortt.c:234): four numbers, anything after them ignored
+// "%lf %lf %lf %lf" of the reference's sscanf (gortt.c:234): four numbers, anything after them ignored.
+// Lines whose first four fields are PLAIN decimal numbers standing alone ([+-]digits[.digits][e[+-]digits] followed
+// by white space or the end of the line - every line a program writes) are converted with strtod, for which scanf and
+// strtod agree by definition.  Everything else - hex floats, inf / nan(...), a dangling exponent marker ("1e", "0x1p"),
+// junk glued to a number, "0x." - goes through sscanf itself: scanf's greedy matching differs from strtod's longest
+// valid prefix in exactly those corners (it swallows "1e" and "0x" + nothing, refuses "nan()" and "infinit"), and the
+// reference's behaviour there, error or shifted fields, is whatever its scanf does.
+static bool plain_field(const char *&p)
+{
+    while (std::isspace((unsigned char)*p)) ++p;
+    if (*p == '+' || *p == '-') ++p;
+    int digits = 0;
+    while (std::isdigit((unsigned char)*p)) { ++p; ++digits; }
+    if (*p == '.') {
+        ++p;
+        while (std::isdigit((unsigned char)*p)) { ++p; ++digits; }
+    }
+    if (!digits) return false;
+    if (*p == 'e' || *p == 'E') {
+        ++p;
+        if (*p == '+' || *p == '-') ++p;
+        if (!std::isdigit((unsigned char)*p)) return false;
+        while (std::isdigit((unsigned char)*p)) ++p;
+    }
+    return *p == '\0' || std::isspace((unsigned char)*p);
+}
+
 bool parse_angles(const char *s, double v[4])
 {
+    const char *p = s;
+    bool plain = true;
+    for (int q = 0; q < 4 && plain; ++q) plain = plain_field(p);
+    if (!plain) return std::sscanf(s, "%lf %lf %lf %lf", v, v + 1, v + 2, v + 3) == 4;
     for (int q = 0; q < 4; ++q) {
         char *end;
         v[q] = std::strtod(s, &end);
-        if (end == s) return false;
-        // glibc's scanf("%lf") swallows an exponent marker that no digits follow ("1e", "10e+", "0x1p": the number is
-        // read without it, and the next field starts BEHIND the marker and its sign), strtod hands it back
-        const char *p = s;
-        while (std::isspace((unsigned char)*p)) ++p;
-        if (*p == '+' || *p == '-') ++p;
-        const bool hex = p[0] == '0' && (p[1] == 'x' || p[1] == 'X');
-        if (std::isdigit((unsigned char)*p) || *p == '.') {
-            if (hex ? (*end == 'p' || *end == 'P') : (*end == 'e' || *end == 'E')) {
-                const char *t = end + 1;
-                if (*t == '+' || *t == '-') ++t;
-                if (!std::isdigit((unsigned char)*t)) end = const_cast<char *>(t);
-            }
-        }
         s = end;
     }
     return true;
@@ -708,11 +724,15 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "gortt: %ld lines in %ld chunks of <= %ld; setup %.3f s, total %.3f s; producer: slot wait %.3f, "
                      "read+parse %.3f, submit %.3f; consumer: chunk wait %.3f, format+write %.3f\n", na, k_chunk, CHUNK,
                      t_setup, since(t_start), t_acquire, t_read, t_submit, t_wait, t_write);
-    // Every chunk has been collected and written: nothing is in flight on any device.  Freeing ~150 MB of pinned memory,
-    // the device buffers and the HIP runtime's own state takes 0.03 s + what the runtime's exit handlers take - for a
-    // process that is about to end and whose memory the driver reclaims anyway.  So the process leaves through _Exit once
-    // its streams are flushed; GORTT_ORDERLY_EXIT=1 keeps the orderly teardown (leak checkers).
-    const bool orderly = std::getenv("GORTT_ORDERLY_EXIT") != nullptr;
+    // Every chunk has been collected and written: nothing is in flight on any device.  The process ends the orderly way
+    // - pipes and engines destroyed, exit handlers and static destructors run - so that whatever finalises at exit
+    // (rocprofv3's tool library, gcov, a leak checker) gets its turn.  GORTT_FAST_EXIT=1 skips the teardown (~0.03 s:
+    // ~150 MB of pinned memory, device buffers, the HIP runtime's state - all reclaimed by the driver anyway) and leaves
+    // through _Exit once the streams are flushed; it is ignored when a preloaded or profiling library is in the process.
+    const bool fast_exit = std::getenv("GORTT_FAST_EXIT") && std::atoi(std::getenv("GORTT_FAST_EXIT")) != 0 &&
+                           !std::getenv("LD_PRELOAD") && !std::getenv("ROCP_TOOL_LIBRARIES") && !std::getenv("HSA_TOOLS_LIB") &&
+                           !std::getenv("ASAN_OPTIONS") && !std::getenv("LSAN_OPTIONS");
+    const bool orderly = !fast_exit;
     const auto t_down = std::chrono::steady_clock::now();
     if (orderly)
         for (Dev &dv : devs) {
@@ -722,7 +742,7 @@ int main(int argc, char **argv)
         }
     if (verbose)
         std::fprintf(stderr, "gortt: %.3f s from main() to the first chunk's setup (HIP start-up, gap tables, header, spectra), "
-                     "%.3f s to free pipes and engines%s\n", t_before, since(t_down), orderly ? "" : " (skipped: fast exit)");
+                     "%.3f s to free pipes and engines%s\n", t_before, since(t_down), orderly ? "" : " (skipped: GORTT_FAST_EXIT)");
     auto leave = [&](int rc) -> int {
         std::fflush(stdout);
         std::fflush(stderr);

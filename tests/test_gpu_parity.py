@@ -749,6 +749,24 @@ def test_cli_reads_numbers_like_the_reference():
     assert not diffs, "%d of %d cases differ" % (len(diffs), len(cases))
 
 
+def test_cli_scanf_corners_like_the_reference():
+    """Where scanf("%lf") and strtod part ways: "0x." (0 for scanf), "0xp1" / "nan()" / "nan(1)" / "infinit"
+    (matching failures: `error on input`), "1e" / "0x1p" (marker swallowed) ... - 38 such tokens in each of the four fields
+    of an angle line, 137 runs of the reference (tools/make_golden.py cliscanf): same exit code, stderr and stdout.  Lines
+    that are not plain decimal go through sscanf itself in the drop-in (gortt_main.cpp parse_angles)."""
+    cases = json.load(open(os.path.join(GOLDEN, "cli_scanf_corner_cases.json"), encoding="utf-8"))
+    assert len(cases) >= 130 and sum(c["rc"] for c in cases) >= 50
+    diffs = []
+    for case, run in zip(cases, _run_cases(cases, encoding="utf-8", timeout=120)):
+        out, errtxt = run.stdout.decode("latin-1"), run.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt")
+        same_out = out == case["stdout"] or out.replace("-nan", "nan") == case["stdout"].replace("-nan", "nan")
+        if (run.returncode, errtxt) != (case["rc"], case["stderr"]) or not same_out:
+            diffs.append((case["name"], case["stdin"], (case["rc"], case["stdout"][:160], case["stderr"][:160]), (run.returncode, out[:160], errtxt[:160])))
+    for d in diffs:
+        print(json.dumps(d, ensure_ascii=False))
+    assert not diffs, "%d of %d cases differ" % (len(diffs), len(cases))
+
+
 def test_cli_long_stream_identical_to_reference():
     """4000 random lines x 3 bands with -prnspec -prnprop from the real reference (tests/golden/cli_bulk.json.gz) through
     the drop-in in SMALL chunks (many chunks in flight, several formatting threads) and in one chunk: the same bytes

@@ -66,6 +66,18 @@ def test_pipe_chunks_in_flight_equal_one_call(eng):
     pipe = api.Pipe(eng, 16, depth=2)
     pipe.acquire(); pipe.submit(0)
     assert pipe.wait()["n"] == 0
+    pipe.release()
+    # a chunk that failed when it was submitted is a chunk too: the consumer meets the error - with its cause -
+    # in wait(), the slot is drained and released, and the pipe goes on working
+    pipe.acquire()
+    with pytest.raises(api.GortError, match="17 lines in a slot of 16"):
+        pipe.submit(17)
+    with pytest.raises(api.GortError, match="failed when it was submitted.*17 lines in a slot of 16"):
+        pipe.wait()
+    pipe.release()
+    a = pipe.acquire(); a[:3] = ang[:3]; pipe.submit(3)
+    c = pipe.wait()
+    assert c["n"] == 3 and np.array_equal(c["rsurf"].view(np.int64), whole[:3].view(np.int64))
     pipe.release(); pipe.close()
 
 

@@ -640,6 +640,32 @@ def cli_number_formats_golden(seed=1212):
     json.dump(out, open(os.path.join(GOLD, "cli_number_format_cases.json"), "w"), indent=0, ensure_ascii=False)
 
 
+def cli_scanf_corner_golden():
+    """Where scanf("%lf")'s greedy matching and strtod's longest valid prefix part ways: "0x." is 0 for scanf,
+    "0xp1", "nan()", "nan(1)" and "infinit" are matching failures, "1e" / "0x1p" swallow the marker.  Every such token in
+    every one of the four fields of an angle line (the other three plain), deterministic: the reference's exit code,
+    stderr and stdout say what its sscanf did with it."""
+    toks = ["0x.", "0xp1", "0x", "0x.p1", "0x.8p1", "0x1.8", "0x1p", "0x1p+", "0X1P-", "nan()", "nan(1)", "nan(abc", "nan(ab c)",
+            "infinit", "infinityx", "infinity", "in", "i", "na", "+inf", "-infinity", "1e", "1e+", "1e-", "0e", ".e1", "+.5", "-.5e1",
+            "5.", "1e5x", "12abc", "1..2", "1e0005", "00x1", "1.e", "+", "-.", "1e+5e"]
+    out = []
+    for tok in toks:
+        for pos in range(4):
+            f = ["10", "0", "30", "20"]
+            f[pos] = tok
+            stdin = "1 2 650 865\n" + " ".join(f) + "\n"
+            try:
+                rc, so, se = run(GORTT, ["-LAI", "4.0"], stdin, timeout=20)
+            except subprocess.TimeoutExpired:
+                continue
+            if rc not in (0, 1) or len(so) > 20000:
+                continue
+            out.append({"name": "scanf_%s_field%d" % (tok, pos), "args": ["-LAI", "4.0"], "stdin": stdin, "rc": rc, "stdout": so,
+                        "stderr": se.replace(GORTT, "gortt")})
+    print("cli scanf corners: %d cases, %d with rc 1" % (len(out), sum(c["rc"] for c in out)))
+    json.dump(out, open(os.path.join(GOLD, "cli_scanf_corner_cases.json"), "w"), indent=0, ensure_ascii=False)
+
+
 def cli_bulk_golden(n=4000, seed=4040):
     """One LONG stream through the real reference (4000 random lines x 3 bands, -prnspec -prnprop): what the drop-in's
     chunked, multi-threaded text path has to reproduce row for row.  Kept gzipped (stdin + stdout)."""
@@ -720,6 +746,7 @@ def main():
     if "clibulk" in what: cli_bulk_golden()
     if "clihostile" in what: cli_hostile_goldens()
     if "clinumfmt" in what: cli_number_formats_golden()
+    if "cliscanf" in what: cli_scanf_corner_golden()
     if "prospect" in what: prospect_fuzz_golden()
     if "ensemble" in what: ensemble_states_golden()
     if "wide" in what: wide_stream_golden()
