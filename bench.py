@@ -275,7 +275,7 @@ def main():
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lut-draws", type=int, default=3,
+    ap.add_argument("--lut-draws", type=int, default=5,
                     help="max_draws of gort_lut_alloc, the C ABI's allocator for LUT buffers (1 = plain allocation); the "
                          "first-draw timing is always measured and reported beside it")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")

@@ -88,7 +88,7 @@ DECLARED_SYMBOLS = [
 TUNING_SYMBOLS = [
     "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_stream_form",
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
-    "gort_selftest_index_math",
+    "gort_engine_probe_store_pattern", "gort_selftest_index_math",
 ]
 
 _lib = None
@@ -119,6 +119,8 @@ def lib():
         L.gort_lut_alloc.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]
         L.gort_lut_free.argtypes = [C.c_void_p]
         L.gort_lut_free.restype = None
+        L.gort_engine_probe_store_pattern.restype = C.c_double
+        L.gort_engine_probe_store_pattern.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gort_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gort_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.gort_engine_create.argtypes = [C.POINTER(C.c_void_p)]
@@ -229,7 +231,8 @@ class DeviceBuffer:
 
 
 class LutPlacement(C.Structure):
-    _fields_ = [("draws", C.c_int32), ("picked", C.c_int32), ("probe_gbs", D * 8), ("accept_gbs", D)]
+    _fields_ = [("draws", C.c_int32), ("picked", C.c_int32), ("probe_gbs", D * 8), ("accept_gbs", D), ("shifted", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class LutBuffer:
@@ -242,7 +245,7 @@ class LutBuffer:
         self.shape = (self.nbytes // 8,)
         self.placement = {"draws": int(placement.draws), "picked": int(placement.picked),
                           "probe_gbs": [float(placement.probe_gbs[i]) for i in range(placement.draws)],
-                          "accept_gbs": float(placement.accept_gbs)}
+                          "accept_gbs": float(placement.accept_gbs), "shifted": bool(placement.shifted)}
         self.window = window                 # (offset_doubles, doubles) this process writes, or None = everything
 
     @property
@@ -559,6 +562,13 @@ class Engine:
         _check(lib().gort_lut_alloc(self.h, C.c_size_t(8 * int(doubles)), C.c_size_t(8 * int(off)), C.c_size_t(8 * int(cnt)),
                                     int(max_draws), C.byref(out), C.byref(info)))
         return LutBuffer(out.value, 8 * int(doubles), info, window)
+
+    def probe_store_pattern(self, ptr, nbytes):
+        """GB/s of the LUT kernel's bare store pattern over device memory the caller owns (contents destroyed)."""
+        g = lib().gort_engine_probe_store_pattern(self.h, _ptr(ptr), C.c_size_t(int(nbytes)))
+        if g < 0:
+            _check(int(g))
+        return g
 
     def rsurf_grid_dev(self, grid, row_begin, row_end, lut_t):
         _check(lib().gort_rsurf_grid_dev(self.h, C.byref(grid), row_begin, row_end, _ptr(lut_t)))

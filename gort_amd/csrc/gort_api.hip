@@ -935,6 +935,18 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
 }
 
 // ---- LUT buffers with a measured placement (include/gort_amd.h) ----
+// buffers handed out as a pointer INTO their allocation (shifted windows): pointer -> what hipFree needs
+static std::mutex &lut_bases_mu()
+{
+    static std::mutex m;
+    return m;
+}
+static std::unordered_map<void *, void *> &lut_bases()
+{
+    static std::unordered_map<void *, void *> m;
+    return m;
+}
+
 
 extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, size_t win_bytes, int max_draws,
                               void **out_dev, gort_lut_placement *info)
@@ -959,32 +971,66 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
     int weights[GORT_LUT_MAX_DRAWS][8];
     double gbs[GORT_LUT_MAX_DRAWS] = {0.0};
     int n = 0, best = 0;
-    for (; n < (select ? max_draws : 1); ++n) {
-        if (hipMalloc(&cand[n], bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            cand[n] = nullptr;
-            if (n == 0) return fail(GORT_ENOMEM, "gort_lut_alloc: cannot allocate %zu bytes", bytes);
-            break;                                      // make do with the draws we have
-        }
-        if (!select) continue;
-        double *win = reinterpret_cast<double *>(static_cast<char *>(cand[n]) + win_offset);
-        // three passes of the LUT kernel's bare store pattern over the window (the first one touches the pages)
-        for (int pass = 0; pass < 3 && rc == GORT_OK; ++pass) {
+    // three passes of the LUT kernel's bare store pattern over a candidate window (the first one touches the pages)
+    auto probe = [&](void *buffer, int i) -> int {
+        double *win = reinterpret_cast<double *>(static_cast<char *>(buffer) + win_offset);
+        for (int pass = 0; pass < 3; ++pass) {
             double g = 0.0;
             int w[8];
-            rc = calibrate_xcd_weights(e->stream, win, doubles, w, &g);
-            if (pass > 0 && g > gbs[n]) { gbs[n] = g; std::memcpy(weights[n], w, sizeof w); }
+            const int prc = calibrate_xcd_weights(e->stream, win, doubles, w, &g);
+            if (prc) return prc;
+            if (pass > 0 && g > gbs[i]) { gbs[i] = g; std::memcpy(weights[i], w, sizeof w); }
         }
-        if (rc) break;
-        if (gbs[n] > gbs[best]) best = n;
-        if (accept > 0.0 && gbs[n] >= accept) { ++n; break; }      // as good as anything this engine has seen
+        if (gbs[i] > gbs[best]) best = i;
+        return GORT_OK;
+    };
+    // A window that is a small part of the buffer (a rank's slab of a gatherable LUT: the other ranks' windows are only
+    // ever written by the all-gather) gets its draws from ONE allocation: (draws - 1) windows of slack behind the
+    // buffer, candidate i = the buffer placed i windows further in, so that every candidate window lies on pages of its
+    // own - 6 GB of extra memory per draw instead of another 50 GB buffer.  Else: separate allocations, alive together.
+    const bool shifted = select && win_bytes * 2 <= bytes;
+    void *base = nullptr;
+    if (shifted) {
+        const size_t shift = (win_bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20);       // whole 2-MiB pages
+        int draws = max_draws;
+        for (; draws >= 1; --draws) {
+            if (hipMalloc(&base, bytes + (size_t)(draws - 1) * shift) == hipSuccess) break;
+            (void)hipGetLastError();
+            base = nullptr;
+        }
+        if (!base) return fail(GORT_ENOMEM, "gort_lut_alloc: cannot allocate %zu bytes", bytes);
+        for (; n < draws && rc == GORT_OK; ++n) {
+            cand[n] = static_cast<char *>(base) + (size_t)n * shift;
+            rc = probe(cand[n], n);
+            if (rc == GORT_OK && accept > 0.0 && gbs[n] >= accept) { ++n; break; }
+        }
+        if (rc) {
+            (void)hipFree(base);
+            return rc;
+        }
+        if (cand[best] != base) {                       // an interior pointer: gort_lut_free must find the allocation
+            std::lock_guard<std::mutex> lock(lut_bases_mu());
+            lut_bases()[cand[best]] = base;
+        }
+    } else {
+        for (; n < (select ? max_draws : 1); ++n) {
+            if (hipMalloc(&cand[n], bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                cand[n] = nullptr;
+                if (n == 0) return fail(GORT_ENOMEM, "gort_lut_alloc: cannot allocate %zu bytes", bytes);
+                break;                                      // make do with the draws we have
+            }
+            if (!select) continue;
+            if ((rc = probe(cand[n], n))) break;
+            if (accept > 0.0 && gbs[n] >= accept) { ++n; break; }      // as good as anything this engine has seen
+        }
+        if (rc) {
+            for (int i = 0; i < GORT_LUT_MAX_DRAWS; ++i) if (cand[i]) (void)hipFree(cand[i]);
+            return rc;
+        }
+        for (int i = 0; i < n; ++i)
+            if (i != best && cand[i]) (void)hipFree(cand[i]);
     }
-    if (rc) {
-        for (int i = 0; i < GORT_LUT_MAX_DRAWS; ++i) if (cand[i]) (void)hipFree(cand[i]);
-        return rc;
-    }
-    for (int i = 0; i < n; ++i)
-        if (i != best && cand[i]) (void)hipFree(cand[i]);
     if (select) {
         if (gbs[best] > e->best_pattern_gbs[cls]) e->best_pattern_gbs[cls] = gbs[best];
         if (!e->xcd_weights_fixed && gbs[best] > 0.0) {        // the XCD duty weights of this size class come with the probe
@@ -998,15 +1044,41 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         info->draws = n;
         info->picked = best;
         info->accept_gbs = accept;
+        info->shifted = shifted ? 1 : 0;
         for (int i = 0; i < n; ++i) info->probe_gbs[i] = gbs[i];
     }
     *out_dev = cand[best];
     return GORT_OK;
 }
 
+// the probe of gort_lut_alloc on memory the caller owns (contents destroyed): include/gort_amd_tuning.h
+extern "C" double gort_engine_probe_store_pattern(gort_engine *e, void *dev, size_t bytes)
+{
+    if (!e || !dev || bytes < sizeof(double)) return (double)fail(GORT_EINVAL, "gort_engine_probe_store_pattern: bad argument");
+    double best = 0.0;
+    for (int pass = 0; pass < 3; ++pass) {
+        double g = 0.0;
+        int w[8];
+        const int rc = calibrate_xcd_weights(e->stream, static_cast<double *>(dev), (long)(bytes / sizeof(double)), w, &g);
+        if (rc) return (double)rc;
+        if (pass > 0 && g > best) best = g;
+    }
+    return best;
+}
+
 extern "C" void gort_lut_free(void *lut_dev)
 {
-    if (lut_dev) (void)hipFree(lut_dev);
+    if (!lut_dev) return;
+    void *base = lut_dev;
+    {
+        std::lock_guard<std::mutex> lock(lut_bases_mu());
+        auto it = lut_bases().find(lut_dev);
+        if (it != lut_bases().end()) {
+            base = it->second;
+            lut_bases().erase(it);
+        }
+    }
+    (void)hipFree(base);
 }
 
 static int check_grid(const gort_grid *g, const char *who)

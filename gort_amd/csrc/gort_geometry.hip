@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 // transcendentals of a row are a serial chain: four rows cost the issue time of one), then the lanes walk the
 // GEOM_ROWS x nphi azimuth nodes.  With 361 nodes per row this removes ~70 % of the transcendentals of the
 // per-tuple form.
+constexpr int GEOM_ROW_THREADS = 128;
 constexpr int GEOM_ROWS = 4;
 // mode 0: full stream records (GORT_COEF_STRIDE doubles per node); 1: compact 64-B records for the LUT kernel;
 // 2: FUSED for grids of a few bands (BASELINE config 3 is one band): the node's samples are formed right here from
@@ -77,7 +78,6 @@ constexpr int GEOM_ROWS = 4;
 #ifndef GORT_GEOM_WAVES
 #define GORT_GEOM_WAVES 3      // 168 VGPRs instead of 171: a third wave per SIMD, C3 133 -> 125 us; 4 would spill to scratch
 #endif
-template <int GEOM_ROW_THREADS>
 __global__ __launch_bounds__(GEOM_ROW_THREADS) __attribute__((amdgpu_waves_per_eu(GORT_GEOM_WAVES)))
 void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
@@ -196,24 +196,14 @@ static bool grid_mirrors(const gort_grid &g)
            g.vza0 >= 0.0 && g.dvza >= 0.0;
 }
 
-// threads per workgroup (GORT_GEOM_THREADS = 64 | 128, an A/B knob of round 3)
-static int geom_threads()
-{
-    static const int env = getenv("GORT_GEOM_THREADS") ? atoi(getenv("GORT_GEOM_THREADS")) : 0;
-    return env == 64 ? 64 : 128;
-}
-
+// (round 3 tried 8 rows per workgroup and 64-thread workgroups with the mirrored nodes: 83.6 and 84.3 us for BASELINE
+// config 3 against 78.8 with 4 rows x 128 threads, profiles/r03/c3_rows.log, c3_threads.log)
 static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long rows, double *coef_dev,
                                     int compact, const double *L_dev, int nw, double *rsurf_dev, void *stream)
 {
-    const int mirror = grid_mirrors(g) ? 1 : 0;
-    const dim3 grid((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS));
-    if (geom_threads() == 64)
-        hipLaunchKernelGGL(geometry_grid_kernel<64>, grid, dim3(64), 0, (hipStream_t)stream, canopy_dev, g, row_begin, rows,
-                           coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
-    else
-        hipLaunchKernelGGL(geometry_grid_kernel<128>, grid, dim3(128), 0, (hipStream_t)stream, canopy_dev, g, row_begin, rows,
-                           coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
+    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
+                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev,
+                       grid_mirrors(g) ? 1 : 0);
     return check_launch("geometry_grid_kernel");
 }
 

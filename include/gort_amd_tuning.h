@@ -43,6 +43,10 @@ int  gort_engine_xcd_weights(const gort_engine *e, int weights[8]);
 int  gort_engine_set_xcd_weights(gort_engine *e, const int weights[8]);
 /* GB/s of the calibration pass: the LUT kernel's store pattern without any arithmetic, equal XCD shares; 0 before */
 double gort_engine_store_pattern_gbs(const gort_engine *e);
+/* the placement probe of gort_lut_alloc on memory the caller owns: GB/s of the LUT kernel's bare store pattern over
+ * [dev, dev + bytes) (best of two passes after a first one that touches the pages; the contents are destroyed);
+ * 0 for regions below ~0.8 GB (the pattern needs 64 panels), < 0 = a GORT_E* code */
+double gort_engine_probe_store_pattern(gort_engine *e, void *dev, size_t bytes);
 /* host-only self-test of the flat kernels' index arithmetic (multiply-shift divisions, XCD duty mapping as a
  * bijection); 0 = ok.  Needs no GPU. */
 int  gort_selftest_index_math(void);

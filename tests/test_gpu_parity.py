@@ -998,6 +998,48 @@ def test_lut_kernel_variants_bitwise_identical():
     assert len(set(digests)) == 1, list(zip(envs, digests))
 
 
+def test_lut_alloc_measured_placement_and_zero_copy_view():
+    """gort_lut_alloc (include/gort_amd.h): a whole-buffer window draws separate allocations, a window that is a small
+    part of the buffer draws shifted placements inside ONE allocation (the pointer handed out may then be interior:
+    gort_lut_free must still free it); the engine remembers the best rate per size class and stops drawing early at
+    0.985 of it; the buffer speaks __cuda_array_interface__ (zero-copy torch view for the collectives); what the LUT
+    kernel writes into a window is what it writes into a plain buffer."""
+    import torch
+    e = api.Engine()
+    e.set_canopy(gpu_canopy(lai=4.0))
+    wl = np.linspace(400.0, 2500.0, 1200)
+    e.set_spectra(*api.spectra(wl))
+    g = api.hemisphere_grid(30, 91, 361)
+    rows, row_elems = 30 * 91, 361 * wl.size
+    # a rank's slab of a gatherable buffer: rows [r0, r1) of 4 ranks' worth
+    r0, r1 = 2 * 683, 3 * 683
+    win = (r0 * row_elems, (r1 - r0) * row_elems)                    # 683 rows x 433 200 doubles = 2.4 GB
+    free0 = torch.cuda.mem_get_info()[0]
+    buf = e.lut_alloc(4 * 683 * row_elems, window=win, max_draws=4)
+    pl = buf.placement
+    assert pl["shifted"] and 1 <= pl["draws"] <= 4 and 0 <= pl["picked"] < pl["draws"]
+    assert all(x > 1000.0 for x in pl["probe_gbs"]) and pl["accept_gbs"] == 0.0
+    t = buf.tensor((4 * 683, row_elems))
+    assert t.data_ptr() == buf.ptr and t.dtype == torch.float64
+    e.rsurf_grid_dev(g, r0, r1, buf.at(win[0])); e.synchronize()
+    plain = torch.empty((r1 - r0, row_elems), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    e.rsurf_grid_dev(g, r0, r1, plain); e.synchronize()
+    assert torch.equal(t[r0:r1].view(torch.int64), plain.view(torch.int64))
+    again = e.lut_alloc(4 * 683 * row_elems, window=win, max_draws=4)   # history: may stop at the first good draw
+    assert again.placement["accept_gbs"] > 0 and again.placement["draws"] >= 1
+    del t
+    buf.free(); again.free(); del plain
+    torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)              # interior pointers freed their whole allocation
+    whole = e.lut_alloc((1 << 27) + 4096, max_draws=2)                      # window = everything: separate allocations
+    assert not whole.placement["shifted"] and whole.placement["draws"] in (1, 2)
+    small = e.lut_alloc(1000, max_draws=3)                                  # nothing to select on
+    assert small.placement["draws"] == 1 and small.placement["probe_gbs"] == [0.0]
+    whole.free(); small.free()
+    e.close()
+
+
 def test_bench_two_ranks_rehearsal():
     """The N>1 code path of bench.py exactly as the driver launches it but for the backend: two ranks sharing this GPU
     over gloo.  Every rank computes into ITS WINDOW of one gatherable LUT buffer (gort_lut_alloc), the timed region runs

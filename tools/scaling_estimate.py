@@ -2,7 +2,7 @@
 """What one rank of an N-way strong-scaling run does, measured on ONE GPU: the metric grid's rows are cut with
 gort_amd.shard.row_slab exactly as bench.py does, the slabs of rank 0, N/2 and N-1 are stepped back to back INTO THEIR
 WINDOW OF THE GATHERABLE BUFFER (gort_lut_alloc, window = the slab: bench.py's layout), once on a plain first
-allocation (max_draws 1) and once on the allocator's pick (max_draws 3), and the implied efficiency t(1) / (N t(N)) is
+allocation (max_draws 1) and once on the allocator's pick (max_draws 5, bench.py's default), and the implied efficiency t(1) / (N t(N)) is
 printed for both.  No communication is involved in the timed step of bench.py, so this is the whole per-rank cost bar
 the RCCL barrier.  An ESTIMATE from one GPU, not a scaling measurement."""
 import os
@@ -14,6 +14,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gort_amd import api  # noqa: E402
 from gort_amd.shard import gatherable_rows, row_slab  # noqa: E402
+
+
+DRAWS = (1, 5)            # a plain first allocation, and bench.py's default
 
 
 def main():
@@ -29,11 +32,11 @@ def main():
     t1 = {}
     row_elems = grid.nphi * wl.size
     for world in (1, 2, 4, 8):
-        worst = {1: 0.0, 3: 0.0}
+        worst = {d: 0.0 for d in DRAWS}
         for rank in sorted({0, world // 2, world - 1}):
             r0, r1 = row_slab(rank, world, rows)
             win = (r0 * row_elems, (r1 - r0) * row_elems)
-            for draws in (1, 3):
+            for draws in DRAWS:
                 buf = eng.lut_alloc(gatherable_rows(world, rows) * row_elems, window=win, max_draws=draws)
                 ptr = buf.at(win[0])
                 for _ in range(5):
@@ -52,7 +55,7 @@ def main():
                          " ".join("%.0f" % x for x in buf.placement["probe_gbs"]), buf.placement["picked"]), flush=True)
                 worst[draws] = max(worst[draws], ms)
                 buf.free()
-        for draws in (1, 3):
+        for draws in DRAWS:
             if world == 1:
                 t1[draws] = worst[draws]
             print("  -> N=%d, max_draws %d: slowest rank %.3f ms/step, implied strong-scaling efficiency %.3f"
