@@ -231,7 +231,7 @@ class DeviceBuffer:
 
 
 class LutPlacement(C.Structure):
-    _fields_ = [("draws", C.c_int32), ("picked", C.c_int32), ("probe_gbs", D * 8), ("accept_gbs", D), ("shifted", C.c_int32),
+    _fields_ = [("draws", C.c_int32), ("picked", C.c_int32), ("probe_gbs", D * 64), ("accept_gbs", D), ("shifted", C.c_int32),
                 ("reserved", C.c_int32)]
 
 

@@ -971,37 +971,46 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
     int weights[GORT_LUT_MAX_DRAWS][8];
     double gbs[GORT_LUT_MAX_DRAWS] = {0.0};
     int n = 0, best = 0;
-    // three passes of the LUT kernel's bare store pattern over a candidate window (the first one touches the pages)
-    auto probe = [&](void *buffer, int i) -> int {
+    // passes of the LUT kernel's bare store pattern over a candidate window (the first one touches the pages)
+    auto probe = [&](void *buffer, int i, int passes) -> int {
         double *win = reinterpret_cast<double *>(static_cast<char *>(buffer) + win_offset);
-        for (int pass = 0; pass < 3; ++pass) {
+        for (int pass = 0; pass < passes; ++pass) {
             double g = 0.0;
             int w[8];
             const int prc = calibrate_xcd_weights(e->stream, win, doubles, w, &g);
             if (prc) return prc;
-            if (pass > 0 && g > gbs[i]) { gbs[i] = g; std::memcpy(weights[i], w, sizeof w); }
+            if ((pass > 0 || passes == 1) && g > gbs[i]) { gbs[i] = g; std::memcpy(weights[i], w, sizeof w); }
         }
         if (gbs[i] > gbs[best]) best = i;
         return GORT_OK;
     };
-    // A window that is a small part of the buffer (a rank's slab of a gatherable LUT: the other ranks' windows are only
-    // ever written by the all-gather) gets its draws from ONE allocation: (draws - 1) windows of slack behind the
-    // buffer, candidate i = the buffer placed i windows further in, so that every candidate window lies on pages of its
-    // own - 6 GB of extra memory per draw instead of another 50 GB buffer.  Else: separate allocations, alive together.
-    const bool shifted = select && win_bytes * 2 <= bytes;
+    // A window that is at most half the buffer (a rank's slab of a gatherable LUT: the other ranks' windows are only
+    // ever written by the all-gather) is placed by a SCAN inside one allocation.  Measured (profiles/r03/
+    // placement_scan.log): the rate of a 6 - 25 GB window as a function of where it lies in a big allocation is a
+    // comb - 7.2-7.3 TB/s on plateaus 3-5 GiB wide that recur every 8 to 48 GiB (wherever the window straddles a
+    // boundary of the physical extents behind the allocation), 6.1-6.3 TB/s in between - so a handful of random
+    // placements mostly land in between, and a scan in 1-GiB steps over up to 48 GiB of slack finds a plateau.  The
+    // slack (at most what leaves 8 GiB of the device free) stays allocated with the buffer.
+    const bool scan = select && win_bytes * 2 <= bytes;
     void *base = nullptr;
-    if (shifted) {
-        const size_t shift = (win_bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20);       // whole 2-MiB pages
-        int draws = max_draws;
-        for (; draws >= 1; --draws) {
-            if (hipMalloc(&base, bytes + (size_t)(draws - 1) * shift) == hipSuccess) break;
+    if (scan) {
+        constexpr size_t GIB = (size_t)1 << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        size_t slack_gib = 48;
+        while (slack_gib > 0 && bytes + slack_gib * GIB + 8 * GIB > free_b) slack_gib /= 2;
+        for (;; slack_gib /= 2) {
+            if (hipMalloc(&base, bytes + slack_gib * GIB) == hipSuccess) break;
             (void)hipGetLastError();
             base = nullptr;
+            if (slack_gib == 0) return fail(GORT_ENOMEM, "gort_lut_alloc: cannot allocate %zu bytes", bytes);
         }
-        if (!base) return fail(GORT_ENOMEM, "gort_lut_alloc: cannot allocate %zu bytes", bytes);
-        for (; n < draws && rc == GORT_OK; ++n) {
-            cand[n] = static_cast<char *>(base) + (size_t)n * shift;
-            rc = probe(cand[n], n);
+        int cands = (int)slack_gib + 1;
+        if (cands > GORT_LUT_MAX_DRAWS) cands = GORT_LUT_MAX_DRAWS;
+        const size_t step = cands > 1 ? slack_gib * GIB / (size_t)(cands - 1) / (2u << 20) * (2u << 20) : 0;
+        for (; n < cands && rc == GORT_OK; ++n) {
+            cand[n] = static_cast<char *>(base) + (size_t)n * step;
+            rc = probe(cand[n], n, n == 0 ? 3 : 2);      // neighbours overlap: only the first one meets untouched pages
             if (rc == GORT_OK && accept > 0.0 && gbs[n] >= accept) { ++n; break; }
         }
         if (rc) {
@@ -1013,7 +1022,9 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
             lut_bases()[cand[best]] = base;
         }
     } else {
-        for (; n < (select ? max_draws : 1); ++n) {
+        // the window is (most of) the buffer: separate allocations, alive together; big windows differ little
+        const int draws = select ? (max_draws < 3 ? max_draws : 3) : 1;
+        for (; n < draws; ++n) {
             if (hipMalloc(&cand[n], bytes) != hipSuccess) {
                 (void)hipGetLastError();
                 cand[n] = nullptr;
@@ -1021,7 +1032,7 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
                 break;                                      // make do with the draws we have
             }
             if (!select) continue;
-            if ((rc = probe(cand[n], n))) break;
+            if ((rc = probe(cand[n], n, 3))) break;
             if (accept > 0.0 && gbs[n] >= accept) { ++n; break; }      // as good as anything this engine has seen
         }
         if (rc) {
@@ -1044,7 +1055,7 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         info->draws = n;
         info->picked = best;
         info->accept_gbs = accept;
-        info->shifted = shifted ? 1 : 0;
+        info->shifted = scan ? 1 : 0;
         for (int i = 0; i < n; ++i) info->probe_gbs[i] = gbs[i];
     }
     *out_dev = cand[best];

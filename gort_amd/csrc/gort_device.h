@@ -292,8 +292,13 @@ __host__ __device__ __forceinline__ long duty_logical_block(long b, const XcdDut
     const unsigned long long below = duty.w8 & ((1ull << sh) - 1ull);
     const unsigned pw = (unsigned)((below * 0x0101010101010101ull) >> 56);
     const long i = b >> 3;                               // < 32 q by the size of the grid
-    const long li = (i * w) >> 5;                        // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
+    long li = (i * w) >> 5;                              // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
     if ((((i + 1) * w) >> 5) == li) return -1;
+    if (duty.rotate) {                                   // a rotation of the XCD's own q w blocks: still a bijection
+        const long n = duty.q * w;
+        li += (n * (long)(((unsigned)b) & 7u)) >> 3;
+        if (li >= n) li -= n;
+    }
     const long block = duty.q * pw + li;
     return block < useful ? block : -1;
 }

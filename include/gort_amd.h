@@ -151,25 +151,26 @@ void  gort_dev_free(void *p_dev);
 int   gort_memcpy_h2d(void *dst_dev, const void *src, size_t bytes);
 int   gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
 
-/* Device memory for a LUT with a MEASURED placement.  Which physical pages a buffer of several GB lands on decides up
- * to 12 % of the rate at which the LUT kernel can write it (HBM channel balance; the same buffer is fast or slow for its
- * whole life), and a multi-GPU step ends with its slowest rank.  gort_lut_alloc draws up to max_draws
- * allocations (alive together, hence distinct placements), writes the window [win_offset, win_offset + win_bytes) of
- * each with the LUT kernel's store pattern (no arithmetic, ~1 ms per 6 GB), keeps the fastest and frees the rest;
- * it stops drawing early at 0.985 x the best rate this engine has measured for the size class.  Where the window is at
- * most half the buffer (a rank's slab of a gatherable LUT) the draws come from ONE allocation with (max_draws - 1)
- * windows of slack: candidate i is the buffer placed i windows further in, every candidate window on pages of its own,
- * at a window's worth of extra memory per draw (held until gort_lut_free) instead of another whole buffer.  Windows
- * below 1 GiB and max_draws = 1 are plain allocations.  The window is what this process will write: the whole buffer (win_bytes
- * = 0), or a rank's slab of a gatherable LUT.  Contents are undefined.  Release with gort_lut_free.
+/* Device memory for a LUT with a MEASURED placement.  Where a buffer of several GB lies physically decides up to 15 % of
+ * the rate at which the LUT kernel can write it (the same buffer is fast or slow for its whole life),
+ * and a multi-GPU step ends with its slowest rank.  gort_lut_alloc measures candidates with the LUT kernel's store
+ * pattern (no arithmetic, ~1 ms per 6 GB) over the window [win_offset, win_offset + win_bytes) - what this process
+ * will write: the whole buffer (win_bytes = 0), or a rank's slab of a gatherable LUT - and keeps the fastest:
+ *   - window at most half the buffer: ONE allocation with up to 48 GiB of slack, the buffer placed in 1-GiB steps
+ *     inside it (the rate of a 6-25 GB window is a comb over its position: plateaus of 7.2-7.3 TB/s every 8-48 GiB,
+ *     6.1-6.3 TB/s between them; a scan finds a plateau, a few random draws mostly do not).  The slack stays
+ *     allocated until gort_lut_free; the pointer returned may be interior to the allocation.
+ *   - else: up to min(max_draws, 3) separate allocations, alive together, the rest freed.
+ * It stops early at 0.985 x the best rate this engine has measured for the size class.  Windows below 1 GiB and
+ * max_draws = 1 are plain allocations.  Contents are undefined.  Release with gort_lut_free.
  * New surface (the reference keeps ONE row of nw doubles, malloc in main(): gortt.c:188). */
-#define GORT_LUT_MAX_DRAWS 8
+#define GORT_LUT_MAX_DRAWS 64
 typedef struct gort_lut_placement {
-    int32_t draws;                               /* allocations made */
+    int32_t draws;                               /* candidates measured */
     int32_t picked;                              /* index of the one kept */
-    double probe_gbs[GORT_LUT_MAX_DRAWS];        /* store-pattern rate over the window per draw, GB/s (0 = not probed) */
+    double probe_gbs[GORT_LUT_MAX_DRAWS];        /* store-pattern rate over the window per candidate, GB/s (0 = not probed) */
     double accept_gbs;                           /* early-stop rate used for this call (0 = no history yet) */
-    int32_t shifted;                             /* 1: the draws were placements of the buffer inside ONE allocation */
+    int32_t shifted;                             /* 1: candidates were placements inside ONE allocation (1-GiB steps) */
     int32_t reserved;
 } gort_lut_placement;
 int   gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, size_t win_bytes, int max_draws,

@@ -1000,8 +1000,8 @@ def test_lut_kernel_variants_bitwise_identical():
 
 def test_lut_alloc_measured_placement_and_zero_copy_view():
     """gort_lut_alloc (include/gort_amd.h): a whole-buffer window draws separate allocations, a window that is a small
-    part of the buffer draws shifted placements inside ONE allocation (the pointer handed out may then be interior:
-    gort_lut_free must still free it); the engine remembers the best rate per size class and stops drawing early at
+    part of the buffer is placed by a scan in 1-GiB steps inside ONE allocation with slack (the pointer handed out may
+    then be interior: gort_lut_free must still free it); the engine remembers the best rate per size class and stops drawing early at
     0.985 of it; the buffer speaks __cuda_array_interface__ (zero-copy torch view for the collectives); what the LUT
     kernel writes into a window is what it writes into a plain buffer."""
     import torch
@@ -1017,7 +1017,7 @@ def test_lut_alloc_measured_placement_and_zero_copy_view():
     free0 = torch.cuda.mem_get_info()[0]
     buf = e.lut_alloc(4 * 683 * row_elems, window=win, max_draws=4)
     pl = buf.placement
-    assert pl["shifted"] and 1 <= pl["draws"] <= 4 and 0 <= pl["picked"] < pl["draws"]
+    assert pl["shifted"] and 2 <= pl["draws"] <= 49 and 0 <= pl["picked"] < pl["draws"]     # a scan in 1-GiB steps
     assert all(x > 1000.0 for x in pl["probe_gbs"]) and pl["accept_gbs"] == 0.0
     t = buf.tensor((4 * 683, row_elems))
     assert t.data_ptr() == buf.ptr and t.dtype == torch.float64
