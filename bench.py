@@ -276,8 +276,8 @@ def main():
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lut-draws", type=int, default=5,
-                    help="max_draws of gort_lut_alloc, the C ABI's allocator for LUT buffers (1 = plain allocation); the "
-                         "first-draw timing is always measured and reported beside it")
+                    help="max_draws of gort_lut_alloc, the C ABI's allocator for LUT buffers: > 1 = the placement of this rank's "
+                         "window is measured (1 = plain allocation); the first-draw timing is always measured and reported beside it")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")
     ap.add_argument("--sustain-s", type=float, default=3.0,
                     help="after the timed region, keep stepping for this many seconds and report the mean step ('sustained'); 0 = off")
@@ -462,8 +462,8 @@ def main():
                        "sharding": "rows of (sun zenith, view zenith) in %d contiguous slabs (ceil partition); every rank "
                                    "computes into its window of ONE gatherable LUT buffer (%d rows, %.1f GB per GPU)"
                                    % (world, buf_rows, buf_rows * row_elems * 8 / 1e9),
-                       "allocation": "gort_lut_alloc, max_draws %d (C ABI allocator; first_draw = plain allocation, same steps)"
-                                     % args.lut_draws},
+                       "allocation": "gort_lut_alloc, max_draws %d (the C ABI's allocator: placement of the rank's window measured; "
+                                     "first_draw = plain allocation, same steps)" % args.lut_draws},
             "first_draw": {"value": total_samples * args.steps / fd_dt, "ms_per_step": fd_dt / args.steps * 1e3,
                            "kernel_ms_slowest_rank": fd_kernel_max,
                            "what": "the same warm-up + steps on a plain first allocation (gort_lut_alloc with max_draws 1), max over ranks"},

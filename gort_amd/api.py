@@ -232,7 +232,7 @@ class DeviceBuffer:
 
 class LutPlacement(C.Structure):
     _fields_ = [("draws", C.c_int32), ("picked", C.c_int32), ("probe_gbs", D * 64), ("accept_gbs", D), ("shifted", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("rescans", C.c_int32)]
 
 
 class LutBuffer:
@@ -245,7 +245,8 @@ class LutBuffer:
         self.shape = (self.nbytes // 8,)
         self.placement = {"draws": int(placement.draws), "picked": int(placement.picked),
                           "probe_gbs": [float(placement.probe_gbs[i]) for i in range(placement.draws)],
-                          "accept_gbs": float(placement.accept_gbs), "shifted": bool(placement.shifted)}
+                          "accept_gbs": float(placement.accept_gbs), "shifted": bool(placement.shifted),
+                          "rescans": int(placement.rescans)}
         self.window = window                 # (offset_doubles, doubles) this process writes, or None = everything
 
     @property
@@ -556,7 +557,9 @@ class Engine:
 
     def lut_alloc(self, doubles, window=None, max_draws=3):
         """gort_lut_alloc: `doubles` float64 of HBM for a LUT; window = (offset, count) in doubles of the part this
-        process writes (a rank's slab of a gatherable LUT), default everything.  Returns a LutBuffer."""
+        process writes (a rank's slab of a gatherable LUT), default everything.  max_draws > 1: the placement is
+        measured (a scan inside one allocation with slack for a small window, else up to 3 allocations).  Returns a
+        LutBuffer."""
         off, cnt = window if window is not None else (0, 0)
         out, info = C.c_void_p(), LutPlacement()
         _check(lib().gort_lut_alloc(self.h, C.c_size_t(8 * int(doubles)), C.c_size_t(8 * int(off)), C.c_size_t(8 * int(cnt)),

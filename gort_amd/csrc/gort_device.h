@@ -292,13 +292,10 @@ __host__ __device__ __forceinline__ long duty_logical_block(long b, const XcdDut
     const unsigned long long below = duty.w8 & ((1ull << sh) - 1ull);
     const unsigned pw = (unsigned)((below * 0x0101010101010101ull) >> 56);
     const long i = b >> 3;                               // < 32 q by the size of the grid
-    long li = (i * w) >> 5;                              // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
+    const long li = (i * w) >> 5;                        // evenly spread: slot i works iff floor((i+1)w/32) > floor(iw/32)
     if ((((i + 1) * w) >> 5) == li) return -1;
-    if (duty.rotate) {                                   // a rotation of the XCD's own q w blocks: still a bijection
-        const long n = duty.q * w;
-        li += (n * (long)(((unsigned)b) & 7u)) >> 3;
-        if (li >= n) li -= n;
-    }
+    // (round 3 let XCD x start x/8 of the way into its range, so that the eight write streams never sit at the same
+    // offset of their ranges: no effect on the comb of profiles/r03/placement_scan_rotate.log)
     const long block = duty.q * pw + li;
     return block < useful ? block : -1;
 }

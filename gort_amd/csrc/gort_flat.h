@@ -40,7 +40,6 @@ struct ExpandTuning {
     int xcd_mode = -1;
     int depth = 2;
     int steps = -1;             // -1 = automatic: 6 with the static mapping, 16 with slot counters (fewer atomics)
-    int xcd_rotate = 0;         // GORT_XCD_ROTATE: every XCD starts x/8 of the way into its range (static mapping)
     long waves = 2048;
     // the per-line stream kernel is VALU bound with a heavy prologue (24 band constants per lane): long waves.  Panels
     // of 64 steps x 33616 waves (2.2 GB per panel; streams up to 131 072 lines are ONE panel): 65 536 lines 232-290 us
@@ -57,7 +56,6 @@ struct ExpandTuning {
         if (stream_steps < 1) stream_steps = 1;
         if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_mode = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_STEPS")) steps = atoi(v);
-        if (const char *v = getenv("GORT_XCD_ROTATE")) xcd_rotate = atoi(v) != 0;
         if (xcd_mode < -1 || xcd_mode > 2) xcd_mode = -1;
         if (depth != 1 && depth != 2 && depth != 4) depth = 2;
         if (steps > 0) steps = (steps + depth - 1) / depth * depth;        // whole groups of DEPTH
@@ -109,8 +107,7 @@ inline long plan_xcd_duty(int xcd_mode, long useful, const int *weights, XcdDuty
         sumw += w;
     }
     duty.q = (useful + sumw - 1) / sumw;
-    duty.rotate = tuning().xcd_rotate;
-    duty.pad = 0;
+
     return xcd_mode == 1 ? 8 * 32 * duty.q : useful;
 }
 

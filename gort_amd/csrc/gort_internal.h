@@ -88,10 +88,6 @@ constexpr size_t XCD_SLOT_BYTES = sizeof(int) * 8 * XCD_SLOT_PITCH;
 struct XcdDuty {
     unsigned long long w8;
     long q;
-    // rotate: XCD x walks its range starting x/8 of the way in (and wraps), instead of all eight walking theirs from the
-    // start in step: the eight write streams then never sit at the same offset of equally spaced ranges
-    int rotate;
-    int pad;
 };
 // exact division of n < 2^31 by a divisor fixed per launch: n / d == (n * mul) >> (31 + sh)
 struct FastDiv {

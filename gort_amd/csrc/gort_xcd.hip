@@ -39,7 +39,6 @@ int selftest_index_math()
         const long useful = trial < 2 ? 2044799 / (trial + 1) / 100 : 1 + (long)(next() % 20000);
         XcdDuty duty;
         const long grid = plan_xcd_duty(1, useful, w, duty);
-        duty.rotate = trial & 1;                                     // both forms of the static mapping
         std::vector<unsigned char> seen((size_t)useful, 0);
         long hit = 0;
         for (long b = 0; b < grid; ++b) {

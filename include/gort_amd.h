@@ -158,8 +158,9 @@ int   gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
  * will write: the whole buffer (win_bytes = 0), or a rank's slab of a gatherable LUT - and keeps the fastest:
  *   - window at most half the buffer: ONE allocation with up to 48 GiB of slack, the buffer placed in 1-GiB steps
  *     inside it (the rate of a 6-25 GB window is a comb over its position: plateaus of 7.2-7.3 TB/s every 8-48 GiB,
- *     6.1-6.3 TB/s between them; a scan finds a plateau, a few random draws mostly do not).  The slack stays
- *     allocated until gort_lut_free; the pointer returned may be interior to the allocation.
+ *     6.1-6.3 TB/s between them; a scan finds a plateau, a few random draws mostly do not).  Where the scan is flat
+ *     (the allocation lies inside one physical extent) it is repeated, twice at most, on a new allocation made behind a
+ *     blocker of a few GiB.  The slack stays allocated until gort_lut_free; the pointer returned may be interior.
  *   - else: up to min(max_draws, 3) separate allocations, alive together, the rest freed.
  * It stops early at 0.985 x the best rate this engine has measured for the size class.  Windows below 1 GiB and
  * max_draws = 1 are plain allocations.  Contents are undefined.  Release with gort_lut_free.
@@ -171,7 +172,7 @@ typedef struct gort_lut_placement {
     double probe_gbs[GORT_LUT_MAX_DRAWS];        /* store-pattern rate over the window per candidate, GB/s (0 = not probed) */
     double accept_gbs;                           /* early-stop rate used for this call (0 = no history yet) */
     int32_t shifted;                             /* 1: candidates were placements inside ONE allocation (1-GiB steps) */
-    int32_t reserved;
+    int32_t rescans;                             /* scans repeated on a new allocation because the first found no plateau (0..2) */
 } gort_lut_placement;
 int   gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, size_t win_bytes, int max_draws,
                      void **lut_dev, gort_lut_placement *info);

@@ -50,9 +50,12 @@ def main():
                 ms = (time.perf_counter() - t0) * 1e3 / steps
                 k = eng.last_expand_ms()
                 gb = win[1] * 8 / 1e9
-                print("N=%d rank %d rows [%d,%d) %.2f GB, max_draws %d: %.3f ms/step, expand kernel %.3f ms (%.0f GB/s), other %.3f ms; probe GB/s %s picked %d"
-                      % (world, rank, r0, r1, gb, draws, ms, k, gb / k * 1e3, ms - k,
-                         " ".join("%.0f" % x for x in buf.placement["probe_gbs"]), buf.placement["picked"]), flush=True)
+                pl = buf.placement
+                pg = pl["probe_gbs"]
+                print("N=%d rank %d rows [%d,%d) %.2f GB, max_draws %d: %.3f ms/step, expand kernel %.3f ms (%.0f GB/s), other %.3f ms; "
+                      "%d candidates, picked #%d at %.0f GB/s (median %.0f, first %.0f), rescans %d"
+                      % (world, rank, r0, r1, gb, draws, ms, k, gb / k * 1e3, ms - k, pl["draws"], pl["picked"], pg[pl["picked"]],
+                         float(np.median(pg)), pg[0], pl["rescans"]), flush=True)
                 worst[draws] = max(worst[draws], ms)
                 buf.free()
         for draws in DRAWS:
