@@ -965,7 +965,9 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
     int *slots = nullptr;
     int rc = xcd_slots_for_launch(e, &slots);          // also probes the dispatch order once
     if (rc) return rc;
-    const bool select = max_draws > 1 && doubles >= (1L << 27) && !slots;
+    // ... and windows of 32 GiB or more always span several physical extents: 7.1-7.5 TB/s wherever they lie
+    // (profiles/r03/placement_scan.log, scaling_estimate*.log at N = 1): nothing to select there either
+    const bool select = max_draws > 1 && doubles >= (1L << 27) && doubles < (1L << 32) && !slots;
     const int cls = size_class(doubles);
     const double accept = select ? 0.985 * e->best_pattern_gbs[cls] : 0.0;
     void *cand[GORT_LUT_MAX_DRAWS] = {nullptr};

@@ -64,13 +64,13 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 }
 
 // grid nodes generated from indices; identical to streaming "vza phi sza 0" (SURVEY 8d, C3).
-// One workgroup per GEOM_ROWS LUT rows, a row = (member, sun zenith, view zenith): the azimuth-independent terms
+// One workgroup per GEOM_ROWS (4, 6 or 8: geom_rows_per_workgroup) LUT rows, a row = (member, sun zenith, view zenith): the azimuth-independent terms
 // of each row are evaluated ONCE into LDS, the rows side by side on the first lanes of one wavefront (the ~25
 // transcendentals of a row are a serial chain: four rows cost the issue time of one), then the lanes walk the
 // GEOM_ROWS x nphi azimuth nodes.  With 361 nodes per row this removes ~70 % of the transcendentals of the
 // per-tuple form.
 constexpr int GEOM_ROW_THREADS = 128;
-constexpr int GEOM_ROWS = 4;
+
 // mode 0: full stream records (GORT_COEF_STRIDE doubles per node); 1: compact 64-B records for the LUT kernel;
 // 2: FUSED for grids of a few bands (BASELINE config 3 is one band): the node's samples are formed right here from
 // its coefficients - no 128-B record per node written and read back (383 MB each way for the hemisphere grid,
@@ -78,6 +78,7 @@ constexpr int GEOM_ROWS = 4;
 #ifndef GORT_GEOM_WAVES
 #define GORT_GEOM_WAVES 3      // 168 VGPRs instead of 171: a third wave per SIMD, C3 133 -> 125 us; 4 would spill to scratch
 #endif
+template <int GEOM_ROWS>
 __global__ __launch_bounds__(GEOM_ROW_THREADS) __attribute__((amdgpu_waves_per_eu(GORT_GEOM_WAVES)))
 void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
@@ -196,14 +197,40 @@ static bool grid_mirrors(const gort_grid &g)
            g.vza0 >= 0.0 && g.dvza >= 0.0;
 }
 
-// (round 3 tried 8 rows per workgroup and 64-thread workgroups with the mirrored nodes: 83.6 and 84.3 us for BASELINE
-// config 3 against 78.8 with 4 rows x 128 threads, profiles/r03/c3_rows.log, c3_threads.log)
+// Rows per workgroup.  A workgroup's life is the serial chain of its rows' azimuth-independent terms (on as many lanes
+// as it has rows, the rest waiting) + its share of azimuth nodes; at 168 VGPRs a CU holds six of these two-wave
+// workgroups.  What decides is whether the launch fits the machine in ONE round: the hemisphere's 8281 rows are 2071
+// workgroups of four rows - 1.35 rounds of 1536 slots, the second a third full - but 1381 of six.  Measured with the
+// mirrored nodes (BASELINE config 3, profiles/r03/c3_rows2.log): 4 rows 79.3 us, 5 rows 79.8 (still two rounds),
+// 6 rows 68.7, 7 rows 76.3, 8 rows 83.6 (one round each, ever longer workgroups); 64-thread workgroups 84.3.
+// So: the smallest of 4 / 6 / 8 rows that makes one round, 4 where nothing does.
+static int geom_rows_per_workgroup(long rows)
+{
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        (void)hipGetLastError();
+        slots = cus * (GORT_GEOM_WAVES * 4 / (GEOM_ROW_THREADS / 64));
+    }
+    for (int per : {4, 6, 8})
+        if ((rows + per - 1) / per <= slots) return per;
+    return 4;
+}
+
 static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long rows, double *coef_dev,
                                     int compact, const double *L_dev, int nw, double *rsurf_dev, void *stream)
 {
-    hipLaunchKernelGGL(geometry_grid_kernel, dim3((unsigned)((rows + GEOM_ROWS - 1) / GEOM_ROWS)), dim3(GEOM_ROW_THREADS), 0,
-                       (hipStream_t)stream, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev,
-                       grid_mirrors(g) ? 1 : 0);
+    const int per = geom_rows_per_workgroup(rows), mirror = grid_mirrors(g) ? 1 : 0;
+    const dim3 grid((unsigned)((rows + per - 1) / per)), block(GEOM_ROW_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    if (per == 4)
+        hipLaunchKernelGGL(geometry_grid_kernel<4>, grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
+    else if (per == 6)
+        hipLaunchKernelGGL(geometry_grid_kernel<6>, grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
+    else
+        hipLaunchKernelGGL(geometry_grid_kernel<8>, grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
     return check_launch("geometry_grid_kernel");
 }
 
