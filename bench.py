@@ -191,6 +191,44 @@ def reference_build_id():
     return h.hexdigest()[:16]
 
 
+def measure_traffic(args, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: two child passes of this script under
+    `rocprofv3 --pmc` (WRITE_SIZE, then FETCH_SIZE: separate passes, as MI355X_MICROARCH.md prescribes), 3 steps each, no
+    parity / baselines / config 5; bytes = (WRITE_SIZE + 2 x FETCH_SIZE) x 1024, averaged over the launches of
+    expand_flat_kernel (gfx950's FETCH_SIZE counts half the bytes of wide reads).  Returns (bytes or None, how)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    child = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
+             "--sustain-s", "0", "--no-config5", "--lut-draws", "1", "--no-traffic", "--nsza", str(args.nsza), "--nw", str(args.nw)]
+    kb = {}
+    for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+        d = tempfile.mkdtemp(prefix="gort_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, timeout=timeout_s)
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "expand_flat_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals[row["Dispatch_Id"]] = vals.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not vals:
+                return None, "rocprofv3 --pmc %s: no counter rows (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-200:])
+            kb[counter] = sum(vals.values()) / len(vals)
+        except Exception as ex:                                   # noqa: BLE001  (a missing profile must not cost the bench line)
+            return None, "rocprofv3 --pmc %s failed: %r" % (counter, ex)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (kb["WRITE_SIZE"] + 2.0 * kb["FETCH_SIZE"]) * 1024.0, \
+        ("measured in this run: two child passes of bench.py under rocprofv3 --pmc (WRITE_SIZE %.0f KB, FETCH_SIZE %.0f KB per launch; "
+         "bytes = (WRITE + 2 FETCH) x 1024)" % (kb["WRITE_SIZE"], kb["FETCH_SIZE"]))
+
+
 def oracle_rows(wl, grid, rows_idx, phi_idx):
     """rsurf rows of grid nodes (global row = isza * nvza + ivza, azimuth index) from the CPU restatement."""
     from oracle import oracle as O
@@ -287,6 +325,8 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (ensemble) block")
     ap.add_argument("--c5-members", type=int, default=1000, help="members of the config-5 ensemble (1000 = BASELINE config 5)")
     ap.add_argument("--c5-chunk", type=int, default=40, help="members per LUT chunk of the config-5 block (0 = no LUTs)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="N = 1: do not measure the kernel's HBM traffic with two rocprofv3 --pmc child passes (~30 s)")
     ap.add_argument("--traffic-gb", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (GB)")
     args = ap.parse_args()
@@ -490,6 +530,13 @@ def main():
         if rank == 0:
             out["config5"] = c5
 
+    if rank == 0 and world == 1 and not args.no_traffic and args.traffic_gb is None:
+        # HBM traffic of the dominant kernel from the PMC counters, in this very run (the LUT buffers are gone: the child
+        # passes need the memory); a failure leaves `traffic` null and says why
+        t_bytes, how = measure_traffic(args)
+        out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t_bytes, how
+        if t_bytes and out["roofline"].get("algorithmic_bytes_per_launch"):
+            out["roofline"]["traffic_over_algorithmic"] = t_bytes / out["roofline"]["algorithmic_bytes_per_launch"]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             # the LUT of the timed region is gone (config 5 needed the memory): the check against the reference's own rows

@@ -1103,6 +1103,10 @@ def test_bench_json_contract():
     assert d["parity"]["nan_pattern_equal"] and d["parity"]["max_rel_err"] <= 1e-9
     assert "allgather" not in d and d["config5"]["allgather"]["gbs_received_per_gpu"] is None
     assert d["config5"]["parity"]["foreign_member"]["max_rel_err"] <= 1e-9
+    # the HBM traffic of the dominant kernel is measured inside the run (two rocprofv3 --pmc child passes): the bytes the
+    # counters saw per launch against the algorithmic 8 B per sample
+    assert r["traffic"] is not None, r["traffic_source"]
+    assert 0.99 <= r["traffic"] / r["algorithmic_bytes_per_launch"] <= 1.10 and "rocprofv3" in r["traffic_source"]
 
 
 # ------------------------------------------------- BASELINE.json full sizes

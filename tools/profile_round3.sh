@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-3 profiles (run on the GPU box through gpurun; outputs under gpurun_out/prof3/, the summaries are then
 # committed under profiles/r03/prof/).  The python program itself follows `--` (no env/bash hop under rocprofv3).
-#   A. headline bench: unprofiled, kernel-trace stats, WRITE_SIZE / FETCH_SIZE passes, final run with the measured traffic
+#   A. headline bench: unprofiled (it measures its own HBM traffic with two --pmc child passes), kernel-trace stats,
+#      WRITE_SIZE / FETCH_SIZE passes of our own (cross-check), a run with that figure handed in
 #   B. stream expansion at 65 536 and 1 048 576 random lines x 2101 bands (every line its own sun zenith): stats, HBM
 #      passes, SQ pass
 #   C. `-energy` stream (1M lines x 2101 bands, 91 sun zeniths): kernel trace with rows shared and with every line evaluated
@@ -19,10 +20,10 @@ prof() { # name, then rocprofv3 args..., then -- program
 }
 # ---- A
 cd "$R" && timeout -k 10 500 python3 bench.py > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"; echo "bench rc=$?"
-B="--steps 20 --warmup 3 --no-cpu-baseline --no-parity --sustain-s 0 --no-config5"
+B="--steps 20 --warmup 3 --no-cpu-baseline --no-parity --sustain-s 0 --no-config5 --no-traffic"
 prof bench_stats --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 "$R/bench.py" $B --lut-draws 1
-prof bench_pmc_write --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_pmc_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0 --no-config5 --lut-draws 1
-prof bench_pmc_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0 --no-config5 --lut-draws 1
+prof bench_pmc_write --pmc WRITE_SIZE --output-format csv -d "$OUT/bench_pmc_write" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0 --no-config5 --no-traffic --lut-draws 1
+prof bench_pmc_fetch --pmc FETCH_SIZE --output-format csv -d "$OUT/bench_pmc_fetch" -- python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-parity --sustain-s 0 --no-config5 --no-traffic --lut-draws 1
 # ---- B
 for n in 65536 1048576; do
   prof stream_${n}_stats --kernel-trace --stats --output-format csv -d "$OUT/stream_${n}_stats" -- python3 "$R/tools/bench_stream.py" $n 20 "all distinct"
