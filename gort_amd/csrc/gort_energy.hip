@@ -96,29 +96,18 @@ __global__ __launch_bounds__(256) void energy_rep_kernel(const double *__restric
     if (rep == line) uniq[1 + atomicAdd(&uniq[0], 1u)] = (unsigned)line;
 }
 
-// blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by the members;
-// energy[member][nA][nw][3].  DEDUP: workgroups stride over the list of the lines that stand for themselves (uniq).
-template <bool DEDUP>
-__global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopies,
-                                                                 const double *__restrict__ Lall, int nw,
-                                                                 const double *__restrict__ angles, long nA,
-                                                                 const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
-                                                                 double *__restrict__ energy_all,
-                                                                 const unsigned *__restrict__ uniq)
-{
-    __shared__ double s_part[5][ENERGY_THREADS / 64];
-    __shared__ double s_abar[5];
-    __shared__ double s_sun[6];
-    const long member = blockIdx.y;
-    const gort_canopy &c = canopies[member];
-    const double *__restrict__ L = Lall + member * L_NSLOT * nw;
-    double *__restrict__ energy = energy_all + member * nA * nw * 3;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const long n_lines = DEDUP ? (long)uniq[0] : nA;
-  for (long u = blockIdx.x; u < n_lines; u += gridDim.x) {
-    const long a = DEDUP ? (long)uniq[1 + u] : u;
-    if (DEDUP) __syncthreads();                                              // the shared arrays of the previous line are done with
+// The evaluation of ONE line by one 512-thread workgroup (thread = quadrature node); energy = this member's [nA][nw][3].
+struct EnergyShared {
+    double part[5][ENERGY_THREADS / 64];
+    double abar[5];
+    double sun[6];
+};
 
+__device__ __forceinline__ void energy_line(const gort_canopy &c, const double *__restrict__ L, int nw,
+                                            const double *__restrict__ angles, const double *__restrict__ nodes,
+                                            double *__restrict__ energy, long a, EnergyShared &sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
     // node geometry (gortt_albedo.c:91-105): vaa = pi + pi x_i in (0, 2pi); vza = acos(x_j)
@@ -138,22 +127,22 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         part[k] = wave_sum(part[k]);
-        if (lane == 0) s_part[k][wave] = part[k];
+        if (lane == 0) sh.part[k][wave] = part[k];
     }
     if (tid == 0) {
-        s_sun[0] = g.sun.fd;  s_sun[1] = g.sun.mu;  s_sun[2] = g.sun.t0;
-        s_sun[3] = g.sun.tp0; s_sun[4] = g.sun.eps; s_sun[5] = g.sun.pn0;
+        sh.sun[0] = g.sun.fd;  sh.sun[1] = g.sun.mu;  sh.sun[2] = g.sun.t0;
+        sh.sun[3] = g.sun.tp0; sh.sun[4] = g.sun.eps; sh.sun[5] = g.sun.pn0;
     }
     __syncthreads();
     if (tid < 5) {
         double t = 0.0;
-        for (int q = 0; q < ENERGY_THREADS / 64; ++q) t += s_part[tid][q];
-        s_abar[tid] = t;
+        for (int q = 0; q < ENERGY_THREADS / 64; ++q) t += sh.part[tid][q];
+        sh.abar[tid] = t;
     }
     __syncthreads();
     SunScalars s;
-    s.fd = s_sun[0];  s.mu = s_sun[1];  s.t0 = s_sun[2];  s.tp0 = s_sun[3];  s.eps = s_sun[4];  s.pn0 = s_sun[5];
-    const double aC = s_abar[0], aB = s_abar[1], aZ = s_abar[2], aG = s_abar[3], aT = s_abar[4];
+    s.fd = sh.sun[0];  s.mu = sh.sun[1];  s.t0 = sh.sun[2];  s.tp0 = sh.sun[3];  s.eps = sh.sun[4];  s.pn0 = sh.sun[5];
+    const double aC = sh.abar[0], aB = sh.abar[1], aZ = sh.abar[2], aG = sh.abar[3], aT = sh.abar[4];
     for (int i = tid; i < nw; i += ENERGY_THREADS) {
         const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
         const double albedo = dot5(aC, aB, aZ, aG, aT, b.C0, b.B, b.Z, b.G, b.T);
@@ -166,7 +155,47 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
         o[1] = 1. - albedo - Fd2 + Fu2;
         o[2] = Fd2 - Fu2;
     }
-  }
+}
+
+// the same behind a call: a loop around the inlined body lets the compiler hoist the body's loop-invariant loads in
+// front of the loop, which took the kernel from 135 to 256 VGPRs + 58 spilled (20 -> 24 us per line)
+__device__ __noinline__ void energy_line_call(const gort_canopy &c, const double *__restrict__ L, int nw,
+                                              const double *__restrict__ angles, const double *__restrict__ nodes,
+                                              double *__restrict__ energy, long a, EnergyShared &sh)
+{
+    energy_line(c, L, nw, angles, nodes, energy, a, sh);
+}
+
+// blockIdx.x = angle line, blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by
+// the members; energy[member][nA][nw][3]
+__global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopies,
+                                                                 const double *__restrict__ Lall, int nw,
+                                                                 const double *__restrict__ angles, long nA,
+                                                                 const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
+                                                                 double *__restrict__ energy_all)
+{
+    __shared__ EnergyShared sh;
+    const long member = blockIdx.y;
+    energy_line(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
+                (long)blockIdx.x, sh);
+}
+
+// the lines that stand for themselves (uniq[0] of them, uniq[1..]): workgroups stride over the list
+__global__ __launch_bounds__(ENERGY_THREADS) void energy_list_kernel(const gort_canopy *__restrict__ canopies,
+                                                                      const double *__restrict__ Lall, int nw,
+                                                                      const double *__restrict__ angles, long nA,
+                                                                      const double *__restrict__ nodes,
+                                                                      double *__restrict__ energy_all,
+                                                                      const unsigned *__restrict__ uniq)
+{
+    __shared__ EnergyShared sh;
+    const long member = blockIdx.y;
+    const long n_lines = uniq[0];
+    for (long u = blockIdx.x; u < n_lines; u += gridDim.x) {
+        __syncthreads();                                     // the shared arrays of the previous line are done with
+        energy_line_call(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
+                         (long)uniq[1 + u], sh);
+    }
 }
 
 // rows of the lines that share another line's sun direction: energy[line] = energy[rep[line]].  The output is walked as
@@ -250,8 +279,8 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     hipStream_t s = (hipStream_t)stream;
     if (!ws_dev || nA < ENERGY_DEDUP_MIN_LINES) {
         if (nA >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld lines in one launch", nA);
-        hipLaunchKernelGGL(energy_kernel<false>, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
-                           canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)nullptr);
+        hipLaunchKernelGGL(energy_kernel, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
+                           canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
         return check_launch("energy_kernel");
     }
     if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
@@ -274,9 +303,9 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     if ((rc = check_launch("energy_rep_kernel"))) return rc;
     const unsigned *rep = slot_of;
     const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
-    hipLaunchKernelGGL(energy_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
+    hipLaunchKernelGGL(energy_list_kernel, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
                        angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
-    if ((rc = check_launch("energy_kernel"))) return rc;
+    if ((rc = check_launch("energy_list_kernel"))) return rc;
     const int row = 3 * nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(energy_dev) / sizeof(double)) % CHUNK);
     // member m's slab starts nA*row doubles further: the same shift only if that is a multiple of CHUNK; the kernel's
