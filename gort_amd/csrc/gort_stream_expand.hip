@@ -4,7 +4,9 @@
 // stream_sample), so all of them write the same bits; narrow spectra take the per-sample / band-major kernels,
 // wide ones the aligned flat-panel kernel.  (Round 3 built a second wide form - one persistent 1024-thread workgroup per
 // CU with the band constants of all 2101 bands resident in the 160 KB of LDS, short row-major tasks, records staged
-// through an LDS ring - bitwise equal and 8 % SLOWER at a million lines: profiles/r03/experiments/lds_resident_stream_kernel.md.)
+// through an LDS ring - bitwise equal and 8 % SLOWER at a million lines; and a third, the flat kernel's waves made persistent
+// with the band constants of ONE segment of the spectrum in LDS, seven workgroups per CU - bitwise equal, 12-18 % slower:
+// profiles/r03/experiments/lds_resident_stream_kernel.md.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
