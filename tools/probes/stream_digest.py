@@ -1,3 +1,5 @@
+"""sha256 over the outputs of wide streams (5 band counts x 4 output alignments, NaN lines included): two builds of the
+stream kernel that print the same digest wrote the same bits.  Run from the repo root on a GPU box."""
 import sys, os, hashlib
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
