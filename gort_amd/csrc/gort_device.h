@@ -160,19 +160,23 @@ __device__ inline SunTerms sun_terms(const double *__restrict__ L, int nw, int i
 }
 
 // ---- the STREAM family's form of a sample ---------------------------------------------------------------------
-// rsurf is linear in everything but the two numbers p_df and t'_df (gortt_brdf.c:616-634, 348-365), the only ones in
-// which sun zenith and band meet non-linearly.  Regrouping gortt.c:484-557 around them,
+// rsurf is linear in everything but the two numbers R_df and T_df (gortt_brdf.c:552, 467-471), the only ones in which
+// sun zenith and band meet non-linearly, and those two share one denominator.  Regrouping gortt.c:484-557 and
+// gortt_brdf.c:348-365, 616-634 (p_df = R_df - t_ff X, t'_df = (T_df - p_ff X)(1 - t'_0), X = R_ff T_df + t_0 R_df)
+// around them,
 //
-//   rsurf = alpha p_df + (P1 mgk + P2 rs) t'_df + (Q1 mgk + Q2 rs + Q3 Zf + Q4 Tf + Q5 p_ff + Q6 B)
+//   rsurf = [ n1 (alpha - t0 S) + n2 (W - R_ff S) ] / (1 - x^2) + (Q1 mgk + Q2 rs + Q3 Zf + Q4 Tf + Q5 p_ff + Q6 B)
+//   x = 2 gamma mu,  n1 = (1-gamma)(1-x),  n2 = (1+2mu) (omega/2) (T_ff - t0),  W = P1 mgk + P2 rs,  S = alpha t_ff + W p_ff
 //
-// with NINE scalars per line (alpha .. Q6, line_terms) and six band constants, costs ~24 instructions + one
-// division per sample instead of the ~54 of sun_terms() + dot5(): the per-line stream kernel is fp64-VALU bound.
-// Every kernel that expands a STREAM (per line, grouped by sun zenith, band-major, per sample) evaluates exactly
+// with TWELVE scalars per line (alpha .. Q6, mu, t0, 1+2mu: line_terms) and twelve band constants: 24 instructions +
+// one reciprocal (28 issue slots) per sample, where sun_terms() + dot5() take ~54 and the round-2 form of this
+// regrouping (p_df and t'_df formed explicitly) took 32: the stream kernels are bound by fp64 issue or close to it.
+// Every kernel that expands a STREAM (flat panels, band-major, per sample, fused with the geometry) evaluates exactly
 // these functions, written with explicit FMAs and without contraction so that all of them produce the same bits;
 // the LUT family keeps the five (sun zenith, band) terms and dot5().  The two families differ by rounding only
 // (a few 1e-16 relative; both are held to 1e-9 against the reference).
-struct LineTerms { double alpha, P1, P2, Q1, Q2, Q3, Q4, Q5, Q6, mu, t0, omtp0, m2; };
-constexpr int LINE_NTERMS = 13;                // <= GORT_COEF_STRIDE: a LineTerms record is what layout 1 of the stream records holds
+struct LineTerms { double alpha, P1, P2, Q1, Q2, Q3, Q4, Q5, Q6, mu, t0, m2; };
+constexpr int LINE_NTERMS = 12;                // <= GORT_COEF_STRIDE: a LineTerms record is what layout 1 of the stream records holds
 
 __device__ inline LineTerms line_terms(double aC, double aB, double aZ, double aG, double aT, double fd, double mu,
                                        double t0, double tp0, double eps, double kep, double kk)
@@ -183,23 +187,24 @@ __device__ inline LineTerms line_terms(double aC, double aB, double aZ, double a
     const double cfk = (aC * omfd) * kep;                 // aC (1-fd) k_openep
     const double Zc = __builtin_fma(cfk, 1.0 - kk, aZ);   // what multiplies Z in the end
     const double sCT = aC + aT;
+    const double p1 = fd * sCT, p2 = Zc * fd;             // the weights of t'_df: mgk and rs
+    const double omtp0 = 1.0 - tp0;
     l.alpha = aC * fd;
-    l.P1 = fd * sCT;
-    l.P2 = Zc * fd;
-    l.Q1 = tp0 * l.P1;
-    l.Q2 = __builtin_fma(l.P2, eps, __builtin_fma(cfk, kk, aG));
+    l.P1 = p1 * omtp0;                                    // (1 - t'_0) of gortt_brdf.c:361 folded into the line
+    l.P2 = p2 * omtp0;
+    l.Q1 = tp0 * p1;
+    l.Q2 = __builtin_fma(p2, eps, __builtin_fma(cfk, kk, aG));
     l.Q3 = Zc * omfd;
     l.Q4 = omfd * sCT;
     l.Q5 = aC * omfd;
     l.Q6 = aB;
     l.mu = mu;
     l.t0 = t0;
-    l.omtp0 = 1.0 - tp0;
     l.m2 = 1.0 + 2.0 * mu;
     return l;
 }
 
-struct StreamBand { double g2, c1, c2, Rff, Tff, tff, pff, rs, mgk, Zf, Tf, B; };
+struct StreamBand { double g2, c1, c2, Rff, cT, tff, pff, rs, mgk, Zf, Tf, B; };
 
 __device__ inline StreamBand stream_band(const BandTerms &t)
 {
@@ -208,50 +213,50 @@ __device__ inline StreamBand stream_band(const BandTerms &t)
     b.g2 = 2.0 * t.gam;
     b.c1 = 1.0 - t.gam;
     b.c2 = t.omega / 2.0;
-    b.Rff = t.Rff;  b.Tff = t.Tff;  b.tff = t.tff;  b.pff = t.pff;
+    b.cT = b.c2 * t.Tff;
+    b.Rff = t.Rff;  b.tff = t.tff;  b.pff = t.pff;
     b.rs = t.rs;    b.mgk = t.mgk;  b.Zf = t.Zf;    b.Tf = t.Tf;   b.B = t.B;
     return b;
 }
 
-// p_df and t'_df of (sun zenith, band): R_df = (1-gamma)/(1+2 mu gamma), T_df = (omega/2)(1+2mu)(T_ff - t0)/(1-(2 gamma mu)^2)
-// (gortt_brdf.c:552, 467-471) share one division: 1/(1-x^2), x = 2 gamma mu
-__device__ __forceinline__ void sun_pair(const StreamBand &b, double mu, double t0, double omtp0, double m2, double &pdf,
-                                         double &tpdf)
+// 1 / den for the shared denominator 1 - x^2 of R_df = (1-gamma)/(1+x) and T_df (gortt_brdf.c:552, 467-471)
+__device__ __forceinline__ double stream_reciprocal(double den)
 {
 #pragma clang fp contract(off)
-    const double x = b.g2 * mu;
 #ifdef GORT_IEEE_DIV
-    const double inv = 1.0 / __builtin_fma(-x, x, 1.0);
+    return 1.0 / den;
 #else
-    // v_rcp_f64 + two Newton steps instead of the correctly rounded division sequence: ~8 instead of ~14 issue slots of
-    // the ~38 per sample of the per-line kernel (1 048 576 lines: 3.76 -> 3.40 ms), at most an ulp or two off - the
-    // same function in every stream kernel, so the same bits everywhere; x = 1 (2 gamma mu = 1) is singular either way
-    const double den = __builtin_fma(-x, x, 1.0);
-    double inv = __builtin_amdgcn_rcp(den);
-    inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
-    inv = __builtin_fma(__builtin_fma(-den, inv, 1.0), inv, inv);
+    // v_rcp_f64 + ONE third-order step (e = 1 - den r;  r (1 + e + e^2): 3 FMAs, error e^3) instead of the correctly
+    // rounded division sequence (~14 issue slots) or two Newton steps (4 FMAs): an ulp or two off - the same function
+    // in every stream kernel, so the same bits everywhere; x = 1 (2 gamma mu = 1) is singular either way
+    const double r = __builtin_amdgcn_rcp(den);
+    const double e = __builtin_fma(-den, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
 #endif
-    const double Rdf = (b.c1 * (1.0 - x)) * inv;
-    const double Tdf = ((b.c2 * m2) * (b.Tff - t0)) * inv;
-    const double X = __builtin_fma(b.Rff, Tdf, t0 * Rdf);
-    pdf = __builtin_fma(-b.tff, X, Rdf);                  // gortt_brdf.c:628-630
-    tpdf = __builtin_fma(-b.pff, X, Tdf) * omtp0;         // :423-424, :361
 }
 
 __device__ __forceinline__ double stream_sample(double alpha, double P1, double P2, double Q1, double Q2, double Q3,
-                                                double Q4, double Q5, double Q6, const StreamBand &b, double pdf, double tpdf)
+                                                double Q4, double Q5, double Q6, double mu, double t0, double m2,
+                                                const StreamBand &b)
 {
+#pragma clang fp contract(off)
+    const double x = b.g2 * mu;
+    const double inv = stream_reciprocal(__builtin_fma(-x, x, 1.0));
+    const double n1 = b.c1 * (1.0 - x);
+    const double n2 = m2 * __builtin_fma(-b.c2, t0, b.cT);
+    const double W = __builtin_fma(P2, b.rs, P1 * b.mgk);
+    const double S = __builtin_fma(W, b.pff, alpha * b.tff);
+    const double A = __builtin_fma(-t0, S, alpha);
+    const double Bc = __builtin_fma(-b.Rff, S, W);
+    const double num = __builtin_fma(n1, A, n2 * Bc);
     const double lin = __builtin_fma(Q6, b.B, __builtin_fma(Q5, b.pff, __builtin_fma(Q4, b.Tf, __builtin_fma(Q3, b.Zf,
                        __builtin_fma(Q2, b.rs, Q1 * b.mgk)))));
-    const double W = __builtin_fma(P2, b.rs, P1 * b.mgk);
-    return __builtin_fma(alpha, pdf, __builtin_fma(W, tpdf, lin));
+    return __builtin_fma(inv, num, lin);
 }
 
 __device__ __forceinline__ double stream_sample(const LineTerms &l, const StreamBand &b)
 {
-    double pdf, tpdf;
-    sun_pair(b, l.mu, l.t0, l.omtp0, l.m2, pdf, tpdf);
-    return stream_sample(l.alpha, l.P1, l.P2, l.Q1, l.Q2, l.Q3, l.Q4, l.Q5, l.Q6, b, pdf, tpdf);
+    return stream_sample(l.alpha, l.P1, l.P2, l.Q1, l.Q2, l.Q3, l.Q4, l.Q5, l.Q6, l.mu, l.t0, l.m2, b);
 }
 
 // the line terms of a classic record (narrow kernels derive them on the fly; the wide ones read them precomputed)

@@ -1,6 +1,6 @@
 // gort_stream_expand.hip -- expansion of an ARBITRARY-ANGLE stream (the reference's real interface: one line per
 // sun/view geometry in any order, gortt.c:232-329) from the per-line records of the geometry kernel into
-// rsurf[line][band].  Every kernel here evaluates the stream family's sample (gort_device.h: sun_pair +
+// rsurf[line][band].  Every kernel here evaluates the stream family's sample (gort_device.h:
 // stream_sample), so all of them write the same bits; narrow spectra take the per-sample / band-major kernels,
 // wide ones the aligned flat-panel kernel.  (Round 3 built a second wide form - one persistent 1024-thread workgroup per
 // CU with the band constants of all 2101 bands resident in the 160 KB of LDS, short row-major tasks, records staged
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void expand_stream_bands_kernel(const gort_can
 // The aligned flat form for ARBITRARY angle lines (every line has its own sun zenith): the chunking, the
 // band-preserving stride, the PANELS (K steps x W waves, each XCD one contiguous run of panels) and the slab-edge
 // handling of expand_flat_kernel; but a lane keeps the 12 band constants of its two bands in registers and forms
-// p_df, t'_df and the sample per step from the line's 13 LineTerms (records in layout 1, scalar loads, one step
-// ahead): ~24 instructions + one fp64 division per sample (gort_device.h, stream family).
+// the sample per step from the line's 12 LineTerms (records in layout 1, scalar loads, one step ahead): 24 instructions
+// + one reciprocal per sample (gort_device.h, stream family).
 // coef: stream records (GORT_COEF_STRIDE doubles), one pad record in front, tail pad behind.
 // one step of a wave: the samples of the chunk from the record(s) `rec`, stored with the slab-edge handling
 // a lane's two samples of a chunk: one 16-B store, but for the two edges of the output (front: the elements of chunk 0
@@ -135,10 +135,8 @@ __device__ __forceinline__ void flat_stream_step(const StreamBand (&t)[EPL], con
         double vv[2];
 #pragma unroll
         for (int w = 0; w < (WRAP ? 2 : 1); ++w) {
-            double pdf, tpdf;
-            sun_pair(t[j], rec[w][9], rec[w][10], rec[w][11], rec[w][12], pdf, tpdf);
             vv[w] = stream_sample(rec[w][0], rec[w][1], rec[w][2], rec[w][3], rec[w][4], rec[w][5], rec[w][6], rec[w][7],
-                                  rec[w][8], t[j], pdf, tpdf);
+                                  rec[w][8], rec[w][9], rec[w][10], rec[w][11], t[j]);
         }
         v[j] = (WRAP && second[j]) ? vv[1] : vv[0];
     }

@@ -130,7 +130,7 @@ def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
 
 def test_grid_lines_through_the_stream_equal_the_lut(setup):
     """The metric grid's angles (a slab of it) streamed as lines `vza phi sza 0`: the stream family (regrouped sample:
-    alpha p_df + W t'_df + linear part) against the LUT family (five terms, dot5) - the same numbers up to rounding of
+    one shared reciprocal x bilinear numerator + linear part) against the LUT family (five terms, dot5) - the same numbers up to rounding of
     two different associations: 1e-13 relative."""
     eng, c, torch = setup
     wl = np.arange(400.0, 2501.0)
