@@ -41,11 +41,9 @@ struct ExpandTuning {
     int depth = 2;
     int steps = -1;             // -1 = automatic: 6 with the static mapping, 16 with slot counters (fewer atomics)
     long waves = 2048;
-    // the per-line stream kernel is VALU bound with a heavy prologue (24 band constants per lane): long waves.  Panels
-    // of 64 steps x 33616 waves (2.2 GB per panel; streams up to 131 072 lines are ONE panel): 65 536 lines 232-290 us
-    // whatever the shape, 1 048 576 lines 3.76 ms against 3.83 (one panel) and 4.0-5.0 (8..16 steps)
-    long stream_waves = 16808;      // GORT_STREAM_WAVES: waves per panel of the per-line stream kernel (rounded like `waves`)
-    int stream_steps = 64;          // GORT_STREAM_STEPS: steps per wave = panel height of the per-line stream kernel
+    // the per-line stream kernel: automatic unless set (stream_panel_shape(), gort_stream_expand.hip)
+    long stream_waves = 0;          // GORT_STREAM_WAVES: waves per panel of the per-line stream kernel (rounded like `waves`); 0 = ~2048
+    int stream_steps = 0;           // GORT_STREAM_STEPS: steps per wave = panel height of the per-line stream kernel; 0 = from the stream's size
     ExpandTuning()
     {
         if (const char *v = getenv("GORT_EXPAND_NT")) nt = atoi(v) != 0;
@@ -53,14 +51,14 @@ struct ExpandTuning {
         if (const char *v = getenv("GORT_EXPAND_WAVES")) waves = atol(v);
         if (const char *v = getenv("GORT_STREAM_WAVES")) stream_waves = atol(v);
         if (const char *v = getenv("GORT_STREAM_STEPS")) stream_steps = atoi(v);
-        if (stream_steps < 1) stream_steps = 1;
+        if (stream_steps < 0) stream_steps = 0;
         if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_mode = atoi(v);
         if (const char *v = getenv("GORT_EXPAND_STEPS")) steps = atoi(v);
         if (xcd_mode < -1 || xcd_mode > 2) xcd_mode = -1;
         if (depth != 1 && depth != 2 && depth != 4) depth = 2;
         if (steps > 0) steps = (steps + depth - 1) / depth * depth;        // whole groups of DEPTH
         if (waves < 64) waves = 64;
-        if (stream_waves < 64) stream_waves = 64;
+        if (stream_waves != 0 && stream_waves < 64) stream_waves = 64;
     }
 };
 

@@ -9,6 +9,7 @@
 // profiles/r03/experiments/lds_resident_stream_kernel.md.)
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 #include "gort_flat.h"
@@ -257,15 +258,53 @@ bool stream_is_wide(int nw, long nA, bool want_scomp)
 }
 
 // panel shape of the per-line flat kernel: stride W (chunks) and steps K per wave
+// wave slots of the machine for expand_flat_stream_kernel (CUs x resident waves per CU; 256 x 28 on an MI355X)
+static long stream_wave_slots()
+{
+    static long slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0, wgs = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs, expand_flat_stream_kernel<true>, 256, 0) != hipSuccess || wgs < 1) wgs = 7;
+        (void)hipGetLastError();
+        slots = (long)cus * wgs * 4;
+    }
+    return slots;
+}
+
+// The panels of the flat stream kernel: W waves x K steps.  W = one band-preserving stride of about 2048 chunks (2101 for
+// the 2101-band spectrum: 128 lines per step).  K from the size of the stream: with M = chunks / wave slots steps per
+// slot, a launch costs about tau (M + K/2) for its steps and its tail - the waves of a launch drift apart, so the last
+// ones end half a wave life after the slots begin to drain - plus a prologue per wave, tau_p M / K (24 band constants per
+// lane, ~2 us of a slot): K ~ sqrt(1.2 M), but no fewer steps than make ONE round of waves out of a small stream
+// (<= 16), at most 32, and the rows cut into EQUAL panels (a ragged last panel leaves the XCD that owns it idle).
+// Measured with the 28-slot sample (profiles/r03/stream_panel_sweep.log; W x K, us, 91 sun zeniths, separate processes):
+//   65 536 lines     16808 x 64: 233-239   2101 x 64: 229   2101 x 32: 215-222   2101 x 16: 200-203   2101 x 12: 197-199
+//   262 144 lines    16808 x 64: 857-869   2101 x 64: 818-837   2101 x 32: 783-808   2101 x 16: 816-830
+//   1 048 576 lines  16808 x 64: 3259-3329   2101 x 64: 3180-3248   2101 x 28..36: 3111-3137   2101 x 16: 3211-3224   2101 x 12: 3316-3341
 static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
 {
     const ExpandTuning &tune = tuning();
-    // small streams: fewer waves, so that a wave still has ~6 steps to spread its prologue (24 band constants per lane)
-    // over - 3000 lines: 20 us with 8404 waves, 36 us with 33616; 8192 lines: 37 against 43
-    long target = tune.stream_waves;
-    if (chunks / 6 < target) target = chunks / 6 < 4202 ? 4202 : chunks / 6;
-    *stride = flat_stride(nw, chunks, target);
-    *steps = tune.stream_steps;
+    *stride = flat_stride(nw, chunks, tune.stream_waves > 0 ? tune.stream_waves : 2048);
+    const long rows = (chunks + *stride - 1) / *stride;          // steps of a wave that runs through the whole stream
+    long K;
+    if (tune.stream_steps > 0) {
+        K = tune.stream_steps;
+    } else {
+        const double M = (double)chunks / (double)stream_wave_slots();
+        double k = sqrt(1.2 * M);
+        const double one_round = M < 16.0 ? M : 16.0;
+        if (k < one_round) k = one_round;
+        K = (long)(k + 0.5);
+        K = K < 4 ? 4 : (K > 32 ? 32 : K);
+    }
+    if (K > rows) K = rows;
+    if (tune.stream_steps <= 0) {
+        const long panels = (rows + K - 1) / K;
+        K = (rows + panels - 1) / panels;
+    }
+    *steps = (int)K;
 }
 
 // readable records the wide expansions may touch behind the last line (the caller also keeps ONE in front)
