@@ -417,7 +417,7 @@ static int refresh_lambda_table(gort_engine *e)
 {
     int rc = GORT_OK;
     if (e->have_canopy && e->have_spectra) {
-        rc = e->L.reserve(sizeof(double) * L_NSLOT * (size_t)e->nw * (size_t)e->n_members);
+        rc = e->L.reserve(sizeof(double) * lambda_table_doubles(e->nw, e->n_members));
         if (rc) return rc;
         rc = launch_lambda_table(e->canopy.as<gort_canopy>(), e->n_members, e->nw, e->spectra.as<double>(),
                                  e->L.as<double>(), e->stream);
@@ -645,7 +645,8 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     }
     if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, wide ? 1 : 0, e->stream))) return rc;
     GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
-    rc = launch_expand_stream(c, e->L.as<double>(), e->nw, coef, nA, rsurf_dev, scomp_dev, xcd_slots, e->stream, false);
+    rc = launch_expand_stream(c, e->L.as<double>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw, coef, nA, rsurf_dev,
+                              scomp_dev, xcd_slots, e->stream, false);
     GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
     e->stream_form = wide ? 1 : 0;
     return rc;
@@ -865,7 +866,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         if (nw <= 8 && fuse) return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream);
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
-        return launch_expand_stream(c, e->L.as<double>(), nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr, e->stream, true);
+        return launch_expand_stream(c, e->L.as<double>(), nullptr, nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr, e->stream, true);
     }
     // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).
     // Full-size slabs: ONE buffer, reused by every call - the 191 MB of records the geometry kernel writes are

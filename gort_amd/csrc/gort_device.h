@@ -204,7 +204,10 @@ __device__ inline LineTerms line_terms(double aC, double aB, double aZ, double a
     return l;
 }
 
-struct StreamBand { double g2, c1, c2, Rff, cT, tff, pff, rs, mgk, Zf, Tf, B; };
+// 96 B, in this order in the band table of the flat stream kernel (stream_band_table(): six 16-B loads per band)
+struct alignas(16) StreamBand { double g2, c1, c2, Rff, cT, tff, pff, rs, mgk, Zf, Tf, B; };
+constexpr int STREAM_BAND_DOUBLES = 12;
+static_assert(sizeof(StreamBand) == STREAM_BAND_DOUBLES * sizeof(double), "StreamBand is the band table's record");
 
 __device__ inline StreamBand stream_band(const BandTerms &t)
 {

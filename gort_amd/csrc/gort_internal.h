@@ -50,7 +50,17 @@ static_assert(C_PAD1 + 1 == GORT_COEF_STRIDE, "record size");
 // ---- launchers implemented in the .hip files; all asynchronous on `stream` ----
 // (void* stream is a hipStream_t)
 int launch_gap_probabilities(gort_canopy *members_dev, int n_members, void *stream);
-// member-batched: canopies[n], spectra[n][3][nw] (rsoil, rleaf, tleaf) -> L[n][L_NSLOT][nw]
+// member-batched: canopies[n], spectra[n][3][nw] (rsoil, rleaf, tleaf) -> L[n][L_NSLOT][nw], followed by the first member's
+// StreamBand table [nw][12] (gort_device.h; stream_band_table() finds it): lambda_table_doubles() doubles in all
+inline size_t stream_band_table_offset(int nw, int n_members)            // in doubles, even: the table's records are 16-B aligned
+{
+    return ((size_t)L_NSLOT * n_members * (size_t)nw + 1) & ~(size_t)1;
+}
+inline size_t lambda_table_doubles(int nw, int n_members) { return stream_band_table_offset(nw, n_members) + (size_t)12 * nw; }
+inline const double *stream_band_table(const double *L_dev, int nw, int n_members)
+{
+    return L_dev + stream_band_table_offset(nw, n_members);
+}
 int launch_lambda_table(const gort_canopy *canopies_dev, int n_members, int nw, const double *spectra_dev,
                         double *L_dev, void *stream);
 // leaf/soil spectra of ensemble members on the device (gort_spectra.hip); tables from gort_host.cpp
@@ -113,8 +123,10 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin);
 // five-term sample, so that every LUT path writes the same bits.
 long expand_stream_tail_pad_records(int nw, long nA);
 bool stream_is_wide(int nw, long nA, bool want_scomp);
-int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
-                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream, bool grid_form);
+// band_table_dev: stream_band_table() of the engine's L (wide streams only; may be null for grid_form)
+int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, const double *band_table_dev, int nw,
+                         const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream,
+                         bool grid_form);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);

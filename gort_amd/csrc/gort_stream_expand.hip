@@ -154,30 +154,51 @@ __device__ __forceinline__ void load_line_terms(double (&rec)[WRAP ? 2 : 1][LINE
     }
 }
 
-// The steps of a wave.  One record set: the compiler issues the scalar loads of step k+1 behind the arithmetic of step
-// k and the wave waits for them at the top of the next step; the other waves of the SIMD (6 at 78 VGPRs) fill that
-// gap.  A hand-made double buffer (loads of step k+1 in front of the arithmetic of step k, two SGPR sets) cost a wave
-// of occupancy and ran 30 % SLOWER (4.54 against 3.44 ms for 1 048 576 lines): this kernel lives on thread-level
-// parallelism.
+// The steps of a wave.  One record set, the first record already requested by the caller (in front of its wait for the band
+// constants); the compiler places the scalar loads of step k+1 behind the arithmetic of step k and the wave waits for
+// them at the top of the next step; the other waves of the SIMD fill that gap.  (One step is read beyond the last:
+// expand_stream_tail_pad_records().)  A hand-made double buffer (loads of step k+1 in front of the arithmetic of step
+// k, two SGPR sets) cost a wave of occupancy and ran 30 % SLOWER in round 2: this kernel lives on thread-level parallelism.
 template <bool NT, bool WRAP>
 __device__ __forceinline__ void flat_stream_loop(const StreamBand (&t)[EPL], const bool (&second)[EPL], int first_off,
                                                  int last_step, int last_off, int da, long step, int k_wave,
-                                                 const double *__restrict__ rec_w, double *__restrict__ out_w, int lane)
+                                                 double (&r)[WRAP ? 2 : 1][LINE_NTERMS], const double *__restrict__ rec_w,
+                                                 double *__restrict__ out_w, int lane)
 {
     const long rec_step = (long)da * GORT_COEF_STRIDE;
     double *o = out_w + EPL * lane;
-    double r[WRAP ? 2 : 1][LINE_NTERMS];
     for (int kk = 0; kk < k_wave; ++kk) {
-        load_line_terms<WRAP>(r, rec_w);
-        rec_w += rec_step;
         flat_stream_step<NT, WRAP>(t, second, r, kk == 0 && first_off > 0, kk == last_step, first_off, last_off, o, lane);
+        rec_w += rec_step;
+        load_line_terms<WRAP>(r, rec_w);
         o += step;
     }
 }
 
+// the prologue of a wave behind its index arithmetic: the two bands of every lane (twelve 16-B loads off the band table),
+// the first record (scalar loads) requested while those are in flight
+template <bool NT, bool WRAP>
+__device__ __forceinline__ void flat_stream_wave(const StreamBand *__restrict__ bands, int nw, int band_w, int first_off,
+                                                 int last_step, int last_off, int da, long step, int k_wave,
+                                                 const double *__restrict__ rec_w, double *__restrict__ out_w, int lane)
+{
+    StreamBand t[EPL];
+    bool second[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        int band = band_w + EPL * lane + j;
+        second[j] = WRAP && band >= nw;                      // nw >= CHUNK on this path: one wrap at most
+        if (second[j]) band -= nw;
+        t[j] = bands[band];
+    }
+    double r[WRAP ? 2 : 1][LINE_NTERMS];
+    load_line_terms<WRAP>(r, rec_w);
+    flat_stream_loop<NT, WRAP>(t, second, first_off, last_step, last_off, da, step, k_wave, r, rec_w, out_w, lane);
+}
+
 // 70 VGPRs, 7 waves/SIMD.  Forcing 8 (amdgpu_waves_per_eu) spills 68 B per lane to scratch and halves the rate.
 template <bool NT>
-__global__ __launch_bounds__(256) void expand_flat_stream_kernel(const double *__restrict__ L, int nw,
+__global__ __launch_bounds__(256) void expand_flat_stream_kernel(const StreamBand *__restrict__ bands, int nw,
                                                                   const double *__restrict__ coef, long n_total,
                                                                   int shift, long stride_chunks, int da,
                                                                   int steps_per_wave, FastDiv div_stride, FastDiv div_nw,
@@ -214,21 +235,12 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const double *_
         if ((unsigned)rel == k_last * stride) last_step = (int)k_last;        // ends in the slab's last chunk
     }
     const int first_off = c0 == 0 ? shift : 0;
-    StreamBand t[EPL];
-    bool second[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-        int band = band_w + EPL * lane + j;
-        second[j] = band >= nw;                              // nw >= CHUNK on this path: one wrap at most
-        if (second[j]) band -= nw;
-        t[j] = stream_band(load_band(L, nw, band));
-    }
     const double *rec_w = coef + a_w * GORT_COEF_STRIDE;     // may point at the front pad record
     double *out_w = out + e0;
     if (band_w + CHUNK - 1 >= nw)
-        flat_stream_loop<NT, true>(t, second, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
+        flat_stream_wave<NT, true>(bands, nw, band_w, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
     else
-        flat_stream_loop<NT, false>(t, second, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
+        flat_stream_wave<NT, false>(bands, nw, band_w, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
 }
 
 }  // namespace
@@ -257,7 +269,6 @@ bool stream_is_wide(int nw, long nA, bool want_scomp)
     return !want_scomp && nw >= CHUNK && nA * (long)nw >= (1L << 22);
 }
 
-// panel shape of the per-line flat kernel: stride W (chunks) and steps K per wave
 // wave slots of the machine for expand_flat_stream_kernel (CUs x resident waves per CU; 256 x 28 on an MI355X)
 static long stream_wave_slots()
 {
@@ -274,15 +285,16 @@ static long stream_wave_slots()
 }
 
 // The panels of the flat stream kernel: W waves x K steps.  W = one band-preserving stride of about 2048 chunks (2101 for
-// the 2101-band spectrum: 128 lines per step).  K from the size of the stream: with M = chunks / wave slots steps per
-// slot, a launch costs about tau (M + K/2) for its steps and its tail - the waves of a launch drift apart, so the last
-// ones end half a wave life after the slots begin to drain - plus a prologue per wave, tau_p M / K (24 band constants per
-// lane, ~2 us of a slot): K ~ sqrt(1.2 M), but no fewer steps than make ONE round of waves out of a small stream
-// (<= 16), at most 32, and the rows cut into EQUAL panels (a ragged last panel leaves the XCD that owns it idle).
-// Measured with the 28-slot sample (profiles/r03/stream_panel_sweep.log; W x K, us, 91 sun zeniths, separate processes):
-//   65 536 lines     16808 x 64: 233-239   2101 x 64: 229   2101 x 32: 215-222   2101 x 16: 200-203   2101 x 12: 197-199
-//   262 144 lines    16808 x 64: 857-869   2101 x 64: 818-837   2101 x 32: 783-808   2101 x 16: 816-830
-//   1 048 576 lines  16808 x 64: 3259-3329   2101 x 64: 3180-3248   2101 x 28..36: 3111-3137   2101 x 16: 3211-3224   2101 x 12: 3316-3341
+// the 2101-band spectrum: 128 lines per step).  K from the size of the stream.  With M = chunks / wave slots steps per
+// slot, three things pull: the stores of short-lived waves go faster (bare stores: 6 / 16 / 64 steps 6.3 / 6.1 / 5.6
+// TB/s), the waves of a launch drift apart so its tail costs about K/2 steps whatever M, and every
+// wave pays a prologue (twelve 16-B loads of band constants, ~2 us of its slot).  Measured optimum with the 28-slot
+// sample and the band-table prologue (profiles/r03/stream_panel_sweep.log, us for K = 8 / 12 / 16 / 20 / 24, W = 2101):
+//   8192 lines (M = 19)       31 / 34 / 33 / - / 36            131 072 lines (M = 300)    432 / 399 / 388 / - / 403
+//   32 768 lines (M = 75)     105 / 103 / 110 / - / 115        262 144 lines (M = 600)    - / 817 / 775 / 780 / 791
+//   65 536 lines (M = 150)    - / 200 / 209 / 209 / 213        1 048 576 lines (M = 2400) - / 3178 / 3085 / 3052 / 3060
+// i.e. K = 4 log2(M) - 16 between 8 and 22 (round 2 ran 64 steps x 16 808 waves at every size: 233 us / 3.30 ms for
+// 65 536 / 1 048 576 lines), and the rows cut into EQUAL panels: a ragged last panel leaves the XCD that owns it idle.
 static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
 {
     const ExpandTuning &tune = tuning();
@@ -293,11 +305,8 @@ static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
         K = tune.stream_steps;
     } else {
         const double M = (double)chunks / (double)stream_wave_slots();
-        double k = sqrt(1.2 * M);
-        const double one_round = M < 16.0 ? M : 16.0;
-        if (k < one_round) k = one_round;
-        K = (long)(k + 0.5);
-        K = K < 4 ? 4 : (K > 32 ? 32 : K);
+        K = (long)(4.0 * log2(M > 1.0 ? M : 1.0) - 16.0 + 0.5);
+        K = K < 8 ? 8 : (K > 22 ? 22 : K);
     }
     if (K > rows) K = rows;
     if (tune.stream_steps <= 0) {
@@ -317,10 +326,12 @@ long expand_stream_tail_pad_records(int nw, long nA)
     return 2 * (stride * CHUNK / nw) + 4;       // one step of prefetch (da lines) + wrap record + slack
 }
 
-static int launch_expand_stream_flat(const double *L_dev, int nw, const double *coef_dev, long nA, double *rsurf_dev,
+static int launch_expand_stream_flat(const double *band_table_dev, int nw, const double *coef_dev, long nA, double *rsurf_dev,
                                      int *xcd_slots_dev, hipStream_t s)
 {
     const ExpandTuning &tune = tuning();
+    if (!band_table_dev) return fail(GORT_EINVAL, "stream expansion: wide stream without the band table");
+    const StreamBand *bands = reinterpret_cast<const StreamBand *>(band_table_dev);
     const long n_total = nA * (long)nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(rsurf_dev) / sizeof(double)) % CHUNK);
     const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
@@ -335,17 +346,17 @@ static int launch_expand_stream_flat(const double *L_dev, int nw, const double *
     const int xcd_mode = resolve_xcd_mode(xcd_slots_dev);
     const long useful = (panels * stride + 3) / 4;
     XcdDuty duty;
-    // equal XCD shares: this kernel is VALU bound, the duty weights of the LUT kernel (28:32) change nothing here
-    // (tried: 28:32, 32:28, 30:32 against equal, 65 536 and 1 048 576 lines)
+    // equal XCD shares: the duty weights of the LUT kernel (28:32) change nothing here (tried in rounds 2 and 3, the
+    // second time with the short panels: 26:32, 28:32, 30:32, 32:30, 32:28 against equal, 65 536 and 1 048 576 lines)
     const long nblocks = plan_xcd_duty(xcd_mode, useful, nullptr, duty);
     if (nblocks >= (1L << 31)) return fail(GORT_EINVAL, "stream expansion: %ld workgroups in one launch", nblocks);
     const dim3 grid((unsigned)nblocks);
     if (tune.nt)
-        hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, L_dev, nw, coef_dev, n_total, shift, stride,
+        hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, bands, nw, coef_dev, n_total, shift, stride,
                            da, steps, make_fast_div((unsigned)stride), make_fast_div((unsigned)nw), rsurf_dev, xcd_mode, duty,
                            useful, xcd_slots_dev);
     else
-        hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, L_dev, nw, coef_dev, n_total, shift, stride,
+        hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, bands, nw, coef_dev, n_total, shift, stride,
                            da, steps, make_fast_div((unsigned)stride), make_fast_div((unsigned)nw), rsurf_dev, xcd_mode, duty,
                            useful, xcd_slots_dev);
     return check_launch("expand_flat_stream_kernel");
@@ -354,14 +365,15 @@ static int launch_expand_stream_flat(const double *L_dev, int nw, const double *
 // coef_dev: stream records with ONE readable pad record in front and expand_stream_tail_pad_records() behind the last
 // line; wide streams (stream_is_wide): records in layout 1, the flat-panel kernel.
 // grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's sample.
-int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *coef_dev, long nA,
-                         double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream, bool grid_form)
+int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, const double *band_table_dev, int nw,
+                         const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream,
+                         bool grid_form)
 {
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
     hipStream_t s = (hipStream_t)stream;
     if (!grid_form && stream_is_wide(nw, nA, scomp_dev != nullptr))
-        return launch_expand_stream_flat(L_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, s);
+        return launch_expand_stream_flat(band_table_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, s);
     const long groups = (nA + STREAM_LINES - 1) / STREAM_LINES;
     if (nw >= 64 && groups <= 65535) {
         const dim3 grid((unsigned)((nw + 255) / 256), (unsigned)groups), block(256);

@@ -1,9 +1,11 @@
 // gort_tables.hip -- the small tables the expansion kernels read: the band-only two-stream closed forms
-// L[member][11][nw] (gortt_brdf.c:348-634 hoisted out of the per-sample loop) and, for LUT grids, the five
+// L[member][11][nw] (gortt_brdf.c:348-634 hoisted out of the per-sample loop) with, behind the last member, the first
+// member's twelve StreamBand constants per band ([nw][12], what the flat stream kernel keeps per lane) and, for LUT grids, the five
 // (sun zenith, band) terms sun[q][5][nw] of every sun row.
 #include <hip/hip_runtime.h>
 
 #include "gort_device.h"
+#include "gort_internal.h"
 
 namespace gort {
 namespace {
@@ -12,7 +14,7 @@ namespace {
 // blockIdx.y = ensemble member: canopy[m], spectra[m][3][nw] (rsoil, rleaf, tleaf) -> L[m][11][nw]
 __global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__restrict__ canopies, int nw,
                                                             const double *__restrict__ spectra,
-                                                            double *__restrict__ Lall)
+                                                            double *__restrict__ Lall, StreamBand *__restrict__ stream_bands)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw) return;
@@ -43,6 +45,9 @@ __global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__
     L[L_ZF * nw + i] = (tpff - c.k_openep) * rs;
     L[L_TF * nw + i] = tpff * mgk;
     L[L_B * nw + i] = (1.0 - omega) * omega * (1.0 - gfun);
+    // the band constants of the stream family's sample, ready-made for the flat stream kernel (single-canopy streams:
+    // member 0): the same stream_band() of the same eleven numbers every other stream kernel evaluates per sample
+    if (m == 0 && stream_bands) stream_bands[i] = stream_band(load_band(L, nw, i));
 }
 
 // sun[q - q_begin][5][nw] with q = member * nsza + isza: the "sun rows" of an ensemble are (member, sun zenith)
@@ -77,7 +82,7 @@ int launch_lambda_table(const gort_canopy *canopies_dev, int n_members, int nw, 
 {
     if (nw <= 0 || n_members <= 0) return GORT_OK;
     hipLaunchKernelGGL(lambda_table_kernel, dim3((nw + 255) / 256, n_members), dim3(256), 0, (hipStream_t)stream,
-                       canopies_dev, nw, spectra_dev, L_dev);
+                       canopies_dev, nw, spectra_dev, L_dev, reinterpret_cast<StreamBand *>(L_dev + stream_band_table_offset(nw, n_members)));
     return check_launch("lambda_table_kernel");
 }
 
