@@ -5,6 +5,8 @@ must write the SAME BITS for the same lines, agree with the LUT path on grid ang
 
 Reference interface: the per-line loop of main(), gortt.c:232-329 (+ gortt_rsurf, gortt.c:385-578)."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -192,3 +194,23 @@ def test_member_batched_few_band_stream_fuses_the_same_way():
     os.environ.pop("GORT_STREAM_FUSE", None)
     ens.close()
     assert fused.shape == (9, 40, 4) and np.array_equal(fused.view(np.int64), two.view(np.int64))
+
+
+def test_flat_kernel_panel_shapes_write_the_same_bits():
+    """The panel shape of the flat stream kernel (waves x steps: chosen from the stream's size, or GORT_STREAM_WAVES /
+    GORT_STREAM_STEPS) changes the ORDER in which chunks are written, never a bit: one sha256 over 20 outputs (five band
+    counts x four output alignments, NaN lines included; tools/probes/stream_digest.py) under the automatic shape,
+    round 2's 64 steps x ~16 808 waves, very short and ragged panels, the three XCD mappings, plain stores.  (The tuning is read once per process.)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for shape in ({}, {"GORT_STREAM_WAVES": "16808", "GORT_STREAM_STEPS": "64"}, {"GORT_STREAM_STEPS": "3", "GORT_EXPAND_XCD": "2"},
+                  {"GORT_STREAM_WAVES": "5000", "GORT_STREAM_STEPS": "7", "GORT_EXPAND_XCD": "0", "GORT_EXPAND_NT": "0"}):
+        env = dict(os.environ)
+        env.update(shape)
+        run = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "stream_digest.py")], capture_output=True,
+                             timeout=600, env=env, cwd=root)
+        assert run.returncode == 0, run.stderr.decode()[-2000:]
+        line = [x for x in run.stdout.decode().splitlines() if x.startswith("digest ")]
+        assert line, run.stdout.decode()[-500:]
+        digests[str(shape)] = line[-1]
+    assert len(set(digests.values())) == 1, digests
