@@ -196,7 +196,7 @@ __device__ __forceinline__ void flat_stream_wave(const StreamBand *__restrict__ 
     flat_stream_loop<NT, WRAP>(t, second, first_off, last_step, last_off, da, step, k_wave, r, rec_w, out_w, lane);
 }
 
-// 70 VGPRs, 7 waves/SIMD.  Forcing 8 (amdgpu_waves_per_eu) spills 68 B per lane to scratch and halves the rate.
+// 72 VGPRs, 7 waves/SIMD.  Forcing 8 (amdgpu_waves_per_eu) spills 20 VGPRs to scratch (round 2: halved the rate).
 template <bool NT>
 __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const StreamBand *__restrict__ bands, int nw,
                                                                   const double *__restrict__ coef, long n_total,
