@@ -237,10 +237,66 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const StreamBan
     const int first_off = c0 == 0 ? shift : 0;
     const double *rec_w = coef + a_w * GORT_COEF_STRIDE;     // may point at the front pad record
     double *out_w = out + e0;
-    if (band_w + CHUNK - 1 >= nw)
+    if (band_w + CHUNK - 1 >= nw) {
         flat_stream_wave<NT, true>(bands, nw, band_w, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
-    else
+    } else {
         flat_stream_wave<NT, false>(bands, nw, band_w, first_off, last_step, last_off, da, step, k_wave, rec_w, out_w, lane);
+    }
+}
+
+// ---- spectra of 17 ... 127 bands: lines in lanes, bands through the scalar cache, rows transposed in LDS ------------
+// With fewer than 128 bands a 1-KiB chunk spans several lines; a flat form whose lanes fetch their own line terms (six
+// 16-B loads per element and step) was built and is bound by the issue of those loads (1M lines x 32 / 64 / 127 bands:
+// 152 / 275 / 508 us, the narrow kernels 274 / 478 / 538; profiles/r03/stream_mid_bands.log).  Here a wave takes 64 consecutive LINES:
+// lane = line, its twelve terms loaded once; the bands come one after the other with their twelve constants wave-uniform
+// (scalar loads off the StreamBand table), so a sample costs its 28 issue slots and nothing else.  The samples of 16
+// bands go through a wave-private LDS tile [64 lines][16 bands] and leave as sixteen stores in which 16 lanes write the
+// 128 contiguous bytes of one line (a lane-per-line store would touch 64 cache lines per instruction).  Rows of a
+// multiple of 16 bands are whole cache lines and leave non-temporally (32 / 64 / 96 bands: 64 / 110 / 172 us); other
+// rows straddle lines whose halves are written a tile apart, which plain stores let the L2 merge (17 / 65 / 127 bands:
+// 57 / 249 / 483 us plain, 111 / 398 / 891 non-temporal).
+constexpr int TILE_BANDS = 16;
+constexpr int TILE_PITCH = TILE_BANDS + 1;                   // doubles per line of the tile: odd, so that lanes spread over the banks
+template <bool NT>
+__global__ __launch_bounds__(256) void expand_tile_stream_kernel(const StreamBand *__restrict__ bands, int nw,
+                                                                  const double *__restrict__ coef, long nA,
+                                                                  double *__restrict__ out)
+{
+    __shared__ double s_tile[4][64 * TILE_PITCH];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long a0 = ((long)blockIdx.x * 4 + wave_in_block) * 64;
+    if (a0 >= nA) return;
+    double *tile = s_tile[wave_in_block];
+    const long a = a0 + lane < nA ? a0 + lane : nA - 1;       // lanes behind the stream compute the last line again, store nothing
+    const dbl2 *p = reinterpret_cast<const dbl2 *>(coef + a * GORT_COEF_STRIDE);
+    dbl2 r[LINE_NTERMS / 2];
+#pragma unroll
+    for (int q = 0; q < LINE_NTERMS / 2; ++q) r[q] = p[q];
+    // the stores of a tile: lane -> (line 4 k + lane / 16, band lane % 16), k = 0 .. 15
+    const int sl = lane >> 4, sb = lane & 15;
+    const long lines_here = nA - a0 < 64 ? nA - a0 : 64;
+    for (int t0 = 0; t0 < nw; t0 += TILE_BANDS) {
+        const int nb = nw - t0 < TILE_BANDS ? nw - t0 : TILE_BANDS;
+#pragma unroll 2
+        for (int i = 0; i < nb; ++i) {
+            const StreamBand b = bands[t0 + i];                                   // wave-uniform: scalar loads
+            tile[lane * TILE_PITCH + i] = stream_sample(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, r[4].x,
+                                                        r[4].y, r[5].x, r[5].y, b);
+        }
+        if (sb < nb) {
+            double *o = out + (a0 + sl) * nw + t0 + sb;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int line = 4 * k + sl;
+                if (line < lines_here) {
+                    const double v = tile[line * TILE_PITCH + sb];
+                    if (NT) __builtin_nontemporal_store(v, o + (long)(4 * k) * nw);
+                    else o[(long)(4 * k) * nw] = v;
+                }
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -264,9 +320,13 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
 }
 
 // ---- aligned flat forms: large, wide streams without component spectra (their records are in layout 1) ----
+// (>= 128 bands: the flat-panel kernel from 4M samples; 17 ... 127 bands: the tile kernel from 256K samples.  Up to 16
+// bands the stream is fused with the geometry unless GORT_STREAM_FUSE=0, and then it takes the narrow kernels.)
+constexpr int TILE_MIN_BANDS = 17;
 bool stream_is_wide(int nw, long nA, bool want_scomp)
 {
-    return !want_scomp && nw >= CHUNK && nA * (long)nw >= (1L << 22);
+    if (want_scomp || nw < TILE_MIN_BANDS) return false;
+    return nA * (long)nw >= (nw < CHUNK ? (1L << 18) : (1L << 22));
 }
 
 // wave slots of the machine for expand_flat_stream_kernel (CUs x resident waves per CU; 256 x 28 on an MI355X)
@@ -319,7 +379,7 @@ static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
 // readable records the wide expansions may touch behind the last line (the caller also keeps ONE in front)
 long expand_stream_tail_pad_records(int nw, long nA)
 {
-    if (!stream_is_wide(nw, nA, false)) return 0;
+    if (!stream_is_wide(nw, nA, false) || nw < CHUNK) return 0;          // the tile kernel of < 128 bands reads its own lines only
     long stride;
     int steps;
     stream_panel_shape(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK, &stride, &steps);
@@ -329,6 +389,20 @@ long expand_stream_tail_pad_records(int nw, long nA)
 static int launch_expand_stream_flat(const double *band_table_dev, int nw, const double *coef_dev, long nA, double *rsurf_dev,
                                      int *xcd_slots_dev, hipStream_t s)
 {
+    if (nw < CHUNK) {
+        {
+            if (!band_table_dev) return fail(GORT_EINVAL, "stream expansion: wide stream without the band table");
+            const long waves = (nA + 63) / 64, blocks = (waves + 3) / 4;
+            if (blocks >= (1L << 31)) return fail(GORT_EINVAL, "stream expansion: %ld workgroups in one launch", blocks);
+            const StreamBand *tb = reinterpret_cast<const StreamBand *>(band_table_dev);
+            const bool whole_lines = nw % 16 == 0 && reinterpret_cast<uintptr_t>(rsurf_dev) % 128 == 0;
+            if (tuning().nt && whole_lines)
+                hipLaunchKernelGGL(expand_tile_stream_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, tb, nw, coef_dev, nA, rsurf_dev);
+            else
+                hipLaunchKernelGGL(expand_tile_stream_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, tb, nw, coef_dev, nA, rsurf_dev);
+            return check_launch("expand_tile_stream_kernel");
+        }
+    }
     const ExpandTuning &tune = tuning();
     if (!band_table_dev) return fail(GORT_EINVAL, "stream expansion: wide stream without the band table");
     const StreamBand *bands = reinterpret_cast<const StreamBand *>(band_table_dev);

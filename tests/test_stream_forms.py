@@ -37,14 +37,15 @@ def setup():
 
 
 def _run(eng, torch, ang, nw, pieces=False, out=None):
-    """The stream in ONE call (wide kernel where it applies), or cut into pieces below the wide kernel's threshold."""
+    """The stream in ONE call (wide kernel where it applies), or cut into pieces below the wide kernels' thresholds (4M
+    samples from 128 bands, 256K samples for 17 ... 127 bands)."""
     a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
     n = ang.shape[0]
     if out is None:
         out = torch.full((n, nw), -7.0, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
     forms = set()
-    step = n if not pieces else max(1, ((1 << 22) - 1) // nw)
+    step = n if not pieces else max(1, ((1 << (22 if nw >= 128 else 18)) - 1) // nw)
     for i in range(0, n, step):
         eng.rsurf_stream_dev(a[i:i + step], out[i:i + step])
         forms.add(eng.stream_form())
@@ -84,10 +85,11 @@ def test_flat_kernel_equals_narrow_kernels_bitwise_and_oracle(setup):
     assert relerr(got, ref, floor=1e-12) <= REGRESSION
 
 
-@pytest.mark.parametrize("nw", [128, 129, 143, 144, 1000, 1999, 2048, 3000])
+@pytest.mark.parametrize("nw", [17, 31, 32, 33, 64, 100, 127, 128, 129, 143, 144, 1000, 1999, 2048, 3000])
 def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
     """Band counts with every gcd(nw, 128) (wave strides of 1..128 chunk columns), the last panel ragged, the output
-    itself starting off a 1-KiB chunk boundary (front and back edge handling)."""
+    itself starting off a 1-KiB chunk boundary (front and back edge handling).  Below 128 bands: the tile kernel (lines in
+    lanes, rows transposed through LDS; whole-line rows stored non-temporally, others plainly), ragged last wave and tile."""
     eng, c, torch = setup
     rng = np.random.default_rng(nw)
     wl = np.linspace(400.0, 2500.0, nw)
@@ -96,8 +98,8 @@ def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
     ang = _lines(rng, n, np.array([0.0, 12.5, 30.0, 47.25, 60.0, 75.0, 88.0]))
     p, form = _run(eng, torch, ang, nw, pieces=True)
     assert form == "narrow"
-    for offset in (0, 1, 5, 16):                         # doubles in front of the output
-        buf = torch.full((n * nw + 32,), -7.0, dtype=torch.float64, device="cuda")
+    for offset in (0, 1, 5, 16, 127):                    # doubles in front of the output
+        buf = torch.full((n * nw + 160,), -7.0, dtype=torch.float64, device="cuda")
         out = buf[offset:offset + n * nw].view(n, nw)
         g, form = _run(eng, torch, ang, nw, out=out)
         assert form == "flat"
