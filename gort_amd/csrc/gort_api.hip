@@ -1220,8 +1220,10 @@ extern "C" int gort_energy_stream_dev(gort_engine *e, const double *angles_dev, 
     if ((rc = ensure_nodes(e))) return rc;
     void *ws = nullptr;
     if ((rc = energy_workspace(e, nA, &ws))) return rc;
+    int *slots = nullptr;
+    if ((rc = xcd_slots_for_launch(e, &slots))) return rc;              // probes the dispatch order once
     return launch_energy(e->canopy.as<gort_canopy>(), 1, e->L.as<double>(), e->nw, angles_dev, nA,
-                         e->nodes.as<double>(), energy_dev, ws, e->stream);
+                         e->nodes.as<double>(), energy_dev, ws, e->xcd_round_robin == 1, e->stream);
 }
 
 extern "C" int gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
@@ -1238,9 +1240,11 @@ extern "C" int gort_energy_members_dev(gort_engine *e, const double *angles_dev,
     if ((rc = ensure_nodes(e))) return rc;
     void *ws = nullptr;
     if ((rc = energy_workspace(e, nA, &ws))) return rc;
+    int *slots = nullptr;
+    if ((rc = xcd_slots_for_launch(e, &slots))) return rc;
     return launch_energy(e->canopy.as<gort_canopy>() + member_begin, member_end - member_begin,
                          e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw, e->nw, angles_dev, nA,
-                         e->nodes.as<double>(), energy_dev, ws, e->stream);
+                         e->nodes.as<double>(), energy_dev, ws, e->xcd_round_robin == 1, e->stream);
 }
 
 extern "C" int gort_energy_stream(gort_engine *e, const double *angles, long nA, double *energy)

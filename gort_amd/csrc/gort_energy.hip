@@ -4,6 +4,7 @@
 
 #include <cstdint>
 
+#include "gort_flat.h"
 #include "gort_geometry.h"
 
 namespace gort {
@@ -200,35 +201,53 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_list_kernel(const gort_
 
 // rows of the lines that share another line's sun direction: energy[line] = energy[rep[line]].  The output is walked as
 // ONE flat array in 1-KiB chunks aligned in absolute address (rows of 3 nw doubles start on 8-byte boundaries only, and
-// HBM wants whole lines per wave store: DESIGN.md 5.1 step 2); the few source rows stay in L2.  A chunk of 128 doubles
-// lies in at most two rows when a row has >= 128 doubles (ROWS2: their representatives are two wave-uniform loads);
-// shorter rows (a handful of bands) take the per-element form.
+// HBM wants whole lines per wave store: DESIGN.md 5.1 step 2), in PANELS of K steps x W waves like the flat expansion
+// kernels - short-lived waves, every XCD a contiguous run of panels where dispatch is round-robin (DESIGN.md 5.1, 5.5 (7):
+// a grid-stride loop of long-lived waves wrote 4.85 TB/s here) - and the few source rows stay in L2.  A chunk of 128
+// doubles lies in at most two rows when a row has >= 128 doubles (ROWS2: their representatives are two wave-uniform
+// loads, the chunk's row and offset advance incrementally); shorter rows (a handful of bands) take the per-element form.
 template <bool ROWS2>
 __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row, double *__restrict__ energy_all,
-                                                                const unsigned *__restrict__ rep, int shift, long chunks)
+                                                                const unsigned *__restrict__ rep, int shift, long chunks,
+                                                                int K, unsigned W, long dq, int dr, int xcd_static,
+                                                                XcdDuty duty, long useful_blocks)
 {
     double *__restrict__ energy = energy_all + (long)blockIdx.y * nA * row;
     const long n_total = nA * (long)row;
     const int lane = threadIdx.x & 63;
-    const long wave0 = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (long)gridDim.x * 4;
-    for (long ch = wave0; ch < chunks; ch += nwaves) {
-        const long c0 = ch * CHUNK - shift;                           // element of the chunk's first double (< 0 only for chunk 0)
+    const long block = xcd_static ? duty_logical_block((long)blockIdx.x, duty, useful_blocks)
+                                  : ((long)blockIdx.x < useful_blocks ? (long)blockIdx.x : -1);
+    if (block < 0) return;
+    const long wave = block * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long panel = wave / W;
+    long ch = panel * K * W + (wave - panel * W);
+    // the row of the chunk's first double and its offset in that row (row -1 for the doubles in front of the output)
+    long c0 = ch * CHUNK - shift, line_c = -1;
+    int off_c = row + (int)c0;
+    if (ROWS2 && c0 >= 0) {
+        line_c = c0 / row;
+        off_c = (int)(c0 - line_c * row);
+    }
+    for (int k = 0; k < K && ch < chunks; ++k, ch += W, c0 += (long)W * CHUNK) {
         const long e0 = c0 + EPL * lane;                              // first of this lane's two elements
         double v[EPL];
         bool put[EPL];
         if (ROWS2) {
-            const long first = c0 < 0 ? 0 : c0;
-            const long line0 = first / row;                           // wave-uniform
-            const long edge = (line0 + 1) * row;                      // first element of the next row
-            const long rep0 = rep[line0], rep1 = line0 + 1 < nA ? (long)rep[line0 + 1] : line0 + 1;
-            if (rep0 == line0 && (edge >= c0 + CHUNK || rep1 == line0 + 1)) continue;        // nothing to copy in this chunk
+            const long line0 = line_c;
+            const int off0 = off_c;
+            off_c += dr;                                              // the next step's chunk
+            line_c += dq;
+            if (off_c >= row) { off_c -= row; ++line_c; }
+            const long rep0 = line0 >= 0 ? (long)rep[line0] : line0, rep1 = line0 + 1 < nA ? (long)rep[line0 + 1] : line0 + 1;
+            if (rep0 == line0 && (off0 + CHUNK <= row || rep1 == line0 + 1)) continue;      // nothing to copy in this chunk
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
                 const long e = e0 + j;
-                const bool second = e >= edge;
+                const int t = off0 + EPL * lane + j;
+                const bool second = t >= row;
                 const long line = second ? line0 + 1 : line0, r = second ? rep1 : rep0;
                 put[j] = e >= 0 && e < n_total && r != line;
-                v[j] = put[j] ? energy[r * row + (e - line * row)] : 0.0;
+                v[j] = put[j] ? energy[r * row + (second ? t - row : t)] : 0.0;
             }
         } else {
 #pragma unroll
@@ -272,7 +291,8 @@ size_t energy_dedup_workspace(long nA)
 
 // ws_dev: energy_dedup_workspace(nA) bytes, or nullptr = every line evaluated (few lines; tests compare the two)
 int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
-                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *ws_dev, void *stream)
+                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *ws_dev,
+                  bool xcd_round_robin, void *stream)
 {
     if (nA <= 0 || nw <= 0 || n_members <= 0) return GORT_OK;
     if (n_members > 65535) return fail(GORT_EINVAL, "energy: %d members in one launch (max 65535)", n_members);
@@ -311,12 +331,25 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     // member m's slab starts nA*row doubles further: the same shift only if that is a multiple of CHUNK; the kernel's
     // alignment is a matter of speed, not of correctness, and the member-batched call is the small one
     const long chunks = (nA * (long)row + shift + CHUNK - 1) / CHUNK;
-    const long want = (chunks + 3) / 4;
-    const dim3 grid((unsigned)(want < 65536 ? want : 65536), (unsigned)n_members);
+    // panels of 16 steps x 2048 waves (32 MB), XCD-contiguous where the dispatch is round-robin.  1M lines x 2101 bands, 91
+    // sun directions (profiles/r03/energy_broadcast_sweep.log): the whole call 11.15 ms with the grid-stride loop of round 3's
+    // first version, 10.8 / 9.7 / 9.5 / 9.4 / 9.26 / 9.4 ms for 4 / 6 / 8 / 12 / 16 / 32 steps, the same for 1024 ... 8192 waves
+    const int K = 16;
+    const unsigned W = 2048;
+    const long panels = (chunks + (long)K * W - 1) / ((long)K * W);
+    const long useful = (panels * W + 3) / 4;
+    XcdDuty duty;
+    const long nblocks = plan_xcd_duty(xcd_round_robin ? 1 : 0, useful, nullptr, duty);
+    if (nblocks >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld workgroups in one launch", nblocks);
+    const dim3 grid((unsigned)nblocks, (unsigned)n_members);
+    const long dq = (long)W * CHUNK / row;
+    const int dr = (int)((long)W * CHUNK - dq * row);
     if (row >= CHUNK)
-        hipLaunchKernelGGL(energy_broadcast_kernel<true>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks);
+        hipLaunchKernelGGL(energy_broadcast_kernel<true>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks, K, W, dq, dr,
+                           xcd_round_robin ? 1 : 0, duty, useful);
     else
-        hipLaunchKernelGGL(energy_broadcast_kernel<false>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks);
+        hipLaunchKernelGGL(energy_broadcast_kernel<false>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks, K, W, dq, dr,
+                           xcd_round_robin ? 1 : 0, duty, useful);
     return check_launch("energy_broadcast_kernel");
 }
 

@@ -143,10 +143,13 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
                        void *stream);
 // energy_dev[n_members][nA][nw][3]; members are canopies_dev[0..n) with L_dev[m][L_NSLOT][nw].
 // ws_dev: energy_dedup_workspace(nA) bytes of device scratch (0 for few lines) - lines with the same normalised sun
-// direction are evaluated once and their row is copied; nullptr = every line evaluated (same bits)
+// direction are evaluated once and their row is copied; nullptr = every line evaluated (same bits).
+// xcd_round_robin: workgroups b, b + 8, ... share an XCD (probe_xcd_dispatch): the row copy then gives every XCD one
+// contiguous run of its panels
 size_t energy_dedup_workspace(long nA);
 int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
-                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *ws_dev, void *stream);
+                  const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *ws_dev,
+                  bool xcd_round_robin, void *stream);
 
 }  // namespace gort
 #endif
