@@ -633,7 +633,7 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     int *xcd_slots = nullptr;
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
-    const bool wide = stream_is_wide(e->nw, nA, scomp_dev != nullptr);
+    const bool large = stream_is_large(e->nw, nA, scomp_dev != nullptr);
     for (int i = 0; i < 2; ++i)
         if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
     if (stream_fuses(e->nw, scomp_dev != nullptr)) {
@@ -643,12 +643,12 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
         e->stream_form = 0;
         return rc;
     }
-    if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, wide ? 1 : 0, e->stream))) return rc;
+    if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, large ? 1 : 0, e->stream))) return rc;
     GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
     rc = launch_expand_stream(c, e->L.as<double>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw, coef, nA, rsurf_dev,
                               scomp_dev, xcd_slots, e->stream, false);
     GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
-    e->stream_form = wide ? 1 : 0;
+    e->stream_form = large ? 1 : 0;
     return rc;
 }
 

@@ -72,8 +72,8 @@ const double *price_eof_table();          // [4][421]
 void interface_transmissivity_tables(const double **t12, const double **talf);   // [2101] each
 // ---- geometry (gort_geometry.hip).  n_members > 1: one launch for all members (blockIdx.z), canopy_dev[m],
 // records coef_dev[m][nA][GORT_COEF_STRIDE], outputs member-major.
-// layout 0: classic records (CoefSlot); 1: the stream family's LineTerms (gort_device.h), what the WIDE stream
-// expansions read (stream_is_wide)
+// layout 0: classic records (CoefSlot); 1: the stream family's LineTerms (gort_device.h), what the stream
+// expansions of large streams read (stream_is_large)
 int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const double *angles_dev, long nA,
                            double *coef_dev, double *K_dev, int layout, void *stream);
 // streams of few bands without component spectra: geometry and samples in ONE launch, no records (same bits as the
@@ -117,12 +117,13 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin);
 // coef_dev: stream records (GORT_COEF_STRIDE doubles each) with ONE readable pad record in front and
 // expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the
 // call, or nullptr for the static XCD mapping.
-// Wide streams (stream_is_wide: >= 128 bands, >= 4M samples, no component spectra) have their records in layout 1 and
-// are expanded by expand_flat_stream_kernel (aligned flat panels).
+// Large streams without component spectra (stream_is_large: >= 128 bands and >= 4M samples, or 17 ... 127 bands and
+// >= 256K samples) have their records in layout 1 (the twelve LineTerms) and are expanded by expand_flat_stream_kernel
+// (aligned flat panels) or expand_tile_stream_kernel (lines in lanes, rows transposed in LDS).
 // grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's
 // five-term sample, so that every LUT path writes the same bits.
 long expand_stream_tail_pad_records(int nw, long nA);
-bool stream_is_wide(int nw, long nA, bool want_scomp);
+bool stream_is_large(int nw, long nA, bool want_scomp);
 // band_table_dev: stream_band_table() of the engine's L (wide streams only; may be null for grid_form)
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, const double *band_table_dev, int nw,
                          const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream,

@@ -323,7 +323,7 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
 // (>= 128 bands: the flat-panel kernel from 4M samples; 17 ... 127 bands: the tile kernel from 256K samples.  Up to 16
 // bands the stream is fused with the geometry unless GORT_STREAM_FUSE=0, and then it takes the narrow kernels.)
 constexpr int TILE_MIN_BANDS = 17;
-bool stream_is_wide(int nw, long nA, bool want_scomp)
+bool stream_is_large(int nw, long nA, bool want_scomp)
 {
     if (want_scomp || nw < TILE_MIN_BANDS) return false;
     return nA * (long)nw >= (nw < CHUNK ? (1L << 18) : (1L << 22));
@@ -379,7 +379,7 @@ static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
 // readable records the wide expansions may touch behind the last line (the caller also keeps ONE in front)
 long expand_stream_tail_pad_records(int nw, long nA)
 {
-    if (!stream_is_wide(nw, nA, false) || nw < CHUNK) return 0;          // the tile kernel of < 128 bands reads its own lines only
+    if (!stream_is_large(nw, nA, false) || nw < CHUNK) return 0;          // the tile kernel of < 128 bands reads its own lines only
     long stride;
     int steps;
     stream_panel_shape(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK, &stride, &steps);
@@ -437,7 +437,7 @@ static int launch_expand_stream_flat(const double *band_table_dev, int nw, const
 }
 
 // coef_dev: stream records with ONE readable pad record in front and expand_stream_tail_pad_records() behind the last
-// line; wide streams (stream_is_wide): records in layout 1, the flat-panel kernel.
+// line; large streams (stream_is_large): records in layout 1, the flat-panel or the tile kernel.
 // grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's sample.
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, const double *band_table_dev, int nw,
                          const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream,
@@ -446,7 +446,7 @@ int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, con
     const long n = nA * nw;
     if (n <= 0) return GORT_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (!grid_form && stream_is_wide(nw, nA, scomp_dev != nullptr))
+    if (!grid_form && stream_is_large(nw, nA, scomp_dev != nullptr))
         return launch_expand_stream_flat(band_table_dev, nw, coef_dev, nA, rsurf_dev, xcd_slots_dev, s);
     const long groups = (nA + STREAM_LINES - 1) / STREAM_LINES;
     if (nw >= 64 && groups <= 65535) {
