@@ -343,6 +343,7 @@ def main():
     # exercises sharding, window layout, gather and the max-over-ranks timing exactly as the real multi-GPU run does.
     dev_index = 0 if args.rehearse else local
     torch.cuda.set_device(dev_index)
+    api.set_device(dev_index)        # the engine, its LUT buffers and streams live on THIS rank's GPU whatever torch has initialised so far
     red_dev = "cpu" if args.rehearse else "cuda"
     dist = None
     if world > 1:

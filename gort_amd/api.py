@@ -130,6 +130,7 @@ def lib():
         L.gort_host_malloc.restype = C.c_void_p
         L.gort_host_malloc.argtypes = [C.c_size_t]
         L.gort_host_free.argtypes = [C.c_void_p]
+        L.gort_set_device.argtypes = [C.c_int]
         L.gort_pipe_create.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_uint, C.POINTER(C.c_void_p)]
         L.gort_pipe_acquire.argtypes = [C.c_void_p, C.POINTER(C.POINTER(D))]
         L.gort_pipe_submit.argtypes = [C.c_void_p, C.c_long]
@@ -420,6 +421,19 @@ def lut_read(path, c):
 
 def device_count():
     return lib().gort_device_count()
+
+
+def set_device(device):
+    """The calling thread's device (include/gort_amd.h gort_set_device): engines, pipes and LUT buffers created afterwards
+    belong to it.  A process with one rank per GPU calls this (beside torch.cuda.set_device) before it creates its engine."""
+    _check(lib().gort_set_device(int(device)))
+
+
+def get_device():
+    d = lib().gort_get_device()
+    if d < 0:
+        _check(d)
+    return d
 
 
 # ---------------------------------------------------------------- device side

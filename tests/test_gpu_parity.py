@@ -998,6 +998,18 @@ def test_lut_kernel_variants_bitwise_identical():
     assert len(set(digests)) == 1, list(zip(envs, digests))
 
 
+def test_set_device_selects_the_engines_gpu():
+    """gort_set_device / gort_get_device (include/gort_amd.h): one rank per GPU pins its engine with it (bench.py); an
+    ordinal the box does not have fails loudly instead of landing on GPU 0."""
+    api.set_device(0)
+    assert api.get_device() == 0
+    with pytest.raises(api.GortError):
+        api.set_device(api.device_count())
+    assert api.get_device() == 0
+    e = api.Engine()
+    e.close()
+
+
 def test_lut_alloc_measured_placement_and_zero_copy_view():
     """gort_lut_alloc (include/gort_amd.h): a whole-buffer window draws separate allocations, a window that is a small
     part of the buffer is placed by a scan in 1-GiB steps inside ONE allocation with slack (the pointer handed out may

@@ -144,6 +144,8 @@ def test_device_entry_points_fail_loudly_without_gpu():
     assert e.value.code == api.ENODEVICE
     with pytest.raises(api.GortError):
         api.gap_probabilities(api.make_canopy(lai=4.0))
+    with pytest.raises(api.GortError):
+        api.set_device(0)                                     # bench.py pins every rank to its GPU through this
 
 
 def test_format_f6_equals_printf():
