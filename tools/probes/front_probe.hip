@@ -108,6 +108,98 @@ __global__ __launch_bounds__(256) void panels_bare(double *out, long chunks, uns
     }
 }
 
+// persistent waves that work through the SAME tasks in the SAME order as the short-lived waves of panels_bare<K> (task =
+// K steps of one column of a panel, adjacent waves take adjacent columns, XCD x owns a contiguous run of tasks): is it the
+// lifetime of a wave that slows its stores, or what it does during that life?
+template <int K>
+__global__ __launch_bounds__(256) void tasks_bare(double *out, long chunks, unsigned W, long tasks_per_xcd, long n_tasks, int waves_per_xcd)
+{
+    const int x = blockIdx.x & 7;
+    const long lw = (long)(blockIdx.x >> 3) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    dbl2 v; v.x = 1.0 + lane; v.y = 2.0;
+    const long t1 = (x + 1) * tasks_per_xcd < n_tasks ? (x + 1) * tasks_per_xcd : n_tasks;
+    for (long t = x * tasks_per_xcd + lw; t < t1; t += waves_per_xcd) {
+        const long panel = t / W, w = t - panel * W;
+        const long c0 = panel * K * W + w;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const long c = c0 + (long)k * W;
+            if (c < chunks) __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(out + c * 128 + 2 * lane));
+        }
+    }
+}
+
+// ... and the same persistent waves taking their tasks DYNAMICALLY (one returning atomic per task on their XCD's counter,
+// requested one task ahead): a wave on a slower CU then simply takes fewer tasks, as the dispatcher arranges for short-lived
+// workgroups
+template <int K>
+__global__ __launch_bounds__(256) void tasks_dynamic(double *out, long chunks, unsigned W, long tasks_per_xcd, long n_tasks, int *counters)
+{
+    // one atomic per WORKGROUP and group of four adjacent tasks (a returning atomic on one address completes every ~16 ns:
+    // one per wave and task capped 6-step tasks at 3 TB/s), requested one group ahead, handed to the waves through LDS
+    __shared__ int s_group[2];
+    const int x = blockIdx.x & 7;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    dbl2 v; v.x = 1.0 + lane; v.y = 2.0;
+    const long t0 = x * tasks_per_xcd, t1 = t0 + tasks_per_xcd < n_tasks ? t0 + tasks_per_xcd : n_tasks;
+    int *ctr = counters + 64 * x;
+    if (threadIdx.x == 0) s_group[0] = atomicAdd(ctr, 1);
+    __syncthreads();
+    int buf = 0;
+    long t = t0 + 4L * s_group[0] + wave;
+    while (t - wave < t1) {
+        if (threadIdx.x == 0) s_group[buf ^ 1] = atomicAdd(ctr, 1);          // the next group, requested before this one's stores
+        if (t < t1) {
+            const long panel = t / W, w = t - panel * W;
+            const long c0 = panel * K * W + w;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const long c = c0 + (long)k * W;
+                if (c < chunks) __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(out + c * 128 + 2 * lane));
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+        t = t0 + 4L * s_group[buf] + wave;
+    }
+}
+
+template <int K>
+static float run_dynamic(double *out, long n, unsigned W, int wgs_per_cu, int reps, hipEvent_t e0, hipEvent_t e1, int *counters)
+{
+    const long chunks = (n + 127) / 128;
+    const long panels = (chunks + (long)K * W - 1) / ((long)K * W);
+    const long n_tasks = panels * W, tasks_per_xcd = (n_tasks + 7) / 8;
+    const int wgs = 256 * wgs_per_cu;
+    float total = 0.f;
+    for (int i = 0; i < reps + 2; ++i) {
+        CK(hipMemsetAsync(counters, 0, 8 * 64 * sizeof(int), 0));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(tasks_dynamic<K>, dim3(wgs), dim3(256), 0, 0, out, chunks, W, tasks_per_xcd, n_tasks, counters);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 2) total += ms;
+    }
+    return total / reps;
+}
+
+template <int K>
+static float run_tasks(double *out, long n, unsigned W, int wgs_per_cu, int reps, hipEvent_t e0, hipEvent_t e1)
+{
+    const long chunks = (n + 127) / 128;
+    const long panels = (chunks + (long)K * W - 1) / ((long)K * W);
+    const long n_tasks = panels * W, tasks_per_xcd = (n_tasks + 7) / 8;
+    const int wgs = 256 * wgs_per_cu, waves_per_xcd = wgs / 8 * 4;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(tasks_bare<K>, dim3(wgs), dim3(256), 0, 0, out, chunks, W, tasks_per_xcd, n_tasks, waves_per_xcd);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(tasks_bare<K>, dim3(wgs), dim3(256), 0, 0, out, chunks, W, tasks_per_xcd, n_tasks, waves_per_xcd);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
 template <int K>
 static float run_panels(double *out, long n, unsigned W, int reps, hipEvent_t e0, hipEvent_t e1)
 {
@@ -144,6 +236,23 @@ int main(int argc, char **argv)
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         return ms / reps;
     };
+    if (argc > 3 && argv[3][0] == 't') {
+        // tasks: short-lived waves against persistent waves on the same tasks
+        printf("panels of K steps x 2101 waves, short-lived waves:  K=6 %6.0f  K=8 %6.0f  K=12 %6.0f  K=16 %6.0f GB/s\n",
+               n * 8 / run_panels<6>(out, n, 2101, reps, e0, e1) / 1e6, n * 8 / run_panels<8>(out, n, 2101, reps, e0, e1) / 1e6,
+               n * 8 / run_panels<12>(out, n, 2101, reps, e0, e1) / 1e6, n * 8 / run_panels<16>(out, n, 2101, reps, e0, e1) / 1e6);
+        for (int wgs_per_cu : {2, 4, 7})
+            printf("the same tasks, persistent waves (%d workgroups per CU):    K=6 %6.0f  K=8 %6.0f  K=12 %6.0f  K=16 %6.0f GB/s\n", wgs_per_cu,
+                   n * 8 / run_tasks<6>(out, n, 2101, wgs_per_cu, reps, e0, e1) / 1e6, n * 8 / run_tasks<8>(out, n, 2101, wgs_per_cu, reps, e0, e1) / 1e6,
+                   n * 8 / run_tasks<12>(out, n, 2101, wgs_per_cu, reps, e0, e1) / 1e6, n * 8 / run_tasks<16>(out, n, 2101, wgs_per_cu, reps, e0, e1) / 1e6);
+        int *counters;
+        CK(hipMalloc(&counters, 8 * 64 * sizeof(int)));
+        for (int wgs_per_cu : {2, 4, 7})
+            printf("the same tasks, persistent waves, tasks taken dynamically (%d workgroups per CU): K=6 %6.0f  K=8 %6.0f  K=12 %6.0f  K=16 %6.0f GB/s\n", wgs_per_cu,
+                   n * 8 / run_dynamic<6>(out, n, 2101, wgs_per_cu, reps, e0, e1, counters) / 1e6, n * 8 / run_dynamic<8>(out, n, 2101, wgs_per_cu, reps, e0, e1, counters) / 1e6,
+                   n * 8 / run_dynamic<12>(out, n, 2101, wgs_per_cu, reps, e0, e1, counters) / 1e6, n * 8 / run_dynamic<16>(out, n, 2101, wgs_per_cu, reps, e0, e1, counters) / 1e6);
+        return 0;
+    }
     if (argc > 3 && argv[3][0] == 'p') {
         // pmc: three kernels with different names for a counter trace - short-lived waves (K = 6), long ones (K = 64),
         // persistent ones (A = 16, three XCD-owned teams)
