@@ -25,8 +25,10 @@ namespace gort {
 #define GORT_HIP(call)                                                                              \
     do {                                                                                            \
         hipError_t err__ = (call);                                                                  \
-        if (err__ != hipSuccess)                                                                    \
+        if (err__ != hipSuccess) {                                                                  \
+            (void)hipGetLastError();     /* reported here: must not resurface in a later launch check */ \
             return fail(GORT_ENODEVICE, "%s: %s", #call, hipGetErrorString(err__));                 \
+        }                                                                                           \
     } while (0)
 
 // grow-only device buffer
