@@ -565,7 +565,7 @@ class Engine:
         m = lib().gort_engine_stream_form(self.h)
         if m < 0:
             _check(m)
-        return {0: "narrow", 1: "flat"}[m]
+        return {0: "narrow", 1: "flat", 2: "lines"}[m]
 
     def last_stream_ms(self):
         return lib().gort_engine_last_stream_ms(self.h)

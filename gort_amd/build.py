@@ -27,6 +27,7 @@ UNITS = [
     ("gort_tables.hip", []),
     ("gort_lut_expand.hip", []),
     ("gort_stream_expand.hip", []),
+    ("gort_stream_lines.hip", []),
     ("gort_energy.hip", []),
     ("gort_xcd.hip", []),
     ("gort_pipe.hip", []),

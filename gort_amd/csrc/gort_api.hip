@@ -625,6 +625,17 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if ((rc = require_ready(e, "gort_rsurf_stream_dev"))) return rc;
     if (nA < 0 || (nA > 0 && (!angles_dev || !rsurf_dev))) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
     if (nA == 0) return GORT_OK;
+    for (int i = 0; i < 2; ++i)
+        if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
+    // 17 ... ~250 bands (all the reference's command line can read): one kernel from the angle line to its row
+    if (stream_takes_lines_kernel(e->nw, nA, scomp_dev != nullptr)) {
+        GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
+        rc = launch_stream_lines(e->canopy.as<gort_canopy>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw,
+                                 angles_dev, nA, rsurf_dev, K_dev, e->stream);
+        GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
+        e->stream_form = 2;
+        return rc;
+    }
     // line records with one pad record in front and a tail pad (the aligned flat expansion prefetches)
     const long tail = expand_stream_tail_pad_records(e->nw, nA);
     const size_t coef_bytes = sizeof(double) * GORT_COEF_STRIDE * (size_t)(nA + 1 + tail);
@@ -636,8 +647,6 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if ((rc = xcd_slots_for_launch(e, &xcd_slots))) return rc;
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
     const bool large = stream_is_large(e->nw, nA, scomp_dev != nullptr);
-    for (int i = 0; i < 2; ++i)
-        if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
     if (stream_fuses(e->nw, scomp_dev != nullptr)) {
         GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
         rc = launch_geometry_stream_fused(c, 1, e->L.as<double>(), e->nw, angles_dev, nA, rsurf_dev, K_dev, e->stream);

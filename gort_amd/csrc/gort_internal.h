@@ -128,6 +128,11 @@ bool stream_is_large(int nw, long nA, bool want_scomp);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, const double *band_table_dev, int nw,
                          const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream,
                          bool grid_form);
+// ---- streams of 17 ... ~250 bands without component spectra (gort_stream_lines.hip): geometry and samples in one kernel,
+// lanes = lines, rows leave LDS as whole 128-B lines whatever the band count; band_table_dev as above
+bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp);
+int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_dev, int nw, const double *angles_dev, long nA,
+                        double *rsurf_dev, double *K_dev, void *stream);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);

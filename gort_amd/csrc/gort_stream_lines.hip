@@ -1,0 +1,263 @@
+// gort_stream_lines.hip -- streams of 17 ... LINES_MAX_BANDS bands, the range the reference's own command line can
+// ingest (its header line holds ~190 wavelengths, gortt.c:153-184): ONE kernel from the angle line to its row of
+// reflectances (the per-line loop of main(), gortt.c:232-329, with gortt_rsurf, gortt.c:385-578).
+//
+// A wave takes 64 consecutive LINES, lane = line.  The lane evaluates its line's geometry (gort_geometry.h) and keeps
+// the twelve LineTerms of the stream family's sample in registers - no 128-B record per line written and read back -
+// then walks the bands: their twelve constants are wave-uniform (scalar loads off the StreamBand table), so a sample
+// costs its 28 fp64 issue slots and nothing else.
+//
+// The output of the wave's 64 lines is ONE contiguous span of 64 nw doubles.  A band's 64 samples belong to 64
+// different rows of it, nw doubles apart, and rows start on 8-byte boundaries only: round 3's tile kernel stored 16-band
+// pieces row by row, which are whole 128-B lines only where nw is a multiple of 16 (everywhere else every cache line
+// was written in two halves a tile apart: half the rate, 1.3 x the traffic).  Here every lane has a RING of 32 doubles
+// in LDS indexed by the ABSOLUTE position of the sample in the output (mod 32): after band block k the cache line
+// number k-1 of every row is complete in its ring whatever the row's alignment, and leaves as one 128-B line, 16 B per
+// lane, eight rows per store instruction.  The cache line a row shares with the next one (its tail + the next row's
+// head) is completed at the end: every lane keeps the 16 samples of its first band block in registers and drops its
+// head into the ring of the row in front.  So only the two ends of a wave's span can be partial lines, and with an
+// output that starts on a 128-B boundary only those of the whole stream (64 nw doubles are a multiple of 16).
+//
+// Same functions on the same numbers as every other stream kernel (geometry_core, store_coef, line_terms_of_record,
+// stream_sample): the same bits (tests/test_stream_forms.py).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "gort_geometry.h"
+
+namespace gort {
+namespace {
+
+constexpr int RING = 32;                        // doubles per line in flight: the band block being written + the one before
+constexpr int BLOCK_BANDS = 16;                 // one cache line per row and block
+
+// The twelve constants of a band, wave-uniform, through the scalar cache.  Left to the compiler a band's s_load sits
+// directly in front of the s_waitcnt for it (it sinks the load of a value used in the next iteration to the end of the
+// loop body whatever the source says), which at the two waves per SIMD this kernel's LDS rings
+// allow is ~150 exposed cycles per 112 of arithmetic.  So the request and the wait are written out: two register sets,
+// the band after next requested while this one is evaluated.  The wait takes the registers as operands, so nothing that
+// reads them can move in front of it; a set is always waited for before it dies (the loads land whenever they land).
+typedef double double8v __attribute__((ext_vector_type(8)));
+typedef double double4v __attribute__((ext_vector_type(4)));
+struct BandRegs { double8v lo; double4v hi; };
+__device__ __forceinline__ void band_request(BandRegs &r, const StreamBand *p)
+{
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40" : "=&s"(r.lo), "=&s"(r.hi) : "s"(p));
+    __builtin_amdgcn_sched_barrier(0);          // or the scheduler lets the arithmetic that follows in the source go first
+}
+__device__ __forceinline__ void band_wait(BandRegs &r)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi) : : "memory");
+}
+__device__ __forceinline__ StreamBand band_of(const BandRegs &r)
+{
+    StreamBand b;
+    b.g2 = r.lo[0];  b.c1 = r.lo[1];  b.c2 = r.lo[2];  b.Rff = r.lo[3];  b.cT = r.lo[4];  b.tff = r.lo[5];  b.pff = r.lo[6];
+    b.rs = r.lo[7];  b.mgk = r.hi[0];  b.Zf = r.hi[1];  b.Tf = r.hi[2];  b.B = r.hi[3];
+    return b;
+}
+
+// the cache line at position X (relative to the wave's 256-B aligned origin, a multiple of 16) of ring row `row`:
+// lane q of eight moves 16 bytes; positions outside [lo, hi) are not the wave's to write
+template <bool NT>
+__device__ __forceinline__ void emit_cache_line(const double *__restrict__ ring, int row, int pitch, int X, int lo, int hi, int q,
+                                                double *__restrict__ origin)
+{
+    const dbl2 v = reinterpret_cast<const dbl2 *>(ring)[((row * pitch + (X & (RING - 1))) >> 1) + q];      // all even: 16-B aligned
+    const int p = X + 2 * q;
+    double *o = origin + p;
+    if (hi - lo == 16) {
+        if (NT) __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(o));
+        else *reinterpret_cast<dbl2 *>(o) = v;
+    } else {
+        if (p >= lo && p < hi) o[0] = v.x;
+        if (p + 1 >= lo && p + 1 < hi) o[1] = v.y;
+    }
+}
+
+// ring rows: 0 = the cache line in front of the wave's first row (its head only), 1 + l = line l of the wave
+template <bool NT>
+__global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__restrict__ canopy,
+                                                          const double *__restrict__ angles, long nA,
+                                                          const StreamBand *__restrict__ bands, int nw, int pitch,
+                                                          double *__restrict__ out, double *__restrict__ K)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_ring[];
+    const int lane = threadIdx.x;
+    const long a0 = (long)blockIdx.x * 64;
+    const int lines_here = nA - a0 < 64 ? (int)(nA - a0) : 64;
+    const bool live = lane < lines_here;
+    const long a = a0 + (live ? lane : lines_here - 1);       // lanes behind the stream compute the last line again, store nothing
+
+    // ---- the line: geometry -> record -> line terms, all in registers
+    const gort_canopy &c = *canopy;
+    LineTerms l;
+    {
+        const double *ap = angles + 4 * a;
+        double vza, sza, saa, raa;
+        normalise_angles(ap[0], ap[1], ap[2], ap[3], vza, sza, saa, raa);
+        GeomOut g;
+        geometry_core(c, vza, sza, raa, g);
+        double rec[GORT_COEF_STRIDE];
+        store_coef(rec, c, g);
+        l = line_terms_of_record(rec, c.k_openep, c.k_open);
+        if (K && live) {
+            double *k = K + 4 * a;
+            k[0] = g.Kc;  k[1] = g.Kg;  k[2] = g.Kt;  k[3] = g.Kz;
+        }
+    }
+
+    // ---- where the wave's span lies: positions are relative to `origin`, a 256-B aligned address at or below its
+    // first element (never dereferenced below `out`)
+    const int base_off = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & (RING - 1));
+    const long G0 = base_off + a0 * nw;
+    const int g0 = (int)(G0 & (RING - 1));
+    double *const origin = out - base_off + (G0 - g0);
+    const int pos = g0 + lane * nw;                           // my row starts here
+    double *const my_ring = s_ring + (lane + 1) * pitch;
+    const int sub = lane >> 3, q = lane & 7;                  // as a store lane: row 8 i + sub, 16 bytes number q of its cache line
+    const int m = (nw + BLOCK_BANDS - 1) / BLOCK_BANDS;
+
+    // full cache line j of every row (rows whose line j is not complete inside the row skip it): eight reads, then the stores
+    auto emit_full = [&](int j) {
+        dbl2 v[8];
+        int X[8];
+        bool ok[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * i + sub;
+            const int pr = g0 + r * nw;
+            const int F = (pr + 15) & ~15;
+            const int n = (pr + nw - F) >> 4;
+            ok[i] = r < lines_here && j < n;
+            X[i] = F + 16 * j;
+            v[i] = reinterpret_cast<const dbl2 *>(s_ring)[(((r + 1) * pitch + (X[i] & (RING - 1))) >> 1) + q];      // all even: 16-B aligned
+        }
+        // the reads are waited for HERE, outside the branches of the stores: else the compiler's wait-count pass carries
+        // them as pending round the loop and drains everything - the band request included - at the top of the next block
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (ok[i]) {
+                dbl2 *o = reinterpret_cast<dbl2 *>(origin + X[i] + 2 * q);
+                if (NT) __builtin_nontemporal_store(v[i], o);
+                else *o = v[i];
+            }
+        }
+    };
+
+    // ---- band block 0: its 16 samples stay in registers as well (the row's head is among them)
+    double head[BLOCK_BANDS];
+#pragma unroll
+    for (int i = 0; i < BLOCK_BANDS; ++i) {
+        const StreamBand b = bands[i];                         // wave-uniform: scalar loads
+        const double v = stream_sample(l, b);
+        head[i] = v;
+        my_ring[(pos + i) & (RING - 1)] = v;
+    }
+    // the other blocks: the sample of a band is written to the ring one band later (its ds_write would otherwise sit
+    // directly in front of the next wait, which counts LDS operations too)
+    {
+        BandRegs A, B;
+        int t = BLOCK_BANDS;
+        double vprev = head[BLOCK_BANDS - 1];                  // written again where it already is: harmless
+        band_request(A, bands + t);                            // nw >= 17
+        while (t < nw) {
+            const int block_end = t + BLOCK_BANDS < nw ? t + BLOCK_BANDS : nw;
+            while (t + 1 < block_end) {
+                band_wait(A);
+                band_request(B, bands + t + 1);
+                my_ring[(pos + t - 1) & (RING - 1)] = vprev;
+                vprev = stream_sample(l, band_of(A));
+                band_wait(B);
+                band_request(A, bands + (t + 2 < nw ? t + 2 : nw - 1));
+                my_ring[(pos + t) & (RING - 1)] = vprev;
+                vprev = stream_sample(l, band_of(B));
+                t += 2;
+            }
+            if (t < block_end) {                               // an odd band at the end of the last block
+                band_wait(A);
+                my_ring[(pos + t - 1) & (RING - 1)] = vprev;
+                vprev = stream_sample(l, band_of(A));
+                t += 1;
+            }
+            my_ring[(pos + t - 1) & (RING - 1)] = vprev;
+            emit_full((t - 1) / BLOCK_BANDS - 1);
+        }
+        band_wait(A);                                          // the last request may still be on its way
+    }
+    emit_full(m - 1);
+
+    // ---- the cache lines between rows: my head completes the line my predecessor's tail began
+    {
+        const int s = (-pos) & 15;
+        double *const prev_ring = s_ring + lane * pitch;
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < BLOCK_BANDS - 1; ++i)
+                if (i < s) prev_ring[(pos + i) & (RING - 1)] = head[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int r = 8 * i + sub - 1;                     // -1: the line in front of the wave's first row
+            if (r >= lines_here) continue;
+            int X, lo, hi;
+            if (r < 0) {
+                hi = (g0 + 15) & ~15;
+                X = hi - 16;
+                lo = g0;
+            } else {
+                const int pr = g0 + r * nw;
+                const int F = (pr + 15) & ~15;
+                const int n = (pr + nw - F) >> 4;
+                const int end = pr + nw;
+                X = F + 16 * n;
+                lo = X;
+                hi = X == end ? X : (r + 1 < lines_here ? X + 16 : end);
+            }
+            if (hi > lo) emit_cache_line<NT>(s_ring, r + 1, pitch, X, lo, hi, q, origin);
+        }
+    }
+}
+
+}  // namespace
+
+// Which streams take this kernel: no component spectra, 17 ... LINES_MAX_BANDS bands, and enough lines to fill the
+// machine (below that the narrow kernels, whose threads are samples, have more parallelism)
+constexpr int LINES_MIN_BANDS = 17;
+constexpr int LINES_MAX_BANDS = 255;
+bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp)
+{
+    const char *v = getenv("GORT_LINES_MAX_BANDS");           // read per call: tests and tools/shape_scan.py move the hand-over
+    const int max_bands = v ? atoi(v) : LINES_MAX_BANDS;       // to the flat-panel kernel inside one process
+    return !want_scomp && nw >= LINES_MIN_BANDS && nw <= max_bands && nA * (long)nw >= (1L << 18);
+}
+
+int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_dev, int nw, const double *angles_dev, long nA,
+                        double *rsurf_dev, double *K_dev, void *stream)
+{
+    if (nA <= 0) return GORT_OK;
+    if (!band_table_dev) return fail(GORT_EINVAL, "stream lines kernel: no band table");
+    if (nw < LINES_MIN_BANDS) return fail(GORT_EINVAL, "stream lines kernel: %d bands (needs at least %d)", nw, LINES_MIN_BANDS);
+    const long blocks = (nA + 63) / 64;
+    if (blocks >= (1L << 31) || (long)nw * 64 + RING >= (1L << 30))
+        return fail(GORT_EINVAL, "stream lines kernel: %ld lines x %d bands in one launch", nA, nw);
+    // ring pitch: even (16-B aligned rows); lanes' ring positions differ by nw, so a multiple of four bands wants
+    // rows two doubles apart in the banks (two-way conflicts at worst), any other count none
+    const int pitch = (nw % 4 == 0) ? RING + 2 : RING;
+    const size_t lds = sizeof(double) * 65 * (size_t)pitch;
+    const StreamBand *tb = reinterpret_cast<const StreamBand *>(band_table_dev);
+    static const bool nt = !(getenv("GORT_EXPAND_NT") && atoi(getenv("GORT_EXPAND_NT")) == 0);
+    if (nt)
+        hipLaunchKernelGGL(stream_lines_kernel<true>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
+                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
+    else
+        hipLaunchKernelGGL(stream_lines_kernel<false>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
+                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
+    return check_launch("stream_lines_kernel");
+}
+
+}  // namespace gort

@@ -823,13 +823,17 @@ def test_wide_stream_kernels_against_the_reference():
     eng.set_spectra(*api.spectra(wl))
     a = torch.as_tensor(ang, device="cuda")
     worst = {}
-    for name in ("flat", "narrow"):
+    for name in ("lines", "flat", "narrow"):
         out = torch.full((a.shape[0], len(wl)), -7.0, dtype=torch.float64, device="cuda")
         torch.cuda.synchronize()
-        step = a.shape[0] if name == "flat" else ((1 << 22) - 1) // len(wl)
-        for i in range(0, a.shape[0], step):
-            eng.rsurf_stream_dev(a[i:i + step], out[i:i + step])
-            assert eng.stream_form() == name
+        step = a.shape[0] if name != "narrow" else ((1 << 18) - 1) // len(wl)
+        os.environ["GORT_LINES_MAX_BANDS"] = "255" if name == "lines" else "0"     # 0: the flat-panel kernel takes 180 bands
+        try:
+            for i in range(0, a.shape[0], step):
+                eng.rsurf_stream_dev(a[i:i + step], out[i:i + step])
+                assert eng.stream_form() == name
+        finally:
+            os.environ.pop("GORT_LINES_MAX_BANDS", None)
         eng.synchronize()
         got = out[torch.as_tensor(pick, device="cuda")].cpu().numpy()
         worst[name] = err(got, ref)

@@ -38,14 +38,14 @@ def setup():
 
 def _run(eng, torch, ang, nw, pieces=False, out=None):
     """The stream in ONE call (wide kernel where it applies), or cut into pieces below the wide kernels' thresholds (4M
-    samples from 128 bands, 256K samples for 17 ... 127 bands)."""
+    samples from 256 bands, 256K samples for 17 ... 255 bands)."""
     a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
     n = ang.shape[0]
     if out is None:
         out = torch.full((n, nw), -7.0, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
     forms = set()
-    step = n if not pieces else max(1, ((1 << (22 if nw >= 128 else 18)) - 1) // nw)
+    step = n if not pieces else max(1, ((1 << (22 if nw > 255 else 18)) - 1) // nw)
     for i in range(0, n, step):
         eng.rsurf_stream_dev(a[i:i + step], out[i:i + step])
         forms.add(eng.stream_form())
@@ -85,7 +85,7 @@ def test_flat_kernel_equals_narrow_kernels_bitwise_and_oracle(setup):
     assert relerr(got, ref, floor=1e-12) <= REGRESSION
 
 
-@pytest.mark.parametrize("nw", [17, 31, 32, 33, 64, 100, 127, 128, 129, 143, 144, 1000, 1999, 2048, 3000])
+@pytest.mark.parametrize("nw", [17, 18, 31, 32, 33, 47, 48, 64, 65, 100, 127, 128, 129, 143, 144, 190, 255, 256, 1000, 1999, 2048, 3000])
 def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
     """Band counts with every gcd(nw, 128) (wave strides of 1..128 chunk columns), the last panel ragged, the output
     itself starting off a 1-KiB chunk boundary (front and back edge handling).  Below 128 bands: the tile kernel (lines in
@@ -102,7 +102,7 @@ def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
         buf = torch.full((n * nw + 160,), -7.0, dtype=torch.float64, device="cuda")
         out = buf[offset:offset + n * nw].view(n, nw)
         g, form = _run(eng, torch, ang, nw, out=out)
-        assert form == "flat"
+        assert form == ("lines" if nw <= 255 else "flat")
         assert _bits_equal(g, p), (nw, offset)
         assert float(buf[:offset].min() if offset else -7.0) == -7.0 and float(buf[offset + n * nw:].max()) == -7.0
 

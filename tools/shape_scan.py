@@ -10,7 +10,7 @@ from gort_amd import api
 c = api.gap_probabilities(api.make_canopy(lai=4.0))
 eng = api.Engine(); eng.set_canopy(c)
 rng = np.random.default_rng(0)
-for n, nw in ((1000000, 4), (1000000, 7), (1000000, 16), (1000000, 17), (1000000, 32), (1000000, 64), (1000000, 65), (1000000, 80), (1000000, 96), (1000000, 100), (1000000, 127), (1000000, 128), (500000, 300),
+for n, nw in ((1000000, 4), (1000000, 7), (1000000, 16), (1000000, 17), (1000000, 32), (1000000, 64), (1000000, 65), (1000000, 80), (1000000, 96), (1000000, 100), (1000000, 127), (1000000, 128), (1000000, 129), (1000000, 160), (1000000, 190), (1000000, 255), (1000000, 256), (500000, 300),
               (100000, 300), (1000, 2101), (1900, 2101), (2000, 2101), (10000, 1000), (4000000, 32)):
     wl = np.linspace(400.0, 2500.0, nw)
     eng.set_spectra(*api.spectra(wl))
