@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "gort_internal.h"
+#include "gort_math.h"
 
 namespace gort {
 namespace {
@@ -78,24 +79,105 @@ __device__ inline double normalised_sza(double sza_deg)
 
 struct Primed { double ang, s, c, sec, t; };     // theta' = atan((b/r) tan theta)  (gortt.c:581-588)
 
-__device__ inline Primed prime(double ell, double tan_za)
+// sine and cosine of an azimuth difference in radians: main() folds it into [0, 2 pi] (gortt.c:266-279), so one
+// reduction step and the kernels of gort_math.h do; the fold below only guards the function's contract
+__device__ inline void sincos_of(double x, double &s, double &c)
 {
-    Primed p;
-    p.ang = atan(ell * tan_za);
-    sincos(p.ang, &p.s, &p.c);
-    p.sec = 1.0 / p.c;
-    p.t = p.s / p.c;
-    return p;
+    if (__builtin_expect(fabs(x) > gm::SINCOS_MAX, 0)) x = fmod(x, 2 * PI);      // inf -> NaN
+    gm::sincos_reduced(x, s, c);
+}
+
+// ---- the two arithmetics of the geometry stage --------------------------------------------------------------------
+// FastMath: the bounded-range kernels of gort_math.h (within ~1 ulp, divisions by reciprocal + Newton) and the primed
+// angle's cosine, secant and tangent straight from x = (b/r) tan theta (cos = 1/sqrt(1 + x^2), tan = x) instead of
+// through atan and back.  What every line takes - except the ones below.
+// LibMath: the reference's own route step by step - atan, then sin / cos / 1/cos / sin/cos OF THE ROUNDED ANGLE, IEEE
+// division and square root, the device library's (nearly correctly rounded) functions.  Within ~1e-6 rad of a zenith of
+// 90 degrees the reference's numbers are made of exactly that rounding: tan(90 deg) = 1.6e16 and atan((b/r) 1.6e16)
+// rounds to the double nearest pi/2, whose cosine is 6.1e-17 whatever b/r is; 1 - M of gortt_brdf.c:205 is then ONE ulp
+// of 1, and Kc, printed by -prnprop, is a quotient of two such numbers (0.901419 at vza = 90 deg for the default canopy).
+// Lines that close to the horizon evaluate the reference's route so that they print what the reference prints; they are
+// rare, the branch is wave-uniform almost always, and its code is round 3's (which the goldens pinned).
+struct FastMath {
+    static __device__ __forceinline__ double div(double a, double b) { return gm::quot(a, b); }
+    static __device__ __forceinline__ double sqrt(double x) { return gm::sqrt_(x); }
+    static __device__ __forceinline__ double exp(double x) { return gm::exp_(x); }
+    static __device__ __forceinline__ double log(double x) { return gm::log_(x); }
+    static __device__ __forceinline__ double acos(double x) { return gm::acos_(x); }
+    static __device__ __forceinline__ double cos(double x) { return gm::cos_reduced(x); }
+    static __device__ __forceinline__ void sincos(double x, double &s, double &c) { sincos_of(x, s, c); }
+    static __device__ __forceinline__ double over_pi(double x) { return x * INV_PI; }
+    // sin(acos(c)) = sqrt((1 - c)(1 + c)): both factors exact or nearly so
+    static __device__ __forceinline__ double sin_of_acos(double, double c) { return gm::sqrt_((1.0 - c) * (1.0 + c)); }
+    // cos(vza' cphi - sza') for cphi = +-1 is cos vza' cos sza' + cphi sin vza' sin sza', which the caller has: ph
+    static __device__ __forceinline__ double cos_of_difference(const Primed &, const Primed &, double, double ph) { return ph; }
+    // 1 / tan(a / 2) = (1 + sec a) / tan a
+    static __device__ __forceinline__ double cot_half(const Primed &p) { return gm::quot(1.0 + p.sec, p.t); }
+    static __device__ __forceinline__ Primed prime(double ell, double tan_za)
+    {
+#pragma clang fp contract(off)
+        Primed p;
+        const double x = ell * tan_za;
+        p.ang = gm::atan_(x);
+        gm::root_and_inverse(1.0 + x * x, p.sec, p.c);
+        p.s = x * p.c;
+        p.t = x;           // equal zeniths give bitwise equal primed tangents either way: the exact zero of overlap()'s distance
+        return p;
+    }
+};
+// (The library's functions are CALLED from that route, not inlined: beside the kernels their code - huge-argument
+// reduction and all - costs every line 40 to 70 registers of allocation, i.e. a wave or two of occupancy per SIMD.)
+namespace lib {
+__device__ __attribute__((noinline)) double exp_call(double x) { return ::exp(x); }
+__device__ __attribute__((noinline)) double log_call(double x) { return ::log(x); }
+__device__ __attribute__((noinline)) double acos_call(double x) { return ::acos(x); }
+__device__ __attribute__((noinline)) double atan_call(double x) { return ::atan(x); }
+__device__ __attribute__((noinline)) double tan_call(double x) { return ::tan(x); }
+__device__ __attribute__((noinline)) double sin_call(double x) { return ::sin(x); }
+__device__ __attribute__((noinline)) double cos_call(double x) { return ::cos(x); }
+}  // namespace lib
+struct LibMath {
+    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double exp(double x) { return lib::exp_call(x); }
+    static __device__ __forceinline__ double log(double x) { return lib::log_call(x); }
+    static __device__ __forceinline__ double acos(double x) { return lib::acos_call(x); }
+    static __device__ __forceinline__ double cos(double x) { return lib::cos_call(x); }
+    // (the library's sincos(x) returns exactly its sin(x) and cos(x): one reduction, the same two kernels)
+    static __device__ __forceinline__ void sincos(double x, double &s, double &c) { s = lib::sin_call(x);  c = lib::cos_call(x); }
+    static __device__ __forceinline__ double over_pi(double x) { return x / PI; }
+    static __device__ __forceinline__ double sin_of_acos(double t, double) { return lib::sin_call(t); }
+    static __device__ __forceinline__ double cos_of_difference(const Primed &v, const Primed &s, double cphi, double)
+    {
+        return lib::cos_call(v.ang * cphi - s.ang);
+    }
+    static __device__ __forceinline__ double cot_half(const Primed &p) { return 1.0 / lib::tan_call(p.ang / 2.0); }
+    static __device__ __forceinline__ Primed prime(double ell, double tan_za)
+    {
+        Primed p;
+        p.ang = lib::atan_call(ell * tan_za);
+        sincos(p.ang, p.s, p.c);
+        p.sec = 1.0 / p.c;
+        p.t = p.s / p.c;
+        return p;
+    }
+};
+// does a line with these zenith cosines take the reference's route (a zenith within 1e-6 rad of 90 degrees)?
+constexpr double HORIZON_COS = 1e-6;
+__device__ __forceinline__ bool near_horizon(double cos_vz, double cos_sz)
+{
+    return fabs(cos_vz) < HORIZON_COS || fabs(cos_sz) < HORIZON_COS;
 }
 
 // the scalars of a line that depend on its sun zenith only (gortt.c:290-291, 872-915; gortt_brdf.c:447,534)
+template <class M>
 __device__ inline SunScalars sun_scalars(const gort_canopy &c, double sza, double cos_sz, const Primed &sp)
 {
     SunScalars s;
     gap_lookup(c, sza, s.pn0, s.eps);
-    s.fd = c.use_user_fd ? c.fd_user : cos_sz / (cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291
+    s.fd = c.use_user_fd ? c.fd_user : M::div(cos_sz, cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291
     s.mu = sp.c;
-    s.t0 = exp(-(c.k * c.elai * sp.sec));
+    s.t0 = M::exp(-(c.k * c.elai * sp.sec));
     s.tp0 = s.pn0 + s.eps;
     return s;
 }
@@ -104,9 +186,9 @@ __device__ inline SunScalars sun_scalars(const gort_canopy &c, double sza, doubl
 __device__ inline SunScalars sun_from_zenith(const gort_canopy &c, double sza)
 {
     double sin_sz, cos_sz;
-    sincos(sza, &sin_sz, &cos_sz);
-    const Primed sp = prime(c.b / c.r, sin_sz / cos_sz);
-    return sun_scalars(c, sza, cos_sz, sp);
+    sincos(sza, &sin_sz, &cos_sz);                 // the zeniths' own sine and cosine: the library's (gort_geometry.h)
+    if (near_horizon(1.0, cos_sz)) return sun_scalars<LibMath>(c, sza, cos_sz, LibMath::prime(c.ell, sin_sz / cos_sz));
+    return sun_scalars<FastMath>(c, sza, cos_sz, FastMath::prime(c.ell, gm::quot(sin_sz, cos_sz)));
 }
 
 // t'_ff = t_ff (1 - kopen) + kopen with kopen = k_open + k_openep (gortt_brdf.c:348-365): ONE fused operation in

@@ -15,19 +15,21 @@ namespace {
 // Unfused on purpose: for equal primed zeniths and phi = 0 the reference gets d = t^2 + t^2 - 2 t t = 0
 // EXACTLY; an FMA leaves 1e-16 t^2 of product rounding in d, sqrt turns it into 1e-8 t, and Kc at 89/89 deg
 // moves by 3e-8.  All geometry below keeps plain IEEE multiply/add for the same reason.
+// M: the arithmetic (gort_device.h: FastMath for all lines but those at the horizon, LibMath there).
+template <class M>
 __device__ inline double overlap(double hb, const Primed &s, const Primed &v, double cphi, double sphi)
 {
 #pragma clang fp contract(off)
     const double d = s.t * s.t + v.t * v.t - 2.0 * s.t * v.t * cphi;
-    const double D = sqrt(ref_max(0.0, d));
+    const double D = M::sqrt(ref_max(0.0, d));
     const double x = s.t * v.t * sphi;
-    const double t2 = sqrt(D * D + x * x);
+    const double t2 = M::sqrt(D * D + x * x);
     const double t1 = s.sec + v.sec;
-    double cos_t = hb * t2 / t1;
+    double cos_t = M::div(hb * t2, t1);
     cos_t = ref_max(-1.0, cos_t);
     cos_t = ref_min(1.0, cos_t);
-    const double t = acos(cos_t);
-    return ref_max(0.0, (t - sin(t) * cos_t) * t1 / PI);
+    const double t = M::acos(cos_t);
+    return ref_max(0.0, M::over_pi((t - M::sin_of_acos(t, cos_t) * cos_t) * t1));
 }
 
 struct GeomOut {
@@ -45,36 +47,37 @@ struct RowTerms {
     double fF0, fFpi, beta;
     double eps_s, eps_v, ls, lv, h1, kf;
     SunScalars sun;
+    int horizon;                           // the line takes the reference's route (LibMath)
 };
 
 // Restates the azimuth-independent parts of gortt_kg/gortt_kc/gortt_kc_fFbeta (gortt_brdf.c:7-238),
 // gortt_set_zenith_dependant_probabilities (gortt.c:872-915) and gortt_kuusk (gortt_brdf.c:638-702).
-__device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms &r)
+// r.sin_vz ... r.cos_sz are set by the caller.
+template <class M>
+__device__ void row_terms_with(const gort_canopy &c, double vza, double sza, RowTerms &r)
 {
 #pragma clang fp contract(off)
-    const double ell = c.b / c.r;
-    sincos(vza, &r.sin_vz, &r.cos_vz);
-    sincos(sza, &r.sin_sz, &r.cos_sz);
-    r.v = prime(ell, r.sin_vz / r.cos_vz);
-    r.s = prime(ell, r.sin_sz / r.cos_sz);
+    const double ell = c.ell;                             // b / r, formed by gort_canopy_init as the reference does (gortt.c:641)
+    r.v = M::prime(ell, M::div(r.sin_vz, r.cos_vz));
+    r.s = M::prime(ell, M::div(r.sin_sz, r.cos_sz));
     const Primed &v = r.v, &s = r.s;
     r.cov = c.lambda * PI * c.rr;                         // lambda pi r^2
-    r.hb = c.h / c.b;
+    r.hb = M::div(c.h, c.b);
     r.t1 = s.sec + v.sec;
     const double cov = r.cov, t1 = r.t1;
 
     // principal-plane overlaps (Kc is interpolated between phi = 0 and pi, gortt_brdf.c:143-159)
-    const double O_0 = overlap(r.hb, s, v, 1.0, 0.0);
-    const double O_pi = overlap(r.hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
-    const double Kg0 = exp(-(cov * (t1 - O_0)));
-    const double Kgpi = exp(-(cov * (t1 - O_pi)));
+    const double O_0 = overlap<M>(r.hb, s, v, 1.0, 0.0);
+    const double O_pi = overlap<M>(r.hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
+    const double Kg0 = M::exp(-(cov * (t1 - O_0)));
+    const double Kgpi = M::exp(-(cov * (t1 - O_pi)));
 
     const double xs = cov * s.sec, xv = cov * v.sec;
-    r.es = exp(-xs);
-    r.ev = exp(-xv);
-    const double Mi = 1.0 - (1.0 - r.es) / xs;
-    const double Mv = 1.0 - (1.0 - r.ev) / xv;
-    const double theta_Mi = acos(1.0 - 2.0 * Mi);
+    r.es = M::exp(-xs);
+    r.ev = M::exp(-xv);
+    const double Mi = 1.0 - M::div(1.0 - r.es, xs);
+    const double Mv = 1.0 - M::div(1.0 - r.ev, xv);
+    const double theta_Mi = M::acos(1.0 - 2.0 * Mi);
     r.Gv = PI * c.rr * v.sec;
     const double Gv = r.Gv;
 
@@ -88,13 +91,13 @@ __device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms
         const double ph = v.c * s.c + v.s * s.s * cphi;
         const double Gam = PI * c.rr * (t1 - Oq);
         const double Gc = Gv * 0.5 * (1.0 + ph);
-        const double F = Gc / Gam;
-        const double M = 1.0 - (1.0 - Kgq) / (c.lambda * Gam);
-        const double PiMi = (1 - cos(theta_Mi * (1 - (s.ang - v.ang * cphi) / PI))) / 2.0;
-        const double PvMv = Mv - (1.0 - cos(v.ang * cphi - s.ang)) / 2.0;
+        const double F = M::div(Gc, Gam);
+        const double Mq = 1.0 - M::div(1.0 - Kgq, c.lambda * Gam);
+        const double PiMi = (1 - M::cos(theta_Mi * (1 - M::over_pi(s.ang - v.ang * cphi)))) / 2.0;
+        const double PvMv = Mv - (1.0 - M::cos_of_difference(v, s, cphi, ph)) / 2.0;
         // phi = pi lies in (90,270) deg -> Po = PvMv; phi = 0 -> by steepness (gortt_brdf.c:219-221)
         const double Po = (q == 1) ? PvMv : (view_steeper ? PiMi : PvMv);
-        const double f = F * (1.0 - Gv * (PvMv + PiMi - Po) / Gc) / (1.0 - M);
+        const double f = M::div(F * (1.0 - M::div(Gv * (PvMv + PiMi - Po), Gc)), 1.0 - Mq);
         fF[q] = f * F;
     }
     r.fF0 = fF[0];
@@ -105,38 +108,53 @@ __device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms
     } else if (s.ang < 0.000000001) {
         r.beta = 0.0;
     } else {
-        const double Dd = c.r * (1.0 / tan(s.ang / 2.0));
-        const double dh = (c.h2 - c.h1) / Dd;
+        const double Dd = c.r * M::cot_half(s);             // D = r / tan(sza'/2), gortt_brdf.c:196
+        const double dh = M::div(c.h2 - c.h1, Dd);
         const double lg = c.lambda * Gv;
-        r.beta = lg / (lg + dh) * (1.0 - exp(-lg - dh)) / (1.0 - exp(-lg));
+        r.beta = M::div(lg, lg + dh) * M::div(1.0 - M::exp(-lg - dh), 1.0 - M::exp(-lg));
     }
 
     // zenith-dependent gap probabilities; path lengths of Kuusk's hot spot
     double pn0_v;
-    r.sun = sun_scalars(c, sza, r.cos_sz, s);
+    r.sun = sun_scalars<M>(c, sza, r.cos_sz, s);
     r.eps_s = r.sun.eps;
     gap_lookup(c, vza, pn0_v, r.eps_v);
     r.kf = c.k * c.favd;
-    r.ls = -log(r.eps_s) / r.kf;
-    r.lv = -log(r.eps_v) / (0.5 * c.favd);
-    r.h1 = (r.ls * r.lv) > 0.0 ? sqrt(r.ls * r.lv) : 0.0;
+    r.ls = M::div(-M::log(r.eps_s), r.kf);
+    r.lv = M::div(-M::log(r.eps_v), 0.5 * c.favd);
+    r.h1 = (r.ls * r.lv) > 0.0 ? M::sqrt(r.ls * r.lv) : 0.0;
+}
 
+// The sine and cosine of the two ZENITHS are the device library's in both arithmetics.  In the exact hot-spot
+// direction (vza = sza, raa = 0) Kuusk's cos xi is cos^2 + sin^2 of one angle, and whether that sum rounds to 1 or
+// to 1 - 2^-53 decides between q2 = 0 and q2 = 2e-16 ls^2, i.e. 1e-8 of the reflectance at any zenith
+// (gortt_brdf.c:650-666): the reference's value follows the last bit of glibc's sin and cos, which the library's
+// reproduce (both are correctly rounded almost always) and a 1-ulp kernel does not - 24 reference hot-spot rows of
+// tests/golden/fuzz_canopies.npz moved by up to 5e-8 with it.  Two calls per line, ~80 instructions more than the kernels.
+__device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms &r)
+{
+    sincos(vza, &r.sin_vz, &r.cos_vz);
+    sincos(sza, &r.sin_sz, &r.cos_sz);
+    r.horizon = near_horizon(r.cos_vz, r.cos_sz) ? 1 : 0;
+    if (__builtin_expect(r.horizon, 0)) row_terms_with<LibMath>(c, vza, sza, r);
+    else row_terms_with<FastMath>(c, vza, sza, r);
 }
 
 // The azimuth-dependent rest: overlap and Kg at the actual azimuth, the interpolated Kc, the other
 // proportions (gortt.c:424-449) and the hot spot.
-__device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa, GeomOut &o)
+template <class M>
+__device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, double raa, GeomOut &o)
 {
 #pragma clang fp contract(off)
     const Primed &v = r.v, &s = r.s;
     double sin_r, cos_r;
-    sincos(raa, &sin_r, &cos_r);
-    const double O_r = overlap(r.hb, s, v, cos_r, sin_r);
-    const double Kg = exp(-(r.cov * (r.t1 - O_r)));
+    M::sincos(raa, sin_r, cos_r);
+    const double O_r = overlap<M>(r.hb, s, v, cos_r, sin_r);
+    const double Kg = M::exp(-(r.cov * (r.t1 - O_r)));
     const double ph_r = v.c * s.c + v.s * s.s * cos_r;
-    const double F_r = (r.Gv * 0.5 * (1.0 + ph_r)) / (PI * c.rr * (r.t1 - O_r));
+    const double F_r = M::div(r.Gv * 0.5 * (1.0 + ph_r), PI * c.rr * (r.t1 - O_r));
 
-    double frac = raa / PI;
+    double frac = M::over_pi(raa);
     if (frac > 1.0) frac = 2.0 - frac;
     double f = (1. - frac) * r.fF0 + frac * r.fFpi;
     f = r.beta * f + (1.0 - r.beta) * F_r;
@@ -157,15 +175,21 @@ __device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa
         const double cos_xi = r.cos_sz * r.cos_vz + r.sin_sz * r.sin_vz * cos_r;
         const double q2 = r.ls * r.ls + r.lv * r.lv - 2. * r.ls * r.lv * cos_xi;
         if (q2 > 0.0) {
-            const double lsv = sqrt(q2);
-            h2 = (1.0 - exp(-lsv / c.r)) / (lsv / c.r);
+            const double x = M::div(M::sqrt(q2), c.r);
+            h2 = M::div(1.0 - M::exp(-x), x);
         }
     }
-    const double kuusk = r.eps_s * r.eps_v * exp(r.kf * r.h1 * h2);
+    const double kuusk = r.eps_s * r.eps_v * M::exp(r.kf * r.h1 * h2);
 
     o.Kc = Kc;  o.Kg = Kg;  o.Kt = Kt;  o.Kz = Kz;  o.Kpg = Kpg;  o.Kpz = Kpz;
-    o.A = kuusk / (2.0 * s.c * v.c);
+    o.A = M::div(kuusk, 2.0 * s.c * v.c);
     o.sun = r.sun;
+}
+
+__device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa, GeomOut &o)
+{
+    if (__builtin_expect(r.horizon, 0)) finish_angle_with<LibMath>(c, r, raa, o);
+    else finish_angle_with<FastMath>(c, r, raa, o);
 }
 
 // areal proportions + hot spot for one normalised geometry
