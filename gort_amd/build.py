@@ -60,9 +60,8 @@ def build(force=False, verbose_resources=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     cc = hipcc()
-    headers = [os.path.join(ROOT, "include", "gort_amd.h"), os.path.join(ROOT, "include", "gort_amd_tuning.h"),
-               os.path.join(SRC, "gort_internal.h"), os.path.join(SRC, "gort_device.h"), os.path.join(SRC, "gort_geometry.h"),
-               os.path.join(SRC, "gort_flat.h"), os.path.abspath(__file__)]
+    import glob
+    headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(SRC, "*.h"))) + [os.path.abspath(__file__)]
     data = [os.path.join(PKG, "data", f) for f in ("prospect_d_coeffs.f32", "price_soil_eofs.f64")]
     common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
               "-I" + SRC, "--offload-arch=" + ARCH]

@@ -50,10 +50,11 @@ __device__ inline void normalise_angles(double vza_deg, double vaa_deg, double s
                                         double &vza, double &sza, double &saa, double &raa)
 {
 #pragma clang fp contract(off)
-    vza = vza_deg * PI / 180.0;
-    double vaa = vaa_deg * PI / 180.0;
-    sza = sza_deg * PI / 180.0;
-    saa = saa_deg * PI / 180.0;
+    // x * M_PI / 180.0 (gortt.c:240-243): the product, then the correctly rounded quotient by the constant
+    vza = gm::div_by_constant(vza_deg * PI, 180.0, 1.0 / 180.0);
+    double vaa = gm::div_by_constant(vaa_deg * PI, 180.0, 1.0 / 180.0);
+    sza = gm::div_by_constant(sza_deg * PI, 180.0, 1.0 / 180.0);
+    saa = gm::div_by_constant(saa_deg * PI, 180.0, 1.0 / 180.0);
     if (sza < 0.0) { saa += PI; sza *= -1.0; }      // normalised_sza() below restates these two lines
     if (vza < 0.0) { vaa += PI; vza *= -1.0; }
     // the reference wraps by repeated subtraction; beyond +-64 turns fold first so that
@@ -72,7 +73,7 @@ __device__ inline void normalise_angles(double vza_deg, double vaa_deg, double s
 __device__ inline double normalised_sza(double sza_deg)
 {
 #pragma clang fp contract(off)
-    double sza = sza_deg * PI / 180.0;
+    double sza = gm::div_by_constant(sza_deg * PI, 180.0, 1.0 / 180.0);
     if (sza < 0.0) sza *= -1.0;
     return sza;
 }
@@ -99,8 +100,13 @@ __device__ inline void sincos_of(double x, double &s, double &c)
 // Lines that close to the horizon evaluate the reference's route so that they print what the reference prints; they are
 // rare, the branch is wave-uniform almost always, and its code is round 3's (which the goldens pinned).
 struct FastMath {
-    static __device__ __forceinline__ double div(double a, double b) { return gm::quot(a, b); }
+    static __device__ __forceinline__ double div(double a, double b) { return gm::quot_finite(a, b); }     // b finite, not 0
+    static __device__ __forceinline__ double div_ieee(double a, double b) { return gm::quot(a, b); }       // b = 0, inf as IEEE
     static __device__ __forceinline__ double sqrt(double x) { return gm::sqrt_(x); }
+    static __device__ __forceinline__ double acos_unit(double x) { return gm::acos_unit(x); }
+    // sqrt(D D + x x) on the principal plane: x = tan tan sin(phi) is 0 (phi = 0) or 1e-16 of it (phi = M_PI), x x vanishes
+    // beside D D, and the correctly rounded root of a rounded square is the number itself
+    static __device__ __forceinline__ double hypot_principal(double D, double) { return D; }
     static __device__ __forceinline__ double exp(double x) { return gm::exp_(x); }
     static __device__ __forceinline__ double log(double x) { return gm::log_(x); }
     static __device__ __forceinline__ double acos(double x) { return gm::acos_(x); }
@@ -138,7 +144,10 @@ __device__ __attribute__((noinline)) double cos_call(double x) { return ::cos(x)
 }  // namespace lib
 struct LibMath {
     static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double div_ieee(double a, double b) { return a / b; }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double acos_unit(double x) { return lib::acos_call(x); }
+    static __device__ __forceinline__ double hypot_principal(double D, double x) { return ::sqrt(D * D + x * x); }
     static __device__ __forceinline__ double exp(double x) { return lib::exp_call(x); }
     static __device__ __forceinline__ double log(double x) { return lib::log_call(x); }
     static __device__ __forceinline__ double acos(double x) { return lib::acos_call(x); }
@@ -188,7 +197,7 @@ __device__ inline SunScalars sun_from_zenith(const gort_canopy &c, double sza)
     double sin_sz, cos_sz;
     sincos(sza, &sin_sz, &cos_sz);                 // the zeniths' own sine and cosine: the library's (gort_geometry.h)
     if (near_horizon(1.0, cos_sz)) return sun_scalars<LibMath>(c, sza, cos_sz, LibMath::prime(c.ell, sin_sz / cos_sz));
-    return sun_scalars<FastMath>(c, sza, cos_sz, FastMath::prime(c.ell, gm::quot(sin_sz, cos_sz)));
+    return sun_scalars<FastMath>(c, sza, cos_sz, FastMath::prime(c.ell, FastMath::div(sin_sz, cos_sz)));
 }
 
 // t'_ff = t_ff (1 - kopen) + kopen with kopen = k_open + k_openep (gortt_brdf.c:348-365): ONE fused operation in

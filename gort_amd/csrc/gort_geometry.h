@@ -16,19 +16,19 @@ namespace {
 // EXACTLY; an FMA leaves 1e-16 t^2 of product rounding in d, sqrt turns it into 1e-8 t, and Kc at 89/89 deg
 // moves by 3e-8.  All geometry below keeps plain IEEE multiply/add for the same reason.
 // M: the arithmetic (gort_device.h: FastMath for all lines but those at the horizon, LibMath there).
-template <class M>
+template <class M, bool PRINCIPAL>
 __device__ inline double overlap(double hb, const Primed &s, const Primed &v, double cphi, double sphi)
 {
 #pragma clang fp contract(off)
     const double d = s.t * s.t + v.t * v.t - 2.0 * s.t * v.t * cphi;
     const double D = M::sqrt(ref_max(0.0, d));
     const double x = s.t * v.t * sphi;
-    const double t2 = M::sqrt(D * D + x * x);
+    const double t2 = PRINCIPAL ? M::hypot_principal(D, x) : M::sqrt(D * D + x * x);
     const double t1 = s.sec + v.sec;
     double cos_t = M::div(hb * t2, t1);
     cos_t = ref_max(-1.0, cos_t);
     cos_t = ref_min(1.0, cos_t);
-    const double t = M::acos(cos_t);
+    const double t = M::acos_unit(cos_t);                 // hb, t2, t1 >= 0
     return ref_max(0.0, M::over_pi((t - M::sin_of_acos(t, cos_t) * cos_t) * t1));
 }
 
@@ -67,8 +67,8 @@ __device__ void row_terms_with(const gort_canopy &c, double vza, double sza, Row
     const double cov = r.cov, t1 = r.t1;
 
     // principal-plane overlaps (Kc is interpolated between phi = 0 and pi, gortt_brdf.c:143-159)
-    const double O_0 = overlap<M>(r.hb, s, v, 1.0, 0.0);
-    const double O_pi = overlap<M>(r.hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
+    const double O_0 = overlap<M, true>(r.hb, s, v, 1.0, 0.0);
+    const double O_pi = overlap<M, true>(r.hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
     const double Kg0 = M::exp(-(cov * (t1 - O_0)));
     const double Kgpi = M::exp(-(cov * (t1 - O_pi)));
 
@@ -120,8 +120,8 @@ __device__ void row_terms_with(const gort_canopy &c, double vza, double sza, Row
     r.eps_s = r.sun.eps;
     gap_lookup(c, vza, pn0_v, r.eps_v);
     r.kf = c.k * c.favd;
-    r.ls = M::div(-M::log(r.eps_s), r.kf);
-    r.lv = M::div(-M::log(r.eps_v), 0.5 * c.favd);
+    r.ls = M::div_ieee(-M::log(r.eps_s), r.kf);                // favd = 0 (-LAI 0): inf or NaN as the reference's
+    r.lv = M::div_ieee(-M::log(r.eps_v), 0.5 * c.favd);
     r.h1 = (r.ls * r.lv) > 0.0 ? M::sqrt(r.ls * r.lv) : 0.0;
 }
 
@@ -149,7 +149,7 @@ __device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, doubl
     const Primed &v = r.v, &s = r.s;
     double sin_r, cos_r;
     M::sincos(raa, sin_r, cos_r);
-    const double O_r = overlap<M>(r.hb, s, v, cos_r, sin_r);
+    const double O_r = overlap<M, false>(r.hb, s, v, cos_r, sin_r);
     const double Kg = M::exp(-(r.cov * (r.t1 - O_r)));
     const double ph_r = v.c * s.c + v.s * s.s * cos_r;
     const double F_r = M::div(r.Gv * 0.5 * (1.0 + ph_r), PI * c.rr * (r.t1 - O_r));

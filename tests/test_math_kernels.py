@@ -62,6 +62,8 @@ def test_kernels_within_one_ulp(gm):
     # acos on [-1, 1], dense at both ends (the overlap function's argument is clamped there)
     x = np.concatenate([rng.uniform(-1, 1, n), 1 - 10 ** rng.uniform(-16, 0, n), -1 + 10 ** rng.uniform(-16, 0, n), [0.5, -0.5, 0.0, 1.0, -1.0]])
     assert _ulps(_call(gm, "gm_acos", x), [mp.acos(f(v)) for v in x]) <= 1.0
+    x = np.concatenate([rng.uniform(0, 1, n), 1 - 10 ** rng.uniform(-16, 0, n), [0.5, 0.0, 1.0, 0.49999999999999994]])
+    assert _ulps(_call(gm, "gm_acos_unit", x), [mp.acos(f(v)) for v in x]) <= 1.0
     # sine and cosine up to the bound of the one-step reduction
     x = np.concatenate([rng.uniform(-7, 7, n), rng.uniform(-262144, 262144, n)])
     s, c = _call(gm, "gm_sincos", x)
@@ -81,12 +83,16 @@ def test_kernels_within_one_ulp(gm):
     b = rng.uniform(-10, 10, n) * 10 ** rng.uniform(-100, 100, n)
     assert _ulps(_call(gm, "gm_recip", b), [1 / f(v) for v in b]) <= 1.0
     assert _ulps(_call(gm, "gm_quot", a, b), [f(u) / f(v) for u, v in zip(a, b)]) <= 1.0
+    assert np.array_equal(_call(gm, "gm_quot_finite", a, b), _call(gm, "gm_quot", a, b))
+    # degrees -> radians as main() writes it, x * M_PI / 180.0: the division by the constant is correctly rounded
+    x = np.concatenate([rng.uniform(-400, 400, 20 * n), np.arange(-720, 721) * 0.5, np.arange(-360, 361) * 1.0]) * np.pi
+    assert np.array_equal(_call(gm, "gm_div180", x), x / 180.0)
 
 
 def test_special_values_as_the_library(gm):
     inf, nan = np.inf, np.nan
-    e = _call(gm, "gm_exp", np.array([-inf, inf, nan, -1000.0, 1000.0, 0.0]))
-    assert e[0] == 0 and e[1] == inf and np.isnan(e[2]) and e[3] == 0 and e[4] == inf and e[5] == 1
+    e = _call(gm, "gm_exp", np.array([-inf, nan, -1000.0, 1000.0, 0.0, -1e10, -1e300]))
+    assert e[0] == 0 and np.isnan(e[1]) and e[2] == 0 and e[3] == inf and e[4] == 1 and e[5] == 0 and e[6] == 0
     l = _call(gm, "gm_log", np.array([0.0, -1.0, inf, nan, 1.0]))
     assert l[0] == -inf and np.isnan(l[1]) and l[2] == inf and np.isnan(l[3]) and l[4] == 0
     a = _call(gm, "gm_acos", np.array([1.0, -1.0, nan, 1.0000000000000002]))
