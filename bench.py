@@ -203,7 +203,7 @@ def measure_traffic(args, timeout_s=150):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    child = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
              "--sustain-s", "0", "--no-config5", "--lut-draws", "1", "--no-traffic", "--nsza", str(args.nsza), "--nw", str(args.nw)]
     kb = {}
     for counter in ("WRITE_SIZE", "FETCH_SIZE"):
@@ -324,7 +324,16 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="world > 1: skip the all-gather of the LUT after the timed steps")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (ensemble) block")
     ap.add_argument("--c5-members", type=int, default=1000, help="members of the config-5 ensemble (1000 = BASELINE config 5)")
-    ap.add_argument("--c5-chunk", type=int, default=40, help="members per LUT chunk of the config-5 block (0 = no LUTs)")
+    ap.add_argument("--c5-chunk", type=int, default=25,
+                    help="members per LUT chunk of the config-5 block (0 = no LUTs); 25 keeps a chunk's records under the 64 MB "
+                         "up to which the engine overlaps the next chunk's geometry with this chunk's expansion")
+    ap.add_argument("--lut-slack-gib", type=int, default=48,
+                    help="world > 1: cap (GiB) of the slack gort_lut_alloc keeps beside the buffer to place this rank's window "
+                         "(GORT_LUT_SLACK_GIB; 0 = plain allocation).  The timed steps are also run with 0 and 16: `slack_sweep`")
+    ap.add_argument("--collective-timeout", type=float, default=240.0,
+                    help="seconds a collective behind the timed region may take before it is recorded as failed; the JSON line is "
+                         "printed all the same and the run exits non-zero")
+    ap.add_argument("--inject-gather-error", action="store_true", help="test hook: the LUT all-gather raises")
     ap.add_argument("--no-traffic", action="store_true",
                     help="N = 1: do not measure the kernel's HBM traffic with two rocprofv3 --pmc child passes (~30 s)")
     ap.add_argument("--traffic-gb", type=float, default=None,
@@ -347,11 +356,14 @@ def main():
     red_dev = "cpu" if args.rehearse else "cuda"
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        # the library's own watchdog fires well after our deadline: a hung collective must cost its own record, not the line
+        pg_timeout = datetime.timedelta(seconds=args.collective_timeout + 180.0)
         if args.rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=pg_timeout)
 
     def barrier():
         if world > 1:
@@ -363,6 +375,34 @@ def main():
         t = torch.tensor(list(values), dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return [float(x) for x in t]
+
+    # Everything behind the timed region that talks to other ranks runs under a deadline, on a helper thread: an RCCL
+    # error raises, a hang times out - either way the failure is RECORDED, no further collective is attempted (they would
+    # hang on the same fault), rank 0 still prints its line and every rank exits non-zero.  The one multi-GPU run the
+    # driver gets must not end without a line because the 50 GB all-gather threw.
+    errors = []
+
+    def guarded(what, fn, default=None, deadline=None):
+        if errors:
+            return default                         # the process group is not trusted any more
+        import threading
+        box = {}
+
+        def run():
+            try:
+                box["value"] = fn()
+            except BaseException as ex:           # noqa: BLE001
+                box["error"] = repr(ex)
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(deadline or args.collective_timeout)
+        if th.is_alive():
+            errors.append({"where": what, "error": "no completion within %.0f s" % (deadline or args.collective_timeout)})
+            return default
+        if "error" in box:
+            errors.append({"where": what, "error": box["error"]})
+            return default
+        return box.get("value")
 
     # ---- untimed setup: canopy, gap probabilities (GPU), spectra, engine ----
     wl = np.arange(400.0, 2501.0, 1.0) if args.nw == 2101 else np.linspace(400.0, 2500.0, args.nw)
@@ -411,12 +451,34 @@ def main():
     first.free()
     # ---- (2) the product allocator of the C ABI (gort_lut_alloc: best of <= --lut-draws placements by a store-pattern
     #          probe of the window this rank writes); the number of record is measured on its buffer ----
+    #          At world > 1 the window is placed by a scan through slack that stays allocated: the
+    #          same steps are also timed with the slack capped at 0 and 16 GiB, so that the record says what the slack buys.
+    slack_sweep = None
+    if world > 1 and args.lut_draws > 1:
+        slack_sweep = {}
+        for cap in sorted({0, 16} - {args.lut_slack_gib}):
+            os.environ["GORT_LUT_SLACK_GIB"] = str(cap)
+            b2 = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
+            s_dt, s_k = timed_steps(b2.at(window[0]), args.warmup, args.steps)
+            slack_sweep[str(cap)] = {"dt": s_dt, "kernel_ms": s_k, "slack_gb": b2.placement["slack_bytes"] / 1e9}
+            b2.free()
+    os.environ["GORT_LUT_SLACK_GIB"] = str(args.lut_slack_gib)
     buf = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
+    os.environ.pop("GORT_LUT_SLACK_GIB", None)
     lut_ptr = buf.at(window[0])
+    free_b, total_b = torch.cuda.mem_get_info()
+    hbm = {"lut_buffer_gb": buf_rows * row_elems * 8 / 1e9, "placement_slack_gb": buf.placement["slack_bytes"] / 1e9,
+           "device_used_gb_with_lut": (total_b - free_b) / 1e9, "device_total_gb": total_b / 1e9}
     dt, kernel_ms = timed_steps(lut_ptr, args.warmup, args.steps)
 
     # ---- sustained rate: the same step back to back for >= --sustain-s seconds (clocks and power settled) ----
     dt, kernel_ms_max, fd_dt, fd_kernel_max = reduce_max([dt, kernel_ms, fd_dt, fd_kernel])
+    if slack_sweep:
+        for cap, rec in slack_sweep.items():
+            r_dt, r_k = reduce_max([rec["dt"], rec["kernel_ms"]])
+            slack_sweep[cap] = {"value": total_samples * args.steps / r_dt, "ms_per_step": r_dt / args.steps * 1e3,
+                                "kernel_ms_slowest_rank": r_k, "slack_gb_this_rank": rec["slack_gb"]}
+        slack_sweep[str(args.lut_slack_gib)] = "the number of record (value, ms_per_step, roofline)"
     sustained = None
     if args.sustain_s > 0:
         n_sus = max(args.steps, int(args.sustain_s / max(dt / args.steps, 1e-4)) + 1)     # from the reduced dt: equal on all ranks
@@ -427,28 +489,70 @@ def main():
 
     # ---- every rank's own numbers, gathered to rank 0 ----
     mine = {"rank": rank, "rows": [r0, r1], "samples": my_samples, "kernel_ms": kernel_ms,
-            "first_draw_kernel_ms": fd_kernel, "lut_alloc": buf.placement, "xcd_mapping": eng.xcd_mapping(),
+            "first_draw_kernel_ms": fd_kernel, "lut_alloc": buf.placement, "hbm": hbm, "xcd_mapping": eng.xcd_mapping(),
             "xcd_weights_32nds": eng.xcd_weights()[0], "store_pattern_gbs": eng.store_pattern_gbs()}
     per_rank = [mine]
     if world > 1:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+        def gather_records():
+            got = [None] * world
+            dist.all_gather_object(got, mine)
+            return got
+        per_rank = guarded("all_gather_object(per-rank records)", gather_records, default=[mine])
 
     # ---- OUTSIDE the timed step: reassemble the LUT on every rank with one in-place RCCL all-gather ----
     allgather = None
     if world > 1 and not args.no_gather:
         full_t = buf.tensor((buf_rows, row_elems))
-        torch.cuda.synchronize(); barrier()
-        tg = time.perf_counter()
-        all_gather_in_place(full_t, rows)
-        torch.cuda.synchronize(); barrier()
-        ag_s = reduce_max([time.perf_counter() - tg])[0]
+
+        def gather_lut():
+            torch.cuda.synchronize(); barrier()
+            tg = time.perf_counter()
+            if args.inject_gather_error:
+                raise RuntimeError("injected by --inject-gather-error")
+            all_gather_in_place(full_t, rows)
+            torch.cuda.synchronize(); barrier()
+            return reduce_max([time.perf_counter() - tg])[0]
+        ag_s = guarded("all-gather of the LUT", gather_lut)
         received = (buf_rows - buf_rows // world) * row_elems * 8            # bytes that arrive in this GPU's HBM
-        allgather = {"what": "the whole LUT, in place: each rank's window is its send buffer (gort_amd.shard.all_gather_in_place)",
-                     "ms": ag_s * 1e3, "bytes_received_per_gpu": received, "gbs_received_per_gpu": received / ag_s / 1e9,
-                     "xgmi_bound_gbs": XGMI_BOUND_GBS, "frac_of_xgmi_bound": received / ag_s / 1e9 / XGMI_BOUND_GBS,
-                     "backend": "gloo (rehearsal on one GPU: not a measurement)" if args.rehearse else "nccl (RCCL)",
-                     "inside_timed_region": False}
+        what = "the whole LUT, in place: each rank's window is its send buffer (gort_amd.shard.all_gather_in_place)"
+        backend = "gloo (rehearsal on one GPU: not a measurement)" if args.rehearse else "nccl (RCCL)"
+        if ag_s is None:
+            allgather = {"what": what, "error": errors[-1], "bytes_received_per_gpu": received, "backend": backend,
+                         "inside_timed_region": False}
+        else:
+            allgather = {"what": what, "ms": ag_s * 1e3, "bytes_received_per_gpu": received, "gbs_received_per_gpu": received / ag_s / 1e9,
+                         "xgmi_bound_gbs": XGMI_BOUND_GBS, "frac_of_xgmi_bound": received / ag_s / 1e9 / XGMI_BOUND_GBS,
+                         "backend": backend, "inside_timed_region": False}
+
+    # ---- the same exchange once more through the C ABI (gort_rccl_* + gort_lut_allgather: librccl's ncclAllGather on the
+    #      engine's stream, the path of a host without torch).  Idempotent (the windows hold what they held); a failure
+    #      that raises is recorded beside the number and does not count against the run, a hang does.
+    allgather_c_abi = None
+    if allgather is not None and "error" not in allgather and not args.rehearse:
+        from gort_amd.shard import all_gather_in_place_c_abi, rccl_comm_for_group
+        state = {}
+
+        def gather_c_abi():
+            try:
+                comm = rccl_comm_for_group()
+                torch.cuda.synchronize(); barrier()
+                tg = time.perf_counter()
+                all_gather_in_place_c_abi(eng, buf, rows, row_elems, comm)
+                torch.cuda.synchronize(); barrier()
+                state["s"] = time.perf_counter() - tg
+                comm.destroy()
+            except Exception as ex:                        # noqa: BLE001
+                state["error"] = repr(ex)
+            return True
+        done = guarded("all-gather of the LUT through the C ABI", gather_c_abi)
+        if done and "s" in state:
+            ag2 = reduce_max([state["s"]])[0]
+            received = (buf_rows - buf_rows // world) * row_elems * 8
+            allgather_c_abi = {"what": "gort_lut_allgather (include/gort_amd.h): ncclAllGather of librccl, in place, on the engine's stream",
+                               "ms": ag2 * 1e3, "gbs_received_per_gpu": received / ag2 / 1e9,
+                               "frac_of_xgmi_bound": received / ag2 / 1e9 / XGMI_BOUND_GBS}
+        else:
+            allgather_c_abi = {"error": state.get("error") or (errors[-1] if errors else "skipped")}
 
     # ---- parity spot checks (outside the timed region) against the CPU oracle: rows of this rank's window and, after
     #      the gather, rows that other ranks computed (rank 1's and the last rank's windows) ----
@@ -459,7 +563,7 @@ def main():
             idx = np.sort(rng.choice((r1 - r0) * grid.nphi, size=64, replace=False))
             got = np.stack([buf.to_numpy(nw, window[0] + int(i) * nw) for i in idx])
             parity = compare(got, oracle_rows(wl, grid, r0 + idx // grid.nphi, idx % grid.nphi), "64 nodes of rank 0's window")
-            if allgather is not None:
+            if allgather is not None and "error" not in allgather:
                 picks = []
                 for other in sorted({1, world - 1}):
                     o0, o1 = row_slab(other, world, rows)
@@ -514,12 +618,14 @@ def main():
                          "algorithmic_bytes_per_launch": per_launch_bytes, "launch": "rank 0's slab",
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_replayed": replayed},
             "per_rank": per_rank,
+            "slack_sweep": slack_sweep,
             "sustained": sustained,
             "parity": parity,
             "reference_build": reference_build_id(),
         }
         if allgather is not None:
             out["allgather"] = allgather
+            out["allgather_c_abi"] = allgather_c_abi
             out["parity_after_allgather"] = parity_foreign
         elif world > 1:
             out["allgather"] = None
@@ -527,9 +633,9 @@ def main():
 
     # ---- BASELINE config 5 as a block of its own (after the LUT buffer is gone: its chunks want the HBM) ----
     if not args.no_config5:
-        c5 = config5_block(args, rank, world, dist, barrier)
+        c5 = guarded("config 5 block", lambda: config5_block(args, rank, world, dist, barrier), deadline=3 * args.collective_timeout)
         if rank == 0:
-            out["config5"] = c5
+            out["config5"] = c5 if c5 is not None else {"error": errors[-1] if errors else "skipped: an earlier collective failed"}
 
     if rank == 0 and world == 1 and not args.no_traffic and args.traffic_gb is None:
         # HBM traffic of the dominant kernel from the PMC counters, in this very run (the LUT buffers are gone: the child
@@ -571,7 +677,18 @@ def main():
             out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
             out["gpu_over_cpu"] = {"vs_cpu_baseline_same_shape_all_cores": out["value"] / out["cpu_baseline"]["value"],
                                    "vs_port_one_core": out["value"] / out["cpu_baseline_port"]["value"]}
+        if errors:
+            out["errors"] = errors
         print(json.dumps(out), flush=True)
+    if errors:
+        # a collective failed or hangs on a helper thread: the line is out (rank 0), nothing here can be torn down in order.
+        # The launcher (torch.distributed.run) kills every rank as soon as ONE exits non-zero: the other ranks give rank 0
+        # time (a collective deadline and a minute) to get its line out before they report the failure with their exit code.
+        print("bench.py: rank %d: %r" % (rank, errors), file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        if rank != 0:
+            time.sleep(args.collective_timeout + 60.0)     # rank 0 may still be waiting out a deadline of its own; its exit ends this
+        os._exit(4)
     eng.close()
     if world > 1:
         dist.destroy_process_group()

@@ -71,12 +71,13 @@ DECLARED_SYMBOLS = [
     "gort_prospect_d", "gort_spectra", "gort_gauleg", "gort_format_f6", "gort_format_f6_row", "gort_lut_format", "gort_lut_read",
     "gort_device_count", "gort_dev_malloc", "gort_dev_free", "gort_memcpy_h2d", "gort_memcpy_d2h",
     "gort_lut_alloc", "gort_lut_free",
+    "gort_rccl_unique_id", "gort_rccl_comm_init_rank", "gort_rccl_comm_init_all", "gort_rccl_comm_destroy", "gort_lut_allgather",
     "gort_gap_probabilities", "gort_gap_probabilities_dev", "gort_gap_cache_stats", "gort_gap_cache_clear",
     "gort_canopy_check_geometry",
     "gort_canopy_key", "gort_lut_cache_store", "gort_lut_cache_load",
     "gort_engine_create", "gort_engine_destroy", "gort_engine_stream", "gort_engine_synchronize",
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
-    "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_get_member",
+    "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_reserve_members", "gort_engine_get_member",
     "gort_rsurf_members_grid_dev", "gort_rsurf_members_stream", "gort_rsurf_members_stream_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
@@ -155,6 +156,12 @@ def lib():
         L.gort_rsurf_members_stream_dev.argtypes = L.gort_rsurf_members_stream.argtypes
         L.gort_engine_n_members.argtypes = [C.c_void_p]
         L.gort_engine_set_members.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.gort_engine_reserve_members.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.gort_rccl_unique_id.argtypes = [C.c_void_p]
+        L.gort_rccl_comm_init_rank.argtypes = [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.gort_rccl_comm_init_all.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.gort_rccl_comm_destroy.argtypes = [C.c_void_p]
+        L.gort_lut_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         L.gort_engine_set_members_leaf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                    C.c_void_p, C.c_int]
         L.gort_engine_get_member.argtypes = [C.c_void_p, C.c_int, C.POINTER(Canopy), C.c_void_p, C.c_void_p,
@@ -231,9 +238,34 @@ class DeviceBuffer:
             pass
 
 
+RCCL_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """128 opaque bytes (ncclGetUniqueId): rank 0 draws them, the host's bootstrap hands them to the other ranks."""
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    _check(lib().gort_rccl_unique_id(buf))
+    return bytes(buf.raw)
+
+
+class RcclComm:
+    """An RCCL communicator made through the C ABI (gort_rccl_comm_init_rank on the CURRENT device)."""
+
+    def __init__(self, world, unique_id, rank):
+        assert len(unique_id) == RCCL_ID_BYTES
+        h = C.c_void_p()
+        _check(lib().gort_rccl_comm_init_rank(int(world), C.create_string_buffer(unique_id, RCCL_ID_BYTES), int(rank), C.byref(h)))
+        self.h, self.world, self.rank = h, int(world), int(rank)
+
+    def destroy(self):
+        if self.h:
+            _check(lib().gort_rccl_comm_destroy(self.h))
+            self.h = None
+
+
 class LutPlacement(C.Structure):
     _fields_ = [("draws", C.c_int32), ("picked", C.c_int32), ("probe_gbs", D * 64), ("accept_gbs", D), ("shifted", C.c_int32),
-                ("rescans", C.c_int32)]
+                ("rescans", C.c_int32), ("slack_bytes", C.c_uint64)]
 
 
 class LutBuffer:
@@ -247,7 +279,7 @@ class LutBuffer:
         self.placement = {"draws": int(placement.draws), "picked": int(placement.picked),
                           "probe_gbs": [float(placement.probe_gbs[i]) for i in range(placement.draws)],
                           "accept_gbs": float(placement.accept_gbs), "shifted": bool(placement.shifted),
-                          "rescans": int(placement.rescans)}
+                          "rescans": int(placement.rescans), "slack_bytes": int(placement.slack_bytes)}
         self.window = window                 # (offset_doubles, doubles) this process writes, or None = everything
 
     @property
@@ -522,6 +554,10 @@ class Engine:
         _check(lib().gort_engine_set_members_leaf(self.h, arr, larr, len(members), int(compute_gaps), _ptr(w), w.size))
         self.nw = w.size
 
+    def reserve_members(self, n_members, nw):
+        """Allocate everything the member setters need for n_members x nw bands now (gort_engine_reserve_members)."""
+        _check(lib().gort_engine_reserve_members(self.h, int(n_members), int(nw)))
+
     def get_member(self, m):
         c = Canopy()
         rs, rl, tl = np.zeros(self.nw), np.zeros(self.nw), np.zeros(self.nw)
@@ -569,6 +605,12 @@ class Engine:
 
     def last_stream_ms(self):
         return lib().gort_engine_last_stream_ms(self.h)
+
+    def lut_allgather(self, buf, rows_per_rank, row_doubles, comm):
+        """gort_lut_allgather: the in-place RCCL all-gather of a gatherable LUT buffer (api.LutBuffer or a device pointer) on
+        the engine's stream; rank `comm.rank` has written rows [rank * rows_per_rank, (rank + 1) * rows_per_rank)."""
+        ptr = buf.ptr if hasattr(buf, "ptr") else int(buf)
+        _check(lib().gort_lut_allgather(self.h, C.c_void_p(ptr), int(rows_per_rank), int(row_doubles) * 8, comm.rank, comm.world, comm.h))
 
     def lut_alloc(self, doubles, window=None, max_draws=3):
         """gort_lut_alloc: `doubles` float64 of HBM for a LUT; window = (offset, count) in doubles of the part this

@@ -33,6 +33,7 @@ UNITS = [
     ("gort_pipe.hip", []),
     ("gort_spectra.hip", []),
     ("gort_api.hip", []),
+    ("gort_rccl.cpp", []),
     ("gort_host.cpp", ["-ffp-contract=off", '-DGORT_DATA_DIR="%s"' % os.path.join(PKG, "data")]),
 ]
 
@@ -76,7 +77,7 @@ def build(force=False, verbose_resources=False):
             _run([cc] + common + extra + ["-c", s, "-o", o])
         objs.append(o)
     if force or _newer(LIB, objs):
-        _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+        _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"])
     main = os.path.join(SRC, "gortt_main.cpp")
     if os.path.exists(main) and (force or _newer(BIN, [main, LIB] + headers)):
         _run([cc, "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), main, "-o", BIN,

@@ -106,6 +106,7 @@ struct gort_engine {
     int n_members = 1;
     bool have_canopy = false, have_spectra = false, have_nodes = false, have_tables = false;
     int nw = 0;
+    int device = 0;                      // the HIP device the engine was created on: its LUT buffers live there
 };
 
 extern "C" int gort_device_count(void)
@@ -310,6 +311,7 @@ extern "C" int gort_engine_create(gort_engine **out)
         gort_engine_destroy(e);
         return fail(GORT_ENODEVICE, "gort_engine_create: cannot create streams/events");
     }
+    if (hipGetDevice(&e->device) != hipSuccess) { (void)hipGetLastError(); e->device = 0; }
     if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
     if (const char *v = getenv("GORT_ENERGY_DEDUP")) e->energy_dedup = atoi(v) != 0;
     if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
@@ -578,6 +580,22 @@ extern "C" int gort_engine_set_members_leaf(gort_engine *e, const gort_canopy *m
     e->nw = nw;
     e->have_spectra = true;
     return refresh_lambda_table(e);
+}
+
+// capacity for an ensemble of n_members x nw bands: every buffer the member setters and the band tables need, the pinned
+// staging of their uploads and the spectral tables - so that a setter call costs its copies and kernels (~1.5 ms for 1000
+// members) and not the process's first 240 MB of hipMalloc and hipHostMalloc (15 - 30 ms, by the box)
+extern "C" int gort_engine_reserve_members(gort_engine *e, int n_members, int nw)
+{
+    if (!e || n_members <= 0 || n_members > 65535 || nw <= 0) return fail(GORT_EINVAL, "gort_engine_reserve_members: bad argument");
+    int rc = stage_begin(e, (sizeof(gort_canopy) + sizeof(gort_leaf_soil)) * (size_t)n_members + sizeof(double) * (size_t)nw + 1024);
+    if (rc) return rc;
+    if ((rc = ensure_spectral_tables(e))) return rc;
+    if ((rc = e->canopy.reserve(sizeof(gort_canopy) * (size_t)n_members))) return rc;
+    if ((rc = e->leaf.reserve(sizeof(gort_leaf_soil) * (size_t)n_members))) return rc;
+    if ((rc = e->wl.reserve(sizeof(double) * (size_t)nw))) return rc;
+    if ((rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw * (size_t)n_members))) return rc;
+    return e->L.reserve(sizeof(double) * lambda_table_doubles(nw, n_members));
 }
 
 extern "C" int gort_engine_get_member(gort_engine *e, int member, gort_canopy *canopy, double *rsoil, double *rleaf,
@@ -970,6 +988,7 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         win_bytes > bytes - win_offset)
         return fail(GORT_EINVAL, "gort_lut_alloc: bad argument");
     if (win_bytes == 0) { win_offset = 0; win_bytes = bytes / sizeof(double) * sizeof(double); }
+    GORT_HIP(hipSetDevice(e->device));                 // the engine's device, whatever the calling thread had current
     if (max_draws < 1) max_draws = 1;
     if (max_draws > GORT_LUT_MAX_DRAWS) max_draws = GORT_LUT_MAX_DRAWS;
     const long doubles = (long)(win_bytes / sizeof(double));
@@ -1008,6 +1027,7 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
     // slack (at most what leaves 8 GiB of the device free) stays allocated with the buffer.
     const bool scan = select && win_bytes * 2 <= bytes;
     void *base = nullptr;
+    size_t slack_bytes = 0;
     if (scan) {
         constexpr size_t GIB = (size_t)1 << 30;
         // An allocation that lies inside ONE physical extent has no plateau anywhere (a fresh process's first 76 GiB:
@@ -1018,8 +1038,15 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         for (int attempt = 0; attempt < 3 && rc == GORT_OK; ++attempt) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            // GORT_LUT_SLACK_GIB: the cap of the slack that stays allocated with the buffer (default 48; 0 = no scan, a
+            // plain allocation).  Ranks that share a GPU, or a caching allocator beside this one, want it small.
             size_t slack_gib = 48;
+            if (const char *v = getenv("GORT_LUT_SLACK_GIB")) {
+                const long cap = atol(v);
+                slack_gib = cap < 0 ? 0 : (cap > 63 ? 63 : (size_t)cap);
+            }
             while (slack_gib > 0 && bytes + slack_gib * GIB + 8 * GIB > free_b) slack_gib /= 2;
+            slack_bytes = 0;
             for (;; slack_gib /= 2) {
                 if (hipMalloc(&base, bytes + slack_gib * GIB) == hipSuccess) break;
                 (void)hipGetLastError();
@@ -1027,6 +1054,7 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
                 if (slack_gib == 0) break;
             }
             if (!base) { rc = fail(GORT_ENOMEM, "gort_lut_alloc: cannot allocate %zu bytes", bytes); break; }
+            slack_bytes = slack_gib * GIB;
             int cands = (int)slack_gib + 1;
             if (cands > GORT_LUT_MAX_DRAWS) cands = GORT_LUT_MAX_DRAWS;
             const size_t step = cands > 1 ? slack_gib * GIB / (size_t)(cands - 1) / (2u << 20) * (2u << 20) : 0;
@@ -1094,10 +1122,20 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         info->picked = best;
         info->accept_gbs = accept;
         info->shifted = scan ? 1 : 0;
+        info->slack_bytes = (uint64_t)slack_bytes;
         for (int i = 0; i < n; ++i) info->probe_gbs[i] = gbs[i];
     }
     *out_dev = cand[best];
     return GORT_OK;
+}
+
+// the all-gather of a row-sharded LUT on the engine's stream (gort_rccl.cpp): asynchronous like every device entry point
+extern "C" int gort_lut_allgather_on(void *stream, void *lut_dev, size_t rows_per_rank, size_t row_bytes, int rank, int world, void *comm);
+extern "C" int gort_lut_allgather(gort_engine *e, void *lut_dev, size_t rows_per_rank, size_t row_bytes, int rank, int world, void *comm)
+{
+    if (!e) return fail(GORT_EINVAL, "gort_lut_allgather: null engine");
+    GORT_HIP(hipSetDevice(e->device));
+    return gort_lut_allgather_on(e->stream, lut_dev, rows_per_rank, row_bytes, rank, world, comm);
 }
 
 // the probe of gort_lut_alloc on memory the caller owns (contents destroyed): include/gort_amd_tuning.h

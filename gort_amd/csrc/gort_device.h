@@ -36,6 +36,7 @@ __device__ __forceinline__ double dot5(double aC, double aB, double aZ, double a
 // indexes past the table for zenith > 90 deg; defined here as NaN.
 __device__ inline void gap_lookup(const gort_canopy &c, double za, double &pn0, double &epg)
 {
+#pragma clang fp contract(off)
     const double pos = fabs(za) / c.dth;
     const double cf = ceil(pos), ff = floor(pos);
     if (!(cf <= (double)(GORT_NTH - 1))) { pn0 = epg = __builtin_nan(""); return; }
@@ -182,6 +183,7 @@ __device__ __forceinline__ bool near_horizon(double cos_vz, double cos_sz)
 template <class M>
 __device__ inline SunScalars sun_scalars(const gort_canopy &c, double sza, double cos_sz, const Primed &sp)
 {
+#pragma clang fp contract(off)
     SunScalars s;
     gap_lookup(c, sza, s.pn0, s.eps);
     s.fd = c.use_user_fd ? c.fd_user : M::div(cos_sz, cos_sz + 0.09);   // Ni et al. '99, gortt.c:290-291

@@ -98,12 +98,20 @@ __global__ __launch_bounds__(256) void energy_rep_kernel(const double *__restric
 }
 
 // The evaluation of ONE line by one 512-thread workgroup (thread = quadrature node); energy = this member's [nA][nw][3].
+// The 512 nodes are 32 azimuths x 16 zeniths (node = 16 i + j, ensure_nodes() in gort_api.hip), and ~1100 of the ~1500
+// instructions of a node's geometry do not depend on its azimuth (row_terms, gort_geometry.h): sixteen lanes evaluate them
+// once per zenith node into LDS, then every thread finishes its own node - the split the grid kernel makes for its rows.
+// Same two functions on the same numbers as geometry_core(): the same bits (SHARE_ROWS = false keeps the round-3 form,
+// every thread the whole geometry, for the test that says so: GORT_ENERGY_SHARE_ROWS=0).
+constexpr int ENERGY_ZENITH_NODES = 16;
 struct EnergyShared {
     double part[5][ENERGY_THREADS / 64];
     double abar[5];
     double sun[6];
+    RowTerms row[ENERGY_ZENITH_NODES];
 };
 
+template <bool SHARE_ROWS>
 __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *__restrict__ L, int nw,
                                             const double *__restrict__ angles, const double *__restrict__ nodes,
                                             double *__restrict__ energy, long a, EnergyShared &sh)
@@ -118,10 +126,15 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
         raa = saa - vaa;
         raa = fabs((raa - 2 * PI * (int)(0.5 + raa * INV_PI * 0.5)));
     }
-    vza = nodes[3 * tid + 1];
     const double w = nodes[3 * tid + 2];
     GeomOut g;
-    geometry_core(c, vza, sza, raa, g);
+    if (SHARE_ROWS) {
+        if (tid < ENERGY_ZENITH_NODES) row_terms(c, nodes[3 * tid + 1], sza, sh.row[tid]);
+        __syncthreads();
+        finish_angle(c, sh.row[tid & (ENERGY_ZENITH_NODES - 1)], raa, g);
+    } else {
+        geometry_core(c, nodes[3 * tid + 1], sza, raa, g);
+    }
     double rec[GORT_COEF_STRIDE];
     store_coef(rec, c, g);
     double part[5] = {w * rec[A_C], w * rec[A_B], w * rec[A_Z], w * rec[A_G], w * rec[A_T]};
@@ -158,18 +171,10 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     }
 }
 
-// the same behind a call: a loop around the inlined body lets the compiler hoist the body's loop-invariant loads in
-// front of the loop, which took the kernel from 135 to 256 VGPRs + 58 spilled (20 -> 24 us per line)
-__device__ __noinline__ void energy_line_call(const gort_canopy &c, const double *__restrict__ L, int nw,
-                                              const double *__restrict__ angles, const double *__restrict__ nodes,
-                                              double *__restrict__ energy, long a, EnergyShared &sh)
-{
-    energy_line(c, L, nw, angles, nodes, energy, a, sh);
-}
-
 // blockIdx.x = angle line, blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by
 // the members; energy[member][nA][nw][3]
-__global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canopy *__restrict__ canopies,
+template <bool SHARE_ROWS>
+__global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_kernel(const gort_canopy *__restrict__ canopies,
                                                                  const double *__restrict__ Lall, int nw,
                                                                  const double *__restrict__ angles, long nA,
                                                                  const double *__restrict__ nodes,   // [512][3] vaa, vza, weight
@@ -177,12 +182,13 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_kernel(const gort_canop
 {
     __shared__ EnergyShared sh;
     const long member = blockIdx.y;
-    energy_line(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
-                (long)blockIdx.x, sh);
+    energy_line<SHARE_ROWS>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
+                            (long)blockIdx.x, sh);
 }
 
 // the lines that stand for themselves (uniq[0] of them, uniq[1..]): workgroups stride over the list
-__global__ __launch_bounds__(ENERGY_THREADS) void energy_list_kernel(const gort_canopy *__restrict__ canopies,
+template <bool SHARE_ROWS>
+__global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_kernel(const gort_canopy *__restrict__ canopies,
                                                                       const double *__restrict__ Lall, int nw,
                                                                       const double *__restrict__ angles, long nA,
                                                                       const double *__restrict__ nodes,
@@ -194,8 +200,13 @@ __global__ __launch_bounds__(ENERGY_THREADS) void energy_list_kernel(const gort_
     const long n_lines = uniq[0];
     for (long u = blockIdx.x; u < n_lines; u += gridDim.x) {
         __syncthreads();                                     // the shared arrays of the previous line are done with
-        energy_line_call(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
-                         (long)uniq[1 + u], sh);
+        // A loop around the inlined body lets the compiler hoist the body's loop-invariant loads (canopy, nodes) in front
+        // of the loop: 256 VGPRs + spills in round 3, which then put the body behind a call (162 VGPRs, one workgroup
+        // per CU where the per-line kernel has two).  Memory the compiler must assume changed keeps the loads where
+        // they are used.
+        asm volatile("" ::: "memory");
+        energy_line<SHARE_ROWS>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes,
+                                energy_all + member * nA * nw * 3, (long)uniq[1 + u], sh);
     }
 }
 
@@ -212,8 +223,14 @@ __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row,
                                                                 int K, unsigned W, long dq, int dr, int xcd_static,
                                                                 XcdDuty duty, long useful_blocks)
 {
-    double *__restrict__ energy = energy_all + (long)blockIdx.y * nA * row;
+    // member y's slab starts y nA row doubles further on: its own offset against the 1-KiB chunk grid (else an odd nA row
+    // would leave every other member's 16-byte stores on 8-byte boundaries and its chunks off the grid they are cut for)
     const long n_total = nA * (long)row;
+    double *__restrict__ energy = energy_all + (long)blockIdx.y * n_total;
+    if (blockIdx.y) {
+        shift = (int)((shift + (long)blockIdx.y * (n_total % CHUNK)) % CHUNK);
+        chunks = (n_total + shift + CHUNK - 1) / CHUNK;
+    }
     const int lane = threadIdx.x & 63;
     const long block = xcd_static ? duty_logical_block((long)blockIdx.x, duty, useful_blocks)
                                   : ((long)blockIdx.x < useful_blocks ? (long)blockIdx.x : -1);
@@ -297,10 +314,16 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     if (nA <= 0 || nw <= 0 || n_members <= 0) return GORT_OK;
     if (n_members > 65535) return fail(GORT_EINVAL, "energy: %d members in one launch (max 65535)", n_members);
     hipStream_t s = (hipStream_t)stream;
+    const char *sr = getenv("GORT_ENERGY_SHARE_ROWS");       // read per call: the test switches it inside one process
+    const bool share_rows = !(sr && atoi(sr) == 0);
     if (!ws_dev || nA < ENERGY_DEDUP_MIN_LINES) {
         if (nA >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld lines in one launch", nA);
-        hipLaunchKernelGGL(energy_kernel, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
-                           canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
+        if (share_rows)
+            hipLaunchKernelGGL(energy_kernel<true>, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
+                               canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
+        else
+            hipLaunchKernelGGL(energy_kernel<false>, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
+                               canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
         return check_launch("energy_kernel");
     }
     if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
@@ -323,20 +346,22 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     if ((rc = check_launch("energy_rep_kernel"))) return rc;
     const unsigned *rep = slot_of;
     const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
-    hipLaunchKernelGGL(energy_list_kernel, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
-                       angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
+    if (share_rows)
+        hipLaunchKernelGGL(energy_list_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
+                           angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
+    else
+        hipLaunchKernelGGL(energy_list_kernel<false>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
+                           angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
     if ((rc = check_launch("energy_list_kernel"))) return rc;
     const int row = 3 * nw;
     const int shift = (int)((reinterpret_cast<uintptr_t>(energy_dev) / sizeof(double)) % CHUNK);
-    // member m's slab starts nA*row doubles further: the same shift only if that is a multiple of CHUNK; the kernel's
-    // alignment is a matter of speed, not of correctness, and the member-batched call is the small one
-    const long chunks = (nA * (long)row + shift + CHUNK - 1) / CHUNK;
+    const long chunks = (nA * (long)row + shift + CHUNK - 1) / CHUNK;         // member 0; the others derive theirs (one more at most)
     // panels of 16 steps x 2048 waves (32 MB), XCD-contiguous where the dispatch is round-robin.  1M lines x 2101 bands, 91
     // sun directions (profiles/r03/energy_broadcast_sweep.log): the whole call 11.15 ms with the grid-stride loop of round 3's
     // first version, 10.8 / 9.7 / 9.5 / 9.4 / 9.26 / 9.4 ms for 4 / 6 / 8 / 12 / 16 / 32 steps, the same for 1024 ... 8192 waves
     const int K = 16;
     const unsigned W = 2048;
-    const long panels = (chunks + (long)K * W - 1) / ((long)K * W);
+    const long panels = (chunks + (n_members > 1 ? 1 : 0) + (long)K * W - 1) / ((long)K * W);
     const long useful = (panels * W + 3) / 4;
     XcdDuty duty;
     const long nblocks = plan_xcd_duty(xcd_round_robin ? 1 : 0, useful, nullptr, duty);

@@ -202,6 +202,7 @@ __device__ void geometry_core(const gort_canopy &c, double vza, double sza, doub
 
 __device__ inline void store_coef(double *rec, const gort_canopy &c, const GeomOut &g)
 {
+#pragma clang fp contract(off)
     const double fd = g.sun.fd, kep = c.k_openep;
     rec[C_FDA] = fd * g.A;
     rec[C_KPZ] = fd * kep * g.Kpz;

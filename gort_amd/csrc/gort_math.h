@@ -11,6 +11,10 @@
 // host too, with the three hardware primitives spelled in C); outside that range they either fall back to the device
 // library (sincos) or produce the IEEE special value (exp, log, quot), so that NaN / inf patterns are those of libm.
 //
+// Every function pins its own arithmetic (#pragma clang fp contract(off); the fused operations are the ones written as
+// fma_): what a function returns must not depend on what the compiler finds to contract in the kernel it is inlined into -
+// kernels that must write the same bits (tests/test_stream_forms.py, test_energy_forms.py) inline them in different places.
+//
 // Reference call sites these serve: gortt_brdf.c:23-100 (overlap: sqrt, acos, sin), :118-238 (Kc: exp, acos, cos, tan),
 // :638-702 (hot spot: log, exp, sqrt), gortt.c:581-588 (primed angles: atan, tan, cos).
 #ifndef GORT_MATH_H
@@ -92,6 +96,7 @@ GM_FN double fma_c(double a, double b, double c)
 // 1 / b to ~1 ulp: estimate + one third-order step (e = 1 - b r; r (1 + e + e^2)), as stream_reciprocal()
 GM_FN double recip(double b)
 {
+#pragma clang fp contract(off)
     const double r = hw_rcp(b);
     const double e = fma_(-b, r, 1.0);
     return fma_(r, fma_(e, e, e), r);
@@ -100,6 +105,7 @@ GM_FN double recip(double b)
 // a / b within one ulp (reciprocal, product, one residual correction); zero / infinite / NaN operands as IEEE
 GM_FN double quot(double a, double b)
 {
+#pragma clang fp contract(off)
     const double r = recip(b);
     const double q = a * r;
     const double q1 = fma_(fma_(-b, q, a), r, q);
@@ -113,6 +119,7 @@ GM_FN double quot(double a, double b)
 // a / b for finite b != 0 (no special-case pass: a zero or infinite b gives NaN where IEEE gives inf or 0)
 GM_FN double quot_finite(double a, double b)
 {
+#pragma clang fp contract(off)
     const double r = recip(b);
     const double q = a * r;
     return fma_(fma_(-b, q, a), r, q);
@@ -124,6 +131,7 @@ GM_FN double quot_finite(double a, double b)
 // 90 degrees sits on the last node of the gap tables, gortt.c:872-915).
 GM_FN double div_by_constant(double a, double C, double Y)
 {
+#pragma clang fp contract(off)
     double q = a * Y;
     q = fma_(fma_(-C, q, a), Y, q);
     return fma_(fma_(-C, q, a), Y, q);
@@ -133,6 +141,7 @@ GM_FN double div_by_constant(double a, double C, double Y)
 // and one residual correction of g; no input scaling (nothing here is below 2^-700 without being 0)
 GM_FN void root_steps(double w, double &g, double &h)
 {
+#pragma clang fp contract(off)
     const double y = hw_rsq(w);
     g = w * y;
     h = 0.5 * y;
@@ -146,6 +155,7 @@ GM_FN void root_steps(double w, double &g, double &h)
 // sqrt(w): 0 -> 0, inf -> inf, negative -> NaN, NaN -> NaN
 GM_FN double sqrt_(double w)
 {
+#pragma clang fp contract(off)
     double g, h;
     root_steps(w, g, h);
     g = fma_(fma_(-g, g, w), h, g);
@@ -154,6 +164,7 @@ GM_FN double sqrt_(double w)
 // sqrt(w) and 1 / sqrt(w) for finite w > 0 (the secant and cosine of a primed zenith from 1 + tan^2)
 GM_FN void root_and_inverse(double w, double &root, double &inv)
 {
+#pragma clang fp contract(off)
     double g, h;
     root_steps(w, g, h);
     root = fma_(fma_(-g, g, w), h, g);
@@ -171,6 +182,7 @@ constexpr double SINCOS_MAX = 262144.0;
 
 GM_FN double sin_kernel(double r, double z)
 {
+#pragma clang fp contract(off)
     double p = fma_c(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
     p = fma_c(z, p, 2.75573137070700676789e-06);
     p = fma_c(z, p, -1.98412698298579493134e-04);
@@ -180,6 +192,7 @@ GM_FN double sin_kernel(double r, double z)
 }
 GM_FN double cos_kernel(double z)
 {
+#pragma clang fp contract(off)
     double p = fma_c(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
     p = fma_c(z, p, -2.75573143513906633035e-07);
     p = fma_c(z, p, 2.48015872894767294178e-05);
@@ -191,12 +204,14 @@ GM_FN double cos_kernel(double z)
 // the reduced argument and the quadrant
 GM_FN double reduce_pio2(double x, int &n)
 {
+#pragma clang fp contract(off)
     const double k = __builtin_rint(x * TWO_OVER_PI);
     n = (int)k;
     return fma_(-k, PIO2_LO, fma_(-k, PIO2_HI, x));
 }
 GM_FN void sincos_reduced(double x, double &s, double &c)
 {
+#pragma clang fp contract(off)
     int n;
     const double r = reduce_pio2(x, n), z = r * r;
     const double sk = sin_kernel(r, z), ck = cos_kernel(z);
@@ -206,6 +221,7 @@ GM_FN void sincos_reduced(double x, double &s, double &c)
 }
 GM_FN double cos_reduced(double x)
 {
+#pragma clang fp contract(off)
     int n;
     const double r = reduce_pio2(x, n), z = r * r;
     const double v = (n & 1) ? sin_kernel(r, z) : cos_kernel(z);
@@ -217,6 +233,7 @@ GM_FN double cos_reduced(double x)
 // geometry's exponents are optical depths and Kuusk's bounded hot-spot term): -inf -> 0, NaN -> NaN.
 GM_FN double exp_(double x)
 {
+#pragma clang fp contract(off)
     const double k = __builtin_rint(x * 1.44269504088896338700e+00);
     const double r = fma_(-k, 2.31904681384629955842e-17, fma_(-k, 6.93147180559945286227e-01, x));
     double p = fma_c(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
@@ -243,6 +260,7 @@ GM_FN double exp_(double x)
 // (the gap probabilities at the horizon are ~1e-65, at worst 0).
 GM_FN double log_(double x)
 {
+#pragma clang fp contract(off)
     int e;
     double m = hw_frexp(x, e);                      // [0.5, 1)
     const bool low = m < 7.07106781186547524401e-01;
@@ -281,6 +299,7 @@ static const AtanRange ATAN_RANGES[5] = {
 };
 GM_FN double atan_(double x)
 {
+#pragma clang fp contract(off)
     const double ax = __builtin_fabs(x);
     const int id = (ax >= 0.4375) + (ax >= 0.6875) + (ax >= 1.1875) + (ax >= 2.4375);
     const AtanRange g = ATAN_RANGES[id];
@@ -303,6 +322,7 @@ GM_FN double atan_(double x)
 // otherwise through sqrt((1 -+ x) / 2).
 GM_FN double acos_rational(double z)
 {
+#pragma clang fp contract(off)
     double p = fma_c(z, 3.47933107596021167570e-05, 7.91534994289814532176e-04);
     p = fma_c(z, p, -4.00555345006794114027e-02);
     p = fma_c(z, p, 2.01212532134862925881e-01);
@@ -319,6 +339,7 @@ GM_FN double acos_rational(double z)
 // fdlibm's 2 (s + (R s + c)) wants; x = 1 -> 0.
 GM_FN double acos_unit(double x)
 {
+#pragma clang fp contract(off)
     const bool mid = x < 0.5;
     const double z = mid ? x * x : 0.5 * (1.0 - x);
     const double R = acos_rational(z);
@@ -332,6 +353,7 @@ GM_FN double acos_unit(double x)
 }
 GM_FN double acos_(double x)
 {
+#pragma clang fp contract(off)
     const double ax = __builtin_fabs(x);
     const bool mid = ax < 0.5;
     // one evaluation of R and one root serve all three ranges

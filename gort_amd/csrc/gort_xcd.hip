@@ -114,6 +114,7 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
         if (err == hipSuccess) {
             hipLaunchKernelGGL(xcd_pattern_kernel, dim3((unsigned)grid), dim3(256), 0, s, slab + skip, chunks, K, W, duty,
                                useful, dev, dev + 8);
+            if ((rc = check_launch("xcd_pattern_kernel"))) break;      // a failed launch must not be left for an unrelated check to find
             err = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
         }
         if (err == hipSuccess) err = hipStreamSynchronize(s);
@@ -133,9 +134,9 @@ int calibrate_xcd_weights(void *stream, double *slab, long n_doubles, int weight
             // the rate of the bare store pattern with equal shares, first start to last end (wall clock ticks)
             unsigned long long t1 = 0;
             for (int x = 0; x < 8; ++x) if (host[8 + x] > t1) t1 = host[8 + x];
-            int khz = 0, dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0 && t1 > t0)
+            int khz = 0, device = 0;
+            (void)hipGetDevice(&device);
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0 && t1 > t0)
                 *pattern_gbs = (double)chunks * 1024.0 / ((double)(t1 - t0) / khz * 1e-3) / 1e9;
         }
         for (int x = 0; x < 8; ++x) {
@@ -183,6 +184,10 @@ int probe_xcd_dispatch(void *stream, int *round_robin)
     int host[NB];
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(xcd_probe_kernel, dim3(NB), dim3(256), 0, s, dev);
+    if (const int rc = check_launch("xcd_probe_kernel")) {
+        (void)hipFree(dev);
+        return rc;
+    }
     hipError_t err = hipMemcpyAsync(host, dev, sizeof(host), hipMemcpyDeviceToHost, s);
     if (err == hipSuccess) err = hipStreamSynchronize(s);
     (void)hipFree(dev);

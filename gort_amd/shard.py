@@ -77,3 +77,25 @@ def all_gather_lut(slab, rows_total, group=None):
     full = empty_gatherable(rows_total, slab.shape[1], world, slab.dtype, slab.device)
     full[r0:r1] = slab
     return all_gather_in_place(full, rows_total, group)
+
+
+def rccl_comm_for_group(group=None):
+    """An RCCL communicator of the C ABI (gort_rccl_comm_init_rank) for the ranks of a torch.distributed group: rank 0
+    draws the unique id, the group - any backend - carries its 128 bytes to the others.  The calling rank's GPU must be
+    the current device.  What a C host does with MPI_Bcast."""
+    from . import api
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [api.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return api.RcclComm(world, box[0], rank)
+
+
+def all_gather_in_place_c_abi(engine, buf, rows_total, row_elems, comm):
+    """The same exchange as all_gather_in_place, through the C ABI (gort_lut_allgather -> ncclAllGather of librccl on the
+    engine's stream): buf = the api.LutBuffer of gatherable_rows(world, rows_total) x row_elems doubles every rank
+    allocated with gort_lut_alloc and filled its window of."""
+    per = slab_rows(comm.world, rows_total)
+    if buf.nbytes != comm.world * per * row_elems * 8:
+        raise ValueError("buffer of %d bytes, expected %d x %d x %d doubles" % (buf.nbytes, comm.world, per, row_elems))
+    engine.lut_allgather(buf, per, row_elems, comm)
+    engine.synchronize()

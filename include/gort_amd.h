@@ -174,10 +174,29 @@ typedef struct gort_lut_placement {
     double accept_gbs;                           /* early-stop rate used for this call (0 = no history yet) */
     int32_t shifted;                             /* 1: candidates were placements inside ONE allocation (1-GiB steps) */
     int32_t rescans;                             /* scans repeated on a new allocation because the first found no plateau (0..2) */
+    uint64_t slack_bytes;                        /* bytes allocated beyond `bytes` that stay allocated with the buffer (the room the
+                                                  * scan moved it through; capped by GORT_LUT_SLACK_GIB, default 48) */
 } gort_lut_placement;
 int   gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, size_t win_bytes, int max_draws,
                      void **lut_dev, gort_lut_placement *info);
 void  gort_lut_free(void *lut_dev);
+
+/* ---- multi-GPU: the one exchange step of the path (an RCCL all-gather over xGMI reassembles the LUT) ----
+ * One process per GPU (or one process driving several devices): every rank allocates the GATHERABLE LUT - world x
+ * rows_per_rank rows, rows_per_rank = ceil(rows / world) - with gort_lut_alloc(window = its own rows), computes into its
+ * window with gort_rsurf_grid_dev, and ONE in-place ncclAllGather fills the other windows: no receive buffer, no copy.
+ * gort_lut_allgather enqueues it on the engine's stream behind the kernels (asynchronous; gort_engine_synchronize waits).
+ * The communicator is RCCL's (ncclComm_t as void*): the caller's own, or one made here - rank 0 draws a unique id, the
+ * host's bootstrap (MPI, a socket, torch.distributed: 128 opaque bytes) hands it to the other ranks, each calls
+ * gort_rccl_comm_init_rank with its device current; gort_rccl_comm_init_all serves one process with n devices.  librccl
+ * is bound at run time (the copy already in the process, if any).  The reference has no counterpart: it is one process
+ * (README.md:30-36); this is new surface. */
+#define GORT_RCCL_ID_BYTES 128
+int   gort_rccl_unique_id(unsigned char *id /* [GORT_RCCL_ID_BYTES] */);
+int   gort_rccl_comm_init_rank(int world, const unsigned char *id, int rank, void **comm);
+int   gort_rccl_comm_init_all(int n_devices, const int *devices /* NULL = 0..n-1 */, void **comms /* [n_devices] */);
+int   gort_rccl_comm_destroy(void *comm);
+int   gort_lut_allgather(gort_engine *e, void *lut_dev, size_t rows_per_rank, size_t row_bytes, int rank, int world, void *comm);
 
 /* Pinned (page-locked) host memory: buffers from here travel over PCIe by DMA at the link rate, and
  * gort_rsurf_stream / gort_energy_stream copy straight into them; results written into ordinary pageable memory
@@ -227,6 +246,10 @@ int  gort_engine_set_members(gort_engine *e, const gort_canopy *members, int n_m
                              int nw, const double *spectra);
 int  gort_engine_set_members_leaf(gort_engine *e, const gort_canopy *members, const gort_leaf_soil *leaf,
                                   int n_members, int compute_gaps, const double *wl_nm, int nw);
+/* Capacity for n_members x nw bands: device buffers, pinned staging and spectral tables are allocated now, so that the
+ * member setters cost their copies and kernels only (an ensemble filter re-submits its members every cycle; the first
+ * call of a process otherwise pays ~240 MB of allocation).  New surface; optional. */
+int  gort_engine_reserve_members(gort_engine *e, int n_members, int nw);
 int  gort_engine_get_member(gort_engine *e, int member, gort_canopy *canopy, double *rsoil, double *rleaf,
                             double *tleaf);
 

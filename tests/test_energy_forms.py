@@ -1,0 +1,130 @@
+"""The forms of the `-energy` path (gort_amd/csrc/gort_energy.hip) must write the SAME BITS:
+
+* the row terms of the 16 zenith nodes evaluated once per line into LDS (round 4) against every quadrature node
+  evaluating its whole geometry (round 3's kernel, GORT_ENERGY_SHARE_ROWS=0);
+* rows shared between lines of equal sun direction and broadcast by energy_broadcast_kernel - both of its forms, the
+  two-rows-per-chunk form every stream of >= 43 bands takes included, member-batched launches included - against the
+  evaluation of every line (GORT_ENERGY_DEDUP=0).
+
+Reference: gortt_energy / gortt_albedo, gortt_albedo.c:7-138 (512 gortt_rsurf calls per line and band)."""
+import os
+
+import numpy as np
+import pytest
+
+from gort_amd import api
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(wl, dedup="1", lai=4.0):
+    os.environ["GORT_ENERGY_DEDUP"] = dedup               # read when the engine is created
+    try:
+        e = api.Engine()
+    finally:
+        os.environ.pop("GORT_ENERGY_DEDUP")
+    e.set_canopy(api.gap_probabilities(api.make_canopy(lai=lai)))
+    e.set_spectra(*api.spectra(wl))
+    return e
+
+
+def _energy(e, ang, nw, torch, offset=0):
+    """energy[nA][nw][3] into a buffer that starts `offset` doubles behind a 1-KiB boundary, sentinels around it."""
+    n = ang.shape[0]
+    buf = torch.full((n * nw * 3 + 256,), -7.0, dtype=torch.float64, device="cuda")
+    base = (-(buf.data_ptr() // 8)) % 128 + offset          # doubles to the next 1-KiB boundary, then `offset` more
+    out = buf[base:base + n * nw * 3].view(n, nw, 3)
+    a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
+    torch.cuda.synchronize()
+    e.energy_stream_dev(a, out)
+    e.synchronize()
+    assert float(buf[:base].min() if base else -7.0) == -7.0 and float(buf[base + n * nw * 3:].max()) == -7.0
+    return out.cpu().numpy()
+
+
+def _bits(x):
+    return np.ascontiguousarray(x).view(np.int64)
+
+
+def test_row_terms_once_per_zenith_node_same_bits():
+    """BASELINE config 4's 91 sun zeniths (the per-line kernel) and a 3000-line stream in which every line has its own sun
+    direction (the list kernel behind the sun-direction table), a sun on the horizon and a NaN line among them."""
+    import torch
+    wl = np.linspace(400.0, 2500.0, 61)
+    rng = np.random.default_rng(16)
+    c4 = np.array([[0.0, 0.0, float(s), 0.0] for s in range(91)])
+    stream = np.stack([rng.uniform(-89, 89, 3000), rng.uniform(-400, 400, 3000), rng.uniform(0, 89.9, 3000), rng.uniform(-400, 400, 3000)], 1)
+    stream[5, 2] = 90.0
+    stream[9, 2] = np.nan
+    stream[11, 2] = -33.25
+    res = {}
+    for share in ("1", "0"):
+        os.environ["GORT_ENERGY_SHARE_ROWS"] = share
+        try:
+            e = _engine(wl)
+            res[share] = (_energy(e, c4, wl.size, torch), _energy(e, stream, wl.size, torch, offset=3))
+            e.close()
+        finally:
+            os.environ.pop("GORT_ENERGY_SHARE_ROWS")
+    for k in (0, 1):
+        a, b = res["1"][k], res["0"][k]
+        bad = np.flatnonzero((_bits(a) != _bits(b)).any(axis=(1, 2)) & ~(np.isnan(a).all(axis=(1, 2)) & np.isnan(b).all(axis=(1, 2))))
+        assert bad.size == 0, (k, bad[:10], (c4 if k == 0 else stream)[bad[:3]], a[bad[:1], :2], b[bad[:1], :2])
+    assert np.isnan(res["1"][1][9]).all() and np.isfinite(res["1"][1][:5]).all()
+    assert np.abs(res["1"][0][:90].sum(axis=2) - 1.0).max() < 1e-12        # albedo + favegt + fasoil = 1
+
+
+@pytest.mark.parametrize("nw,n", [(43, 4001), (128, 1501), (2101, 333), (7, 5001)])
+def test_broadcast_of_shared_rows_same_bits(nw, n):
+    """Rows of 3 nw doubles copied from the line that owns their sun direction: 43 bands are the first to take the form
+    with two rows per 1-KiB chunk (incremental row / offset carry, chunks that straddle rows, front and back edges), 128
+    and 2101 bands its long rows, 7 bands the per-element form.  Odd nA x row, an output that starts off the chunk grid,
+    sentinels on both sides."""
+    import torch
+    wl = np.linspace(400.0, 2500.0, nw)
+    rng = np.random.default_rng(nw)
+    sza = rng.integers(0, 12, n).astype(float) * 7.0
+    saa = rng.choice(np.array([0.0, 77.5, 180.0]), n)
+    flip = rng.random(n) < 0.2                                              # -sza, saa + 180: the same sun after normalisation
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), np.where(flip, -sza, sza), np.where(flip, saa + 180.0, saa)], 1)
+    ang[-1, 2] = 41.0                                                       # the last line owns its direction: nothing copied into the back edge
+    assert nw % 2 == 0 or (n * nw * 3) % 2 == 1
+    res = {}
+    for dedup in ("1", "0"):
+        e = _engine(wl, dedup)
+        res[dedup] = [_energy(e, ang, nw, torch, offset=off) for off in (0, 5)]
+        e.close()
+    for k in (0, 1):
+        assert not (res["1"][k] == -7.0).any()
+        assert np.array_equal(_bits(res["1"][k]), _bits(res["0"][k])), (nw, k)
+
+
+def test_member_batched_broadcast_same_bits():
+    """gort_energy_members_dev: the lines' rows are shared per member (blockIdx.y); with an odd nA x row every second
+    member's slab starts on an 8-byte boundary of its own."""
+    import torch
+    from gort_amd.ensemble import DEFAULT, Ensemble
+    rng = np.random.default_rng(5)
+    wl = np.linspace(400.0, 2500.0, 45)
+    n = 257
+    ang = np.stack([rng.uniform(-80, 80, n), rng.uniform(0, 360, n), rng.integers(0, 9, n).astype(float) * 10.0, rng.choice([0.0, 120.0], n)], 1)
+    states = [dict(DEFAULT, LAI=float(x), Cab=float(y)) for x, y in zip(rng.uniform(0.5, 6, 3), rng.uniform(10, 60, 3))]
+    res = {}
+    for dedup in ("1", "0"):
+        os.environ["GORT_ENERGY_DEDUP"] = dedup
+        try:
+            ens = Ensemble(wl).set_states(states)
+        finally:
+            os.environ.pop("GORT_ENERGY_DEDUP")
+        buf = torch.full((3 * n * wl.size * 3 + 64,), -7.0, dtype=torch.float64, device="cuda")
+        out = buf[1:1 + 3 * n * wl.size * 3].view(3, n, wl.size, 3)
+        a = torch.as_tensor(ang, device="cuda")
+        torch.cuda.synchronize()
+        ens.eng.energy_members_dev(a, 0, 3, out)
+        ens.eng.synchronize()
+        assert float(buf[0]) == -7.0 and float(buf[1 + 3 * n * wl.size * 3:].max()) == -7.0
+        res[dedup] = out.cpu().numpy()
+        ens.close()
+    assert (n * wl.size * 3) % 2 == 1
+    assert not (res["1"] == -7.0).any()
+    assert np.array_equal(_bits(res["1"]), _bits(res["0"]))

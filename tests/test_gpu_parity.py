@@ -1096,6 +1096,31 @@ def test_bench_two_ranks_rehearsal():
     for k in ("own_member", "foreign_member"):
         assert c5["parity"][k]["nan_pattern_equal"] and c5["parity"][k]["max_rel_err"] <= 1e-9
     assert "cpu_baseline" not in d and "reference_build" in d
+    # round 4: what every rank holds in HBM, what the placement slack buys, and no error list on a clean run
+    for r in pr:
+        assert r["hbm"]["lut_buffer_gb"] > 0 and r["hbm"]["device_used_gb_with_lut"] >= r["hbm"]["lut_buffer_gb"] and "placement_slack_gb" in r["hbm"]
+        assert "slack_bytes" in r["lut_alloc"]
+    assert set(d["slack_sweep"]) == {"0", "16", "48"} and d["slack_sweep"]["0"]["value"] > 0 and "errors" not in d
+
+
+def test_bench_prints_its_line_when_the_allgather_throws():
+    """The one multi-GPU run the driver gets must not end without a JSON line: a collective behind the timed region that
+    raises (here: injected into the LUT all-gather) is recorded, later collectives are skipped, rank 0 prints the line
+    with the timed result in it, and the run exits non-zero."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29549", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--nsza", "3", "--rehearse", "--sustain-s", "0",
+                          "--c5-members", "12", "--c5-chunk", "3", "--no-cpu-baseline", "--inject-gather-error"],
+                         capture_output=True, timeout=900)
+    assert run.returncode != 0
+    lines = [l for l in run.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stderr.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 1e8 and d["ms_per_step"] > 0 and d["roofline"]["frac"] > 0
+    assert d["errors"] and d["errors"][0]["where"] == "all-gather of the LUT" and "injected" in d["errors"][0]["error"]
+    assert "error" in d["allgather"] and d["parity"]["max_rel_err"] <= 1e-9
+    assert "error" in d["config5"]                          # skipped: the process group is not trusted after a failure
 
 
 def test_bench_json_contract():
@@ -1469,7 +1494,7 @@ os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", RANK="0", WORLD_
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))        # RCCL, the calls bench.py makes at N > 1
 from gort_amd import api
-from gort_amd.shard import all_gather_in_place, all_gather_lut, gatherable_rows, row_slab
+from gort_amd.shard import all_gather_in_place, all_gather_in_place_c_abi, all_gather_lut, gatherable_rows, rccl_comm_for_group, row_slab
 wl = np.linspace(400.0, 2500.0, 140)
 e = api.Engine(); e.set_canopy(api.gap_probabilities(api.make_canopy(lai=3.0))); e.set_spectra(*api.spectra(wl))
 g = api.hemisphere_grid(6, 8, 361)
@@ -1491,6 +1516,21 @@ objs = [None]
 dist.all_gather_object(objs, {"rank": 0, "placement": buf.placement})
 assert objs[0]["placement"]["draws"] >= 1
 assert float(t.item()) == 1.25 and np.array_equal(full.cpu().numpy().view(np.int64).ravel(), before)
+# the same exchange through the C ABI: gort_rccl_unique_id -> (bootstrap over the group) -> gort_rccl_comm_init_rank ->
+# gort_lut_allgather = ncclAllGather of librccl on the engine's stream, in place; then one process with its devices
+comm = rccl_comm_for_group()
+assert comm.world == 1 and comm.rank == 0
+all_gather_in_place_c_abi(e, buf, rows, row_elems, comm)
+assert np.array_equal(buf.to_numpy().view(np.int64), before)
+comm.destroy()
+import ctypes as C
+h = C.c_void_p()
+assert api.lib().gort_rccl_comm_init_all(1, None, C.byref(h)) == 0 and h.value
+assert api.lib().gort_lut_allgather(e.h, C.c_void_p(buf.ptr), rows, row_elems * 8, 0, 1, h) == 0
+e.synchronize()
+assert np.array_equal(buf.to_numpy().view(np.int64), before)
+assert api.lib().gort_rccl_comm_destroy(h) == 0
+assert api.lib().gort_lut_allgather(e.h, C.c_void_p(buf.ptr), rows, row_elems * 8, 1, 1, None) != 0     # bad rank / no communicator: refused
 lut = full.clone()
 again = all_gather_lut(lut, rows)                           # the convenience form (own buffer, copy, gather)
 assert torch.equal(again.view(torch.int64), lut.view(torch.int64))
@@ -1503,8 +1543,9 @@ print("rccl ok")
 
 def test_rccl_calls_of_the_multi_gpu_path_on_one_rank():
     """The RCCL side of bench.py (nccl process group bound to the device, barrier, MAX all-reduce of a device
-    scalar, all_gather_object, in-place all_gather_into_tensor on a tensor view of a gort_lut_alloc buffer) executed for
-    real - with the one rank a 1-GPU box allows."""
+    scalar, all_gather_object, in-place all_gather_into_tensor on a tensor view of a gort_lut_alloc buffer) and the C ABI's
+    own collective (gort_rccl_unique_id / _comm_init_rank / _comm_init_all, gort_lut_allgather: librccl's ncclAllGather on
+    the engine's stream) executed for real - with the one rank a 1-GPU box allows."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run(["python3", "-c", _RCCL_SCRIPT % root], capture_output=True, timeout=300)
     assert run.returncode == 0, run.stderr.decode()[-3000:]
