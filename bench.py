@@ -204,7 +204,7 @@ def measure_traffic(args, timeout_s=150):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
-             "--sustain-s", "0", "--no-config5", "--lut-draws", "1", "--no-traffic", "--nsza", str(args.nsza), "--nw", str(args.nw)]
+             "--sustain-s", "0", "--no-config5", "--no-configs", "--lut-draws", "1", "--no-traffic", "--nsza", str(args.nsza), "--nw", str(args.nw)]
     kb = {}
     for counter in ("WRITE_SIZE", "FETCH_SIZE"):
         d = tempfile.mkdtemp(prefix="gort_pmc_", dir="/tmp")
@@ -246,6 +246,80 @@ def compare(got, ref, what):
     return {"max_rel_err": float(np.max(np.abs(got[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1e-12))) if m.any() else 0.0,
             "nan_pattern_equal": bool(np.array_equal(np.isnan(got), np.isnan(ref))), "samples_checked": int(ref.size),
             "tolerance": 1e-5, "rows": what}
+
+
+def configs_block():
+    """The other BASELINE configs and the two stream shapes a user of the reference's CLI has, timed in this run (< 1 s):
+    device-resident inputs and outputs, best of 5 wall-clock times around a stream synchronisation after 0.15 s of the same
+    call (clocks up).  Each with what bounds it and the achieved fraction of that bound: HBM bytes at 8 B per sample + 32 B
+    per line over 8 TB/s, or fp64 VALU issue - the kernels' vector instructions per wave from the committed SQ counter
+    passes (profiles/r04/valu_counts.json) x 4 cycles x waves over 1024 SIMDs x 2.4 GHz x time."""
+    import torch
+    from gort_amd import api
+    counts = {}
+    try:
+        counts = json.load(open(os.path.join(ROOT, "profiles", "r04", "valu_counts.json")))
+    except Exception:                                   # noqa: BLE001
+        pass
+
+    def best(fn, eng, reps=5):
+        t_up = time.perf_counter()
+        while time.perf_counter() - t_up < 0.15:
+            fn(); eng.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); eng.synchronize(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    def valu_frac(key, waves, t):
+        per_wave = counts.get(key)
+        return None if not per_wave else per_wave * waves * 4.0 / (1024 * 2.4e9 * t)
+
+    eng = api.Engine()
+    eng.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
+    out = {}
+    # C2: principal plane, 181 view zeniths x 1 band (one fused launch)
+    eng.set_spectra(*api.spectra([800.0]))
+    ang = torch.tensor([[float(v), 0.0, 30.0, 0.0] for v in range(-90, 91)], dtype=torch.float64, device="cuda")
+    o = torch.empty((181, 1), dtype=torch.float64, device="cuda")
+    t = best(lambda: eng.rsurf_stream_dev(ang, o), eng)
+    out["C2"] = {"workload": "181 view zeniths x 1 band, stream entry point", "us": t * 1e6, "samples_per_s": 181 / t,
+                 "bound": "latency", "note": "one launch of three waves: launch + one serial chain of the geometry"}
+    # C3: hemisphere x 1 band through the LUT entry point (geometry fused with the samples)
+    g = api.hemisphere_grid(); rows = g.nsza * g.nvza
+    lut = torch.empty((rows * g.nphi, 1), dtype=torch.float64, device="cuda")
+    t = best(lambda: eng.rsurf_grid_dev(g, 0, rows, lut), eng)
+    wg = (rows + 5) // 6
+    out["C3"] = {"workload": "91x91x361 angles x 1 band, LUT entry point", "us": t * 1e6, "samples_per_s": rows * g.nphi / t,
+                 "bound": "fp64_valu", "frac": valu_frac("geometry_grid_kernel<6>@c3", 2 * wg, t),
+                 "hbm_frac": rows * g.nphi * 8 / t / 8e12}
+    del lut
+    # C4: albedo / fAPAR table, 91 sun zeniths x 2101 bands
+    wl = np.arange(400.0, 2501.0)
+    eng.set_spectra(*api.spectra(wl))
+    sza = torch.tensor([[0.0, 0.0, float(s), 0.0] for s in range(91)], dtype=torch.float64, device="cuda")
+    en = torch.empty((91, wl.size, 3), dtype=torch.float64, device="cuda")
+    t = best(lambda: eng.energy_stream_dev(sza, en), eng)
+    out["C4"] = {"workload": "91 sun zeniths x 2101 bands x (albedo, fAPAR, soil absorption)", "us": t * 1e6,
+                 "brdf_evaluations_per_s": 91 * 512 * wl.size / t, "bound": "latency",
+                 "note": "91 workgroups on 256 CUs: one serial chain of row terms + node geometry + quadrature per workgroup",
+                 "frac_fp64_valu": valu_frac("energy_kernel<true>@c4", 8 * 91, t)}
+    # the streams a user of the reference's command line has: a million lines x 7 bands (MODIS-like) and x 100 bands
+    rng = np.random.default_rng(0)
+    n = 1000000
+    a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), rng.uniform(0, 360, n)], 1), device="cuda")
+    for nw, key, kernel in ((7, "stream_1M_x_7", "geometry_stream_kernel<true>@7"), (100, "stream_1M_x_100", "stream_lines_kernel@100")):
+        eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
+        o = torch.empty((n, nw), dtype=torch.float64, device="cuda")
+        t = best(lambda: eng.rsurf_stream_dev(a, o), eng)
+        byts = n * nw * 8 + n * 32
+        out[key] = {"workload": "1 000 000 random lines x %d bands, stream entry point (%s kernel)" % (nw, eng.stream_form()),
+                    "us": t * 1e6, "samples_per_s": n * nw / t, "bound": "fp64_valu", "frac": valu_frac(kernel, (n + 63) // 64, t),
+                    "hbm_frac": byts / t / 8e12}
+        del o
+    eng.close()
+    out["valu_counts"] = "profiles/r04/valu_counts.json (SQ_INSTS_VALU / SQ_WAVES per kernel, rocprofv3 --pmc)" if counts else None
+    return out
 
 
 def config5_block(args, rank, world, dist, barrier):
@@ -334,6 +408,7 @@ def main():
                     help="seconds a collective behind the timed region may take before it is recorded as failed; the JSON line is "
                          "printed all the same and the run exits non-zero")
     ap.add_argument("--inject-gather-error", action="store_true", help="test hook: the LUT all-gather raises")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (C2, C3, C4 and two stream shapes, < 1 s)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="N = 1: do not measure the kernel's HBM traffic with two rocprofv3 --pmc child passes (~30 s)")
     ap.add_argument("--traffic-gb", type=float, default=None,
@@ -637,6 +712,11 @@ def main():
         if rank == 0:
             out["config5"] = c5 if c5 is not None else {"error": errors[-1] if errors else "skipped: an earlier collective failed"}
 
+    if rank == 0 and world == 1 and not args.no_configs:
+        try:
+            out["configs"] = configs_block()
+        except Exception as ex:                           # noqa: BLE001
+            out["configs"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_traffic and args.traffic_gb is None:
         # HBM traffic of the dominant kernel from the PMC counters, in this very run (the LUT buffers are gone: the child
         # passes need the memory); a failure leaves `traffic` null and says why

@@ -596,8 +596,7 @@ class Engine:
                                            _ptr(scomp_t), _ptr(K_t)))
 
     def stream_form(self):
-        """'narrow' | 'flat': which kernel family expanded the last stream call; 'flat' = the flat-panel kernel or, for
-        17 ... 127 bands, the tile kernel (include/gort_amd_tuning.h)."""
+        """'narrow' | 'flat' | 'lines': which kernel family expanded the last stream call (include/gort_amd_tuning.h)."""
         m = lib().gort_engine_stream_form(self.h)
         if m < 0:
             _check(m)

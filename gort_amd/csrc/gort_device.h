@@ -134,14 +134,17 @@ struct FastMath {
 };
 // (The library's functions are CALLED from that route, not inlined: beside the kernels their code - huge-argument
 // reduction and all - costs every line 40 to 70 registers of allocation, i.e. a wave or two of occupancy per SIMD.)
+#ifndef GORT_LIB_CALL
+#define GORT_LIB_CALL __attribute__((noinline))
+#endif
 namespace lib {
-__device__ __attribute__((noinline)) double exp_call(double x) { return ::exp(x); }
-__device__ __attribute__((noinline)) double log_call(double x) { return ::log(x); }
-__device__ __attribute__((noinline)) double acos_call(double x) { return ::acos(x); }
-__device__ __attribute__((noinline)) double atan_call(double x) { return ::atan(x); }
-__device__ __attribute__((noinline)) double tan_call(double x) { return ::tan(x); }
-__device__ __attribute__((noinline)) double sin_call(double x) { return ::sin(x); }
-__device__ __attribute__((noinline)) double cos_call(double x) { return ::cos(x); }
+__device__ GORT_LIB_CALL double exp_call(double x) { return ::exp(x); }
+__device__ GORT_LIB_CALL double log_call(double x) { return ::log(x); }
+__device__ GORT_LIB_CALL double acos_call(double x) { return ::acos(x); }
+__device__ GORT_LIB_CALL double atan_call(double x) { return ::atan(x); }
+__device__ GORT_LIB_CALL double tan_call(double x) { return ::tan(x); }
+__device__ GORT_LIB_CALL double sin_call(double x) { return ::sin(x); }
+__device__ GORT_LIB_CALL double cos_call(double x) { return ::cos(x); }
 }  // namespace lib
 struct LibMath {
     static __device__ __forceinline__ double div(double a, double b) { return a / b; }

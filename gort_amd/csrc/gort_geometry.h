@@ -131,11 +131,15 @@ __device__ void row_terms_with(const gort_canopy &c, double vza, double sza, Row
 // (gortt_brdf.c:650-666): the reference's value follows the last bit of glibc's sin and cos, which the library's
 // reproduce (both are correctly rounded almost always) and a 1-ulp kernel does not - 24 reference hot-spot rows of
 // tests/golden/fuzz_canopies.npz moved by up to 5e-8 with it.  Two calls per line, ~80 instructions more than the kernels.
-__device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms &r)
+// reference_route_at_horizon = false: the caller's output is the reflectance alone, which is NaN at a zenith of 90 degrees by
+// either route (EPgap is 0 there and Kuusk's term 0 x inf, gortt_brdf.c:638-702; asserted for every node of the
+// hemisphere grid in tests/test_gpu_parity.py) - the LUT kernels, whose grids hold both horizons in every launch and whose
+// workgroups would otherwise wait for the few that walk the library's code.
+__device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms &r, bool reference_route_at_horizon = true)
 {
     sincos(vza, &r.sin_vz, &r.cos_vz);
     sincos(sza, &r.sin_sz, &r.cos_sz);
-    r.horizon = near_horizon(r.cos_vz, r.cos_sz) ? 1 : 0;
+    r.horizon = reference_route_at_horizon && near_horizon(r.cos_vz, r.cos_sz) ? 1 : 0;
     if (__builtin_expect(r.horizon, 0)) row_terms_with<LibMath>(c, vza, sza, r);
     else row_terms_with<FastMath>(c, vza, sza, r);
 }

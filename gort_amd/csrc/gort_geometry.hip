@@ -100,7 +100,7 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
         double vza, sza, saa, raa;
         normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
-        row_terms(canopies[member], vza, sza, s_row[threadIdx.x]);
+        row_terms(canopies[member], vza, sza, s_row[threadIdx.x], false);      // a LUT holds reflectances only: NaN at the horizon by either route
         s_member[threadIdx.x] = (int)member;
         s_vza_deg[threadIdx.x] = vza_deg;
         s_sza_deg[threadIdx.x] = sza_deg;

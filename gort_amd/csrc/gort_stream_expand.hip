@@ -2,7 +2,7 @@
 // sun/view geometry in any order, gortt.c:232-329) from the per-line records of the geometry kernel into
 // rsurf[line][band].  Every kernel here evaluates the stream family's sample (gort_device.h:
 // stream_sample), so all of them write the same bits; narrow spectra take the per-sample / band-major kernels,
-// wide ones the aligned flat-panel kernel.  (Round 3 built a second wide form - one persistent 1024-thread workgroup per
+// wide ones the aligned flat-panel kernel (and 17 ... 255 bands the fused kernel of gort_stream_lines.hip).  (Round 3 built a second wide form - one persistent 1024-thread workgroup per
 // CU with the band constants of all 2101 bands resident in the 160 KB of LDS, short row-major tasks, records staged
 // through an LDS ring - bitwise equal and 8 % SLOWER at a million lines; and a third, the flat kernel's waves made persistent
 // with the band constants of ONE segment of the spectrum in LDS, seven workgroups per CU - bitwise equal, 12-18 % slower:
@@ -244,61 +244,6 @@ __global__ __launch_bounds__(256) void expand_flat_stream_kernel(const StreamBan
     }
 }
 
-// ---- spectra of 17 ... 127 bands: lines in lanes, bands through the scalar cache, rows transposed in LDS ------------
-// With fewer than 128 bands a 1-KiB chunk spans several lines; a flat form whose lanes fetch their own line terms (six
-// 16-B loads per element and step) was built and is bound by the issue of those loads (1M lines x 32 / 64 / 127 bands:
-// 152 / 275 / 508 us, the narrow kernels 274 / 478 / 538; profiles/r03/stream_mid_bands.log).  Here a wave takes 64 consecutive LINES:
-// lane = line, its twelve terms loaded once; the bands come one after the other with their twelve constants wave-uniform
-// (scalar loads off the StreamBand table), so a sample costs its 28 issue slots and nothing else.  The samples of 16
-// bands go through a wave-private LDS tile [64 lines][16 bands] and leave as sixteen stores in which 16 lanes write the
-// 128 contiguous bytes of one line (a lane-per-line store would touch 64 cache lines per instruction).  Rows of a
-// multiple of 16 bands are whole cache lines and leave non-temporally (32 / 64 / 96 bands: 64 / 110 / 172 us); other
-// rows straddle lines whose halves are written a tile apart, which plain stores let the L2 merge (17 / 65 / 127 bands:
-// 57 / 249 / 483 us plain, 111 / 398 / 891 non-temporal).
-constexpr int TILE_BANDS = 16;
-constexpr int TILE_PITCH = TILE_BANDS + 1;                   // doubles per line of the tile: odd, so that lanes spread over the banks
-template <bool NT>
-__global__ __launch_bounds__(256) void expand_tile_stream_kernel(const StreamBand *__restrict__ bands, int nw,
-                                                                  const double *__restrict__ coef, long nA,
-                                                                  double *__restrict__ out)
-{
-    __shared__ double s_tile[4][64 * TILE_PITCH];
-    const int lane = threadIdx.x & 63;
-    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long a0 = ((long)blockIdx.x * 4 + wave_in_block) * 64;
-    if (a0 >= nA) return;
-    double *tile = s_tile[wave_in_block];
-    const long a = a0 + lane < nA ? a0 + lane : nA - 1;       // lanes behind the stream compute the last line again, store nothing
-    const dbl2 *p = reinterpret_cast<const dbl2 *>(coef + a * GORT_COEF_STRIDE);
-    dbl2 r[LINE_NTERMS / 2];
-#pragma unroll
-    for (int q = 0; q < LINE_NTERMS / 2; ++q) r[q] = p[q];
-    // the stores of a tile: lane -> (line 4 k + lane / 16, band lane % 16), k = 0 .. 15
-    const int sl = lane >> 4, sb = lane & 15;
-    const long lines_here = nA - a0 < 64 ? nA - a0 : 64;
-    for (int t0 = 0; t0 < nw; t0 += TILE_BANDS) {
-        const int nb = nw - t0 < TILE_BANDS ? nw - t0 : TILE_BANDS;
-#pragma unroll 2
-        for (int i = 0; i < nb; ++i) {
-            const StreamBand b = bands[t0 + i];                                   // wave-uniform: scalar loads
-            tile[lane * TILE_PITCH + i] = stream_sample(r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y, r[4].x,
-                                                        r[4].y, r[5].x, r[5].y, b);
-        }
-        if (sb < nb) {
-            double *o = out + (a0 + sl) * nw + t0 + sb;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int line = 4 * k + sl;
-                if (line < lines_here) {
-                    const double v = tile[line * TILE_PITCH + sb];
-                    if (NT) __builtin_nontemporal_store(v, o + (long)(4 * k) * nw);
-                    else o[(long)(4 * k) * nw] = v;
-                }
-            }
-        }
-    }
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------- launchers
@@ -319,14 +264,14 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
     return check_launch("expand_stream_kernel");
 }
 
-// ---- aligned flat forms: large, wide streams without component spectra (their records are in layout 1) ----
-// (>= 128 bands: the flat-panel kernel from 4M samples; 17 ... 127 bands: the tile kernel from 256K samples.  Up to 16
-// bands the stream is fused with the geometry unless GORT_STREAM_FUSE=0, and then it takes the narrow kernels.)
-constexpr int TILE_MIN_BANDS = 17;
+// ---- the aligned flat form: large, wide streams without component spectra (their records are in layout 1) ----
+// (>= 128 bands and >= 4M samples.  Streams of 17 ... 255 bands take gort_stream_lines.hip before they get here - the
+// hand-over is GORT_LINES_MAX_BANDS - and up to 16 bands the stream is fused with the geometry unless GORT_STREAM_FUSE=0.
+// Round 3's tile kernel for 17 ... 127 bands, whose rows left as whole cache lines only for multiples of 16 bands, is gone.)
 bool stream_is_large(int nw, long nA, bool want_scomp)
 {
-    if (want_scomp || nw < TILE_MIN_BANDS) return false;
-    return nA * (long)nw >= (nw < CHUNK ? (1L << 18) : (1L << 22));
+    if (want_scomp || nw < CHUNK) return false;
+    return nA * (long)nw >= (1L << 22);
 }
 
 // wave slots of the machine for expand_flat_stream_kernel (CUs x resident waves per CU; 256 x 28 on an MI355X)
@@ -379,7 +324,7 @@ static void stream_panel_shape(int nw, long chunks, long *stride, int *steps)
 // readable records the wide expansions may touch behind the last line (the caller also keeps ONE in front)
 long expand_stream_tail_pad_records(int nw, long nA)
 {
-    if (!stream_is_large(nw, nA, false) || nw < CHUNK) return 0;          // the tile kernel of < 128 bands reads its own lines only
+    if (!stream_is_large(nw, nA, false)) return 0;
     long stride;
     int steps;
     stream_panel_shape(nw, (nA * (long)nw + 2 * CHUNK - 2) / CHUNK, &stride, &steps);
@@ -389,20 +334,6 @@ long expand_stream_tail_pad_records(int nw, long nA)
 static int launch_expand_stream_flat(const double *band_table_dev, int nw, const double *coef_dev, long nA, double *rsurf_dev,
                                      int *xcd_slots_dev, hipStream_t s)
 {
-    if (nw < CHUNK) {
-        {
-            if (!band_table_dev) return fail(GORT_EINVAL, "stream expansion: wide stream without the band table");
-            const long waves = (nA + 63) / 64, blocks = (waves + 3) / 4;
-            if (blocks >= (1L << 31)) return fail(GORT_EINVAL, "stream expansion: %ld workgroups in one launch", blocks);
-            const StreamBand *tb = reinterpret_cast<const StreamBand *>(band_table_dev);
-            const bool whole_lines = nw % 16 == 0 && reinterpret_cast<uintptr_t>(rsurf_dev) % 128 == 0;
-            if (tuning().nt && whole_lines)
-                hipLaunchKernelGGL(expand_tile_stream_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, tb, nw, coef_dev, nA, rsurf_dev);
-            else
-                hipLaunchKernelGGL(expand_tile_stream_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, tb, nw, coef_dev, nA, rsurf_dev);
-            return check_launch("expand_tile_stream_kernel");
-        }
-    }
     const ExpandTuning &tune = tuning();
     if (!band_table_dev) return fail(GORT_EINVAL, "stream expansion: wide stream without the band table");
     const StreamBand *bands = reinterpret_cast<const StreamBand *>(band_table_dev);
@@ -437,7 +368,7 @@ static int launch_expand_stream_flat(const double *band_table_dev, int nw, const
 }
 
 // coef_dev: stream records with ONE readable pad record in front and expand_stream_tail_pad_records() behind the last
-// line; large streams (stream_is_large): records in layout 1, the flat-panel or the tile kernel.
+// line; large streams (stream_is_large): records in layout 1, the flat-panel kernel.
 // grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's sample.
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, const double *band_table_dev, int nw,
                          const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream,

@@ -88,8 +88,9 @@ def test_flat_kernel_equals_narrow_kernels_bitwise_and_oracle(setup):
 @pytest.mark.parametrize("nw", [17, 18, 31, 32, 33, 47, 48, 64, 65, 100, 127, 128, 129, 143, 144, 190, 255, 256, 1000, 1999, 2048, 3000])
 def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
     """Band counts with every gcd(nw, 128) (wave strides of 1..128 chunk columns), the last panel ragged, the output
-    itself starting off a 1-KiB chunk boundary (front and back edge handling).  Below 128 bands: the tile kernel (lines in
-    lanes, rows transposed through LDS; whole-line rows stored non-temporally, others plainly), ragged last wave and tile."""
+    itself starting off a 1-KiB chunk boundary (front and back edge handling).  Up to 255 bands: the fused line kernel
+    (lines in lanes, rows through LDS rings indexed by absolute position, whole 128-B lines whatever the band count; the
+    output offsets 1 and 5 leave partial lines at both ends of every wave's span), ragged last wave."""
     eng, c, torch = setup
     rng = np.random.default_rng(nw)
     wl = np.linspace(400.0, 2500.0, nw)
