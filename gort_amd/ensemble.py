@@ -143,8 +143,17 @@ def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, g
     canopies, leaf = draw_c5_members(n_members, seed)
     m0, m1 = row_slab(rank, world, n_members)
     eng = api.Engine()
+    lut = None
     if m1 > m0:
-        eng.reserve_members(m1 - m0, wl.size)   # capacity, like the engine itself, before the clock: setup = copies and kernels
+        # capacity, like the engine itself, before the clock (a filter allocates once and cycles many times): the member
+        # buffers, and the ONE chunk buffer the LUTs pass through - placed by the C ABI's allocator (up to three draws: a
+        # 14 GB slab lies on a fast stretch of HBM about half the time)
+        eng.reserve_members(m1 - m0, wl.size)
+        if lut_chunk:
+            g = c5_grid()
+            chunk = min(lut_chunk, m1 - m0)
+            per_member = g.nvza * g.nphi * wl.size
+            lut = eng.lut_alloc(chunk * per_member, max_draws=3)
     sync = barrier or (lambda: None)
     t = {"members": [m0, m1]}
     torch.cuda.synchronize()
@@ -155,11 +164,7 @@ def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, g
         eng.synchronize()
     t["setup_s"] = time.perf_counter() - t0
     t["lut_s"], t["lut_chunk_ms"], t["lut_samples"] = 0.0, [], 0
-    if lut_chunk and m1 > m0:
-        g = c5_grid()
-        chunk = min(lut_chunk, m1 - m0)
-        per_member = g.nvza * g.nphi * wl.size
-        lut = eng.lut_alloc(chunk * per_member, max_draws=1)
+    if lut is not None:
         eng.last_expand_ms()
         t0 = time.perf_counter()
         # The LUTs are a product that is consumed on the device and dropped (what leaves is the reduced table): the chunks
@@ -174,6 +179,7 @@ def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, g
         t["lut_chunk_ms"] = [t["lut_s"] * 1e3 / n_chunks] * n_chunks          # mean: the chunks are not timed one by one any more
         t["lut_kernel_ms"] = eng.last_expand_ms()                            # mean duration of the expansion kernel (HIP events)
         t["lut_samples"] = (m1 - m0) * per_member
+        t["lut_alloc"] = lut.placement
         lut.free()
     t0 = time.perf_counter()
     energy = torch.empty((m1 - m0, 1, wl.size, 3), dtype=torch.float64, device="cuda")

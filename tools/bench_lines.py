@@ -15,9 +15,10 @@ eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
 rng = np.random.default_rng(0)
 a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), rng.uniform(0, 360, n)], 1), device="cuda")
 out = torch.empty((n, nw), dtype=torch.float64, device="cuda")
-for _ in range(3):
+t_up = time.perf_counter()
+while time.perf_counter() - t_up < 0.25:       # clocks up
     eng.rsurf_stream_dev(a, out)
-eng.synchronize()
+    eng.synchronize()
 ex, wall = [], []
 for _ in range(reps):
     t0 = time.perf_counter(); eng.rsurf_stream_dev(a, out); eng.synchronize(); wall.append(time.perf_counter() - t0); ex.append(eng.last_stream_ms() * 1e-3)
