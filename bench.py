@@ -465,6 +465,8 @@ def main():
 
         def run():
             try:
+                torch.cuda.set_device(dev_index)       # the current device is per thread: without this every rank's helper
+                api.set_device(dev_index)              # thread would talk to GPU 0
                 box["value"] = fn()
             except BaseException as ex:           # noqa: BLE001
                 box["error"] = repr(ex)
