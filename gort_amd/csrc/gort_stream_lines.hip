@@ -120,29 +120,34 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
     const int sub = lane >> 3, q = lane & 7;                  // as a store lane: row 8 i + sub, 16 bytes number q of its cache line
     const int m = (nw + BLOCK_BANDS - 1) / BLOCK_BANDS;
 
-    // full cache line j of every row (rows whose line j is not complete inside the row skip it): eight reads, then the stores
+    // full cache line j of every row (rows whose line j is not complete inside the row skip it): eight reads, then the
+    // stores.  What does not depend on j is formed once per wave - per store slot the row's count of full lines, where
+    // its first one lies in its ring (the ring holds two lines: line j sits in half (first + j) & 1) and in the output.
+    int n_full[8], ring_at[8], first_half[8];
+    double *gp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 8 * i + sub;
+        const int pr = g0 + r * nw;
+        const int F = (pr + 15) & ~15;
+        n_full[i] = r < lines_here ? (pr + nw - F) >> 4 : 0;
+        first_half[i] = (F >> 4) & 1;
+        ring_at[i] = (((r + 1) * pitch) >> 1) + q;                 // in 16-byte units: pitch is even
+        gp[i] = origin + F + 2 * q;
+    }
     auto emit_full = [&](int j) {
         dbl2 v[8];
-        int X[8];
-        bool ok[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = 8 * i + sub;
-            const int pr = g0 + r * nw;
-            const int F = (pr + 15) & ~15;
-            const int n = (pr + nw - F) >> 4;
-            ok[i] = r < lines_here && j < n;
-            X[i] = F + 16 * j;
-            v[i] = reinterpret_cast<const dbl2 *>(s_ring)[(((r + 1) * pitch + (X[i] & (RING - 1))) >> 1) + q];      // all even: 16-B aligned
-        }
+        for (int i = 0; i < 8; ++i)
+            v[i] = reinterpret_cast<const dbl2 *>(s_ring)[ring_at[i] + (((first_half[i] + j) & 1) << 3)];
         // the reads are waited for HERE, outside the branches of the stores: else the compiler's wait-count pass carries
         // them as pending round the loop and drains everything - the band request included - at the top of the next block
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (ok[i]) {
-                dbl2 *o = reinterpret_cast<dbl2 *>(origin + X[i] + 2 * q);
+            if (j < n_full[i]) {
+                dbl2 *o = reinterpret_cast<dbl2 *>(gp[i] + 16 * j);
                 if (NT) __builtin_nontemporal_store(v[i], o);
                 else *o = v[i];
             }
