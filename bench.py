@@ -359,6 +359,7 @@ def config5_block(args, rank, world, dist, barrier):
                          "bytes_received_per_gpu": t["gather_bytes_received"],
                          "gbs_received_per_gpu": t["gather_bytes_received"] / worst["gather_s"] / 1e9 if world > 1 else None,
                          "xgmi_bound_gbs": XGMI_BOUND_GBS, "backend": "gloo (rehearsal)" if args.rehearse else ("nccl" if world > 1 else None)},
+           "lut_kernel_ms_rank0": t.get("lut_kernel_ms"), "lut_alloc_rank0": t.get("lut_alloc"),
            "per_rank": per_rank}
     # parity of the exchanged product: one member of this rank and one that arrived through the all-gather
     try:

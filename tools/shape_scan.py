@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The stream expansion across band counts: which kernel a (lines, bands) shape takes and what it delivers - the fused launch
-(<= 16 bands), the tile kernel (17 ... 127 bands), the flat-panel kernel (>= 128), the narrow kernels below their thresholds.
+(<= 16 bands), the fused line kernel (17 ... 255 bands), the flat-panel kernel (>= 256), the narrow kernels below their thresholds.
 Run from the repo root on a GPU box; profiles/r04/shape_scan.log (round 3: profiles/r03/stream_mid_bands.log, without the 0.25 s of load in front of every shape that round 4 added: its numbers read ~20 % high)."""
 import os, sys, time
 import numpy as np
