@@ -146,8 +146,8 @@ def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, g
     lut = None
     if m1 > m0:
         # capacity, like the engine itself, before the clock (a filter allocates once and cycles many times): the member
-        # buffers, and the ONE chunk buffer the LUTs pass through - placed by the C ABI's allocator (up to three draws: a
-        # 14 GB slab lies on a fast stretch of HBM about half the time)
+        # buffers, and the ONE chunk buffer the LUTs pass through - placed by the C ABI's allocator (a 14 GB slab lies on a
+        # fast stretch of HBM about half the time)
         eng.reserve_members(m1 - m0, wl.size)
         if lut_chunk:
             g = c5_grid()
