@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
     // full cache line j of every row (rows whose line j is not complete inside the row skip it): eight reads, then the
     // stores.  What does not depend on j is formed once per wave - per store slot the row's count of full lines, where
     // its first one lies in its ring (the ring holds two lines: line j sits in half (first + j) & 1) and in the output.
-    int n_full[8], ring_at[8], first_half[8];
+    int n_full[8], ring_at[8], first_half[8], tail_len[8];
     double *gp[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         const int pr = g0 + r * nw;
         const int F = (pr + 15) & ~15;
         n_full[i] = r < lines_here ? (pr + nw - F) >> 4 : 0;
+        tail_len[i] = r < lines_here ? (pr + nw - F) & 15 : 0;     // what the row leaves in the cache line behind its last full one
         first_half[i] = (F >> 4) & 1;
         ring_at[i] = (((r + 1) * pitch) >> 1) + q;                 // in 16-byte units: pitch is even
         gp[i] = origin + F + 2 * q;
@@ -205,25 +206,26 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
             for (int i = 0; i < BLOCK_BANDS - 1; ++i)
                 if (i < s) prev_ring[(pos + i) & (RING - 1)] = head[i];
         }
+        // the seam behind row r = 8 i + sub, from the numbers of its store slot: complete where the next row is the wave's too
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int r = 8 * i + sub - 1;                     // -1: the line in front of the wave's first row
-            if (r >= lines_here) continue;
-            int X, lo, hi;
-            if (r < 0) {
-                hi = (g0 + 15) & ~15;
-                X = hi - 16;
-                lo = g0;
-            } else {
-                const int pr = g0 + r * nw;
-                const int F = (pr + 15) & ~15;
-                const int n = (pr + nw - F) >> 4;
-                const int end = pr + nw;
-                X = F + 16 * n;
-                lo = X;
-                hi = X == end ? X : (r + 1 < lines_here ? X + 16 : end);
+        for (int i = 0; i < 8; ++i) {
+            if (tail_len[i] > 0) {
+                const int r = 8 * i + sub;
+                const dbl2 v = reinterpret_cast<const dbl2 *>(s_ring)[ring_at[i] + (((first_half[i] + n_full[i]) & 1) << 3)];
+                double *o = gp[i] + 16 * n_full[i];
+                if (r + 1 < lines_here) {
+                    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(o));
+                    else *reinterpret_cast<dbl2 *>(o) = v;
+                } else {                                           // the wave's last row: its tail only
+                    if (2 * q < tail_len[i]) o[0] = v.x;
+                    if (2 * q + 1 < tail_len[i]) o[1] = v.y;
+                }
             }
-            if (hi > lo) emit_cache_line<NT>(s_ring, r + 1, pitch, X, lo, hi, q, origin);
+        }
+        // the line in front of the wave's first row holds that row's head and nothing else of this wave
+        if (sub == 0 && (g0 & 15)) {
+            const int hi = (g0 + 15) & ~15;
+            emit_cache_line<NT>(s_ring, 0, pitch, hi - 16, g0, hi, q, origin);
         }
     }
 }
