@@ -996,9 +996,10 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
     int *slots = nullptr;
     int rc = xcd_slots_for_launch(e, &slots);          // also probes the dispatch order once
     if (rc) return rc;
-    // ... and windows of 32 GiB or more always span several physical extents: 7.1-7.5 TB/s wherever they lie
-    // (profiles/r03/placement_scan.log, scaling_estimate*.log at N = 1): nothing to select there either
-    const bool select = max_draws > 1 && doubles >= (1L << 27) && doubles < (1L << 32) && !slots;
+    // (round 3 stopped selecting at 32 GiB: the boxes it had seen wrote such windows at 7.1-7.5 TB/s wherever they lay.
+    // Round 4 met boxes where two of four 50 GB allocations alive together run the LUT kernel at 7.45 ms and two at 6.72,
+    // every time, and the probe tells them apart - 6.2 against 7.15 TB/s: profiles/r04/placement_select.log)
+    const bool select = max_draws > 1 && doubles >= (1L << 27) && !slots;
     const int cls = size_class(doubles);
     const double accept = select ? 0.985 * e->best_pattern_gbs[cls] : 0.0;
     void *cand[GORT_LUT_MAX_DRAWS] = {nullptr};
@@ -1088,9 +1089,15 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
             lut_bases()[cand[best]] = base;
         }
     } else {
-        // the window is (most of) the buffer: separate allocations, alive together; big windows differ little
-        const int draws = select ? (max_draws < 3 ? max_draws : 3) : 1;
+        // the window is (most of) the buffer: separate allocations, alive together (a freed candidate's memory would
+        // come straight back) as far as the device has room for them beside 8 GiB for everybody else
+        const int draws = select ? (max_draws < 4 ? max_draws : 4) : 1;
         for (; n < draws; ++n) {
+            size_t free_b = 0, total_b = 0;
+            if (n > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30))) {
+                (void)hipGetLastError();
+                break;
+            }
             if (hipMalloc(&cand[n], bytes) != hipSuccess) {
                 (void)hipGetLastError();
                 cand[n] = nullptr;
