@@ -114,7 +114,7 @@ struct EnergyShared {
 template <bool SHARE_ROWS>
 __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *__restrict__ L, int nw,
                                             const double *__restrict__ angles, const double *__restrict__ nodes,
-                                            double *__restrict__ energy, long a, EnergyShared &sh)
+                                            double *__restrict__ energy, long a, EnergyShared &sh, int band_begin, int band_end)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double vza, sza, saa, raa;
@@ -129,7 +129,10 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     const double w = nodes[3 * tid + 2];
     GeomOut g;
     if (SHARE_ROWS) {
-        if (tid < ENERGY_ZENITH_NODES) row_terms(c, nodes[3 * tid + 1], sza, sh.row[tid]);
+        // reflectances only leave this kernel, and with the sun on the horizon they are NaN by either route (the view zeniths
+        // are Gauss nodes, never on it): no reference route here - it made the 90-degree line of BASELINE config 4 twice
+        // as long as the others (8.8 against 4.5 us of row terms), and a launch ends with its longest line
+        if (tid < ENERGY_ZENITH_NODES) row_terms(c, nodes[3 * tid + 1], sza, sh.row[tid], false);
         __syncthreads();
         finish_angle(c, sh.row[tid & (ENERGY_ZENITH_NODES - 1)], raa, g);
     } else {
@@ -157,7 +160,7 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     SunScalars s;
     s.fd = sh.sun[0];  s.mu = sh.sun[1];  s.t0 = sh.sun[2];  s.tp0 = sh.sun[3];  s.eps = sh.sun[4];  s.pn0 = sh.sun[5];
     const double aC = sh.abar[0], aB = sh.abar[1], aZ = sh.abar[2], aG = sh.abar[3], aT = sh.abar[4];
-    for (int i = tid; i < nw; i += ENERGY_THREADS) {
+    for (int i = band_begin + tid; i < band_end; i += ENERGY_THREADS) {
         const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
         const double albedo = dot5(aC, aB, aZ, aG, aT, b.C0, b.B, b.Z, b.G, b.T);
         const double rs = L[L_RS * nw + i];
@@ -172,7 +175,9 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
 }
 
 // blockIdx.x = angle line, blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by
-// the members; energy[member][nA][nw][3]
+// the members; energy[member][nA][nw][3].  blockIdx.z = band range: a table of a few lines (BASELINE config 4: 91) leaves
+// most CUs idle, so its lines are evaluated by several workgroups, each with the whole quadrature (redundant, on CUs that
+// had nothing to do) and one ENERGY_THREADS-wide pass over its share of the bands instead of nw / ENERGY_THREADS passes.
 template <bool SHARE_ROWS>
 __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_kernel(const gort_canopy *__restrict__ canopies,
                                                                  const double *__restrict__ Lall, int nw,
@@ -182,8 +187,9 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_kernel(const gort_ca
 {
     __shared__ EnergyShared sh;
     const long member = blockIdx.y;
+    const int per = (nw + (int)gridDim.z - 1) / (int)gridDim.z, band_begin = (int)blockIdx.z * per;
     energy_line<SHARE_ROWS>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
-                            (long)blockIdx.x, sh);
+                            (long)blockIdx.x, sh, band_begin, band_begin + per < nw ? band_begin + per : nw);
 }
 
 // the lines that stand for themselves (uniq[0] of them, uniq[1..]): workgroups stride over the list
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_kernel(const go
         // they are used.
         asm volatile("" ::: "memory");
         energy_line<SHARE_ROWS>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes,
-                                energy_all + member * nA * nw * 3, (long)uniq[1 + u], sh);
+                                energy_all + member * nA * nw * 3, (long)uniq[1 + u], sh, 0, nw);
     }
 }
 
@@ -318,11 +324,26 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     const bool share_rows = !(sr && atoi(sr) == 0);
     if (!ws_dev || nA < ENERGY_DEDUP_MIN_LINES) {
         if (nA >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld lines in one launch", nA);
+        // band ranges: as many as give every range one pass, as far as every workgroup still has a CU of its own (two
+        // per CU measured slower than none: C4 27.4 us unsplit, 25.8 in two ranges = 182 workgroups, 29.3 in three)
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+                cus = 256;
+            (void)hipGetLastError();
+        }
+        long splits = (nw + ENERGY_THREADS - 1) / ENERGY_THREADS;
+        if (splits * nA * n_members > (long)cus) splits = (long)cus / (nA * n_members);
+        if (const char *v = getenv("GORT_ENERGY_BAND_SPLITS")) splits = atol(v);         // tests, experiments
+        if (splits < 1) splits = 1;
+        if (splits > 64) splits = 64;
+        const dim3 grid((unsigned)nA, (unsigned)n_members, (unsigned)splits);
         if (share_rows)
-            hipLaunchKernelGGL(energy_kernel<true>, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
+            hipLaunchKernelGGL(energy_kernel<true>, grid, dim3(ENERGY_THREADS), 0, s,
                                canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
         else
-            hipLaunchKernelGGL(energy_kernel<false>, dim3((unsigned)nA, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s,
+            hipLaunchKernelGGL(energy_kernel<false>, grid, dim3(ENERGY_THREADS), 0, s,
                                canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
         return check_launch("energy_kernel");
     }

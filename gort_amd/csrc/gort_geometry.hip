@@ -70,6 +70,11 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 // GEOM_ROWS x nphi azimuth nodes.  With 361 nodes per row this removes ~70 % of the transcendentals of the
 // per-tuple form.
 constexpr int GEOM_ROW_THREADS = 128;
+#ifndef GORT_GEOM_SPAN_THREADS
+#define GORT_GEOM_SPAN_THREADS 256
+#endif
+constexpr int GEOM_SPAN_THREADS = GORT_GEOM_SPAN_THREADS;      // threads of a workgroup of the node-partitioned form
+constexpr int GEOM_SPAN_ROWS = GEOM_SPAN_THREADS / 32 + 4;          // rows such a workgroup may touch (8 / 12 / 20 at 128 / 256 / 512 threads)
 
 // mode 0: full stream records (GORT_COEF_STRIDE doubles per node); 1: compact 64-B records for the LUT kernel;
 // 2: FUSED for grids of a few bands (BASELINE config 3 is one band): the node's samples are formed right here from
@@ -78,8 +83,16 @@ constexpr int GEOM_ROW_THREADS = 128;
 #ifndef GORT_GEOM_WAVES
 #define GORT_GEOM_WAVES 3      // 168 VGPRs instead of 171: a third wave per SIMD, C3 133 -> 125 us; 4 would spill to scratch
 #endif
-template <int GEOM_ROWS>
-__global__ __launch_bounds__(GEOM_ROW_THREADS) __attribute__((amdgpu_waves_per_eu(GORT_GEOM_WAVES)))
+// ONE_MEMBER: every row of the launch belongs to one member (any single-canopy grid: BASELINE configs 1, 3 and a rank's
+// slab of the metric grid).  Two things follow.  (1) Its canopy and the first band's constants are uniform and are read
+// once, ahead of the node loop, where the general form reads them per lane and node (a dozen vector loads and three exposed
+// waits per node).  (2) The launch is partitioned by NODES, not rows: workgroup k takes the nodes [k T / G, (k + 1) T / G)
+// of the launch's T = rows x per_row and evaluates the terms of the <= GEOM_ROWS rows its span touches - so the launcher
+// can choose G = the machine's slots exactly (at 120 VGPRs four waves per SIMD fit: 2048 workgroups), every CU gets the
+// same eight workgroups of the same length, and the grid's row count no longer decides how full the machine is
+// (the row form fills it 2.7 waves per SIMD deep for the hemisphere, unevenly where four fit: C3 61.7 us against 55.6).
+template <int GEOM_ROWS, bool ONE_MEMBER>
+__global__ __launch_bounds__(ONE_MEMBER ? GEOM_SPAN_THREADS : GEOM_ROW_THREADS) __attribute__((amdgpu_waves_per_eu(ONE_MEMBER ? 4 : GORT_GEOM_WAVES)))
 void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
                                                                           double *__restrict__ coef, int compact,
@@ -90,8 +103,28 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
     __shared__ int s_member[GEOM_ROWS];
     __shared__ double s_vza_deg[GEOM_ROWS], s_sza_deg[GEOM_ROWS];
     const long rows_per_member = (long)g.nsza * g.nvza;
-    const long first = (long)blockIdx.x * GEOM_ROWS;                   // first row of this block, relative to row_begin
-    const int rows_here = n_rows - first < GEOM_ROWS ? (int)(n_rows - first) : GEOM_ROWS;
+    const long member0 = row_begin / rows_per_member;                  // ONE_MEMBER: the member of every row
+    // mirror: the azimuth nodes run once round the full circle from phi0 = 0, and everything below depends on the
+    // relative azimuth through cos(raa), sin^2(raa) and the folded raa / pi only (overlap, ph_r, frac, cos xi:
+    // gortt_brdf.c:23-100, 118-169, 650-666): node l' = nphi - 1 - l is the mirror image of node l.  Half the nodes
+    // are evaluated and each result is written twice (the device's cos of 2 pi - x and of x differ in the last place,
+    // as the reference's do: the images agree with their own evaluation to rounding, 1e-15).
+    const int per_row = mirror ? (g.nphi + 1) / 2 : g.nphi;
+    long first;                                                         // first row of this block, relative to row_begin
+    int rows_here, rel0, rel1;                                          // its nodes, counted from node 0 of row `first`
+    if (ONE_MEMBER) {
+        const long total = n_rows * per_row;
+        const long node0 = (long)blockIdx.x * total / gridDim.x, node1 = ((long)blockIdx.x + 1) * total / gridDim.x;
+        first = node0 / per_row;
+        rows_here = node1 > node0 ? (int)((node1 - 1) / per_row - first) + 1 : 0;
+        rel0 = (int)(node0 - first * per_row);
+        rel1 = (int)(node1 - first * per_row);
+    } else {
+        first = (long)blockIdx.x * GEOM_ROWS;
+        rows_here = n_rows - first < GEOM_ROWS ? (int)(n_rows - first) : GEOM_ROWS;
+        rel0 = 0;
+        rel1 = rows_here * per_row;
+    }
     if ((int)threadIdx.x < rows_here) {
         const long grow = row_begin + first + threadIdx.x;
         const long member = grow / rows_per_member;
@@ -100,22 +133,24 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
         double vza, sza, saa, raa;
         normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
-        row_terms(canopies[member], vza, sza, s_row[threadIdx.x], false);      // a LUT holds reflectances only: NaN at the horizon by either route
+        row_terms(canopies[ONE_MEMBER ? member0 : member], vza, sza, s_row[threadIdx.x], false);      // a LUT holds reflectances only: NaN at the horizon by either route
         s_member[threadIdx.x] = (int)member;
         s_vza_deg[threadIdx.x] = vza_deg;
         s_sza_deg[threadIdx.x] = sza_deg;
     }
     __syncthreads();
-    // mirror: the azimuth nodes run once round the full circle from phi0 = 0, and everything below depends on the
-    // relative azimuth through cos(raa), sin^2(raa) and the folded raa / pi only (overlap, ph_r, frac, cos xi:
-    // gortt_brdf.c:23-100, 118-169, 650-666): node l' = nphi - 1 - l is the mirror image of node l.  Half the nodes
-    // are evaluated and each result is written twice (the device's cos of 2 pi - x and of x differ in the last place,
-    // as the reference's do: the images agree with their own evaluation to rounding, 1e-15).
-    const int per_row = mirror ? (g.nphi + 1) / 2 : g.nphi;
-    const int nodes = rows_here * per_row;
-    for (int n = threadIdx.x; n < nodes; n += GEOM_ROW_THREADS) {
+    // ONE_MEMBER: what the node loop reads of the canopy and (fused form) the first band's constants, once, ahead of the loop
+    const gort_canopy &c0 = canopies[member0];
+    const double ko0 = c0.k_open, kep0 = c0.k_openep;
+    BandTerms band0 = {};
+    if (ONE_MEMBER && compact == 2) {
+        band0 = load_band(Lall + member0 * L_NSLOT * nw, nw, 0);
+    }
+    constexpr int THREADS = ONE_MEMBER ? GEOM_SPAN_THREADS : GEOM_ROW_THREADS;
+    for (int n = rel0 + (int)threadIdx.x; n < rel1; n += THREADS) {
         const int r = n / per_row, l = n - r * per_row;
-        const gort_canopy &c = canopies[s_member[r]];
+        const long member = ONE_MEMBER ? member0 : (long)s_member[r];
+        const gort_canopy &c = canopies[member];
         double vza, sza, saa, raa;
         normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
         GeomOut o;
@@ -126,10 +161,11 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         if (compact == 2) {
             double rec[GORT_COEF_STRIDE];
             store_coef(rec, c, o);
-            const double *__restrict__ L = Lall + (long)s_member[r] * L_NSLOT * nw;
+            const double *__restrict__ L = Lall + member * L_NSLOT * nw;
             const SunScalars sun = load_sun(rec);
             for (int b = 0; b < nw; ++b) {
-                const SunTerms t = sun_terms(L, nw, b, sun, c.k_open, c.k_openep);
+                const SunTerms t = ONE_MEMBER ? sun_terms(b == 0 ? band0 : load_band(L, nw, b), sun, ko0, kep0)
+                                              : sun_terms(L, nw, b, sun, c.k_open, c.k_openep);
                 const double v = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t.C0, t.B, t.Z, t.G, t.T);
                 rsurf[i * nw + b] = v;
                 if (i2 >= 0) rsurf[i2 * nw + b] = v;
@@ -204,16 +240,22 @@ static bool grid_mirrors(const gort_grid &g)
 // mirrored nodes (BASELINE config 3, profiles/r03/c3_rows2.log): 4 rows 79.3 us, 5 rows 79.8 (still two rounds),
 // 6 rows 68.7, 7 rows 76.3, 8 rows 83.6 (one round each, ever longer workgroups); 64-thread workgroups 84.3.
 // So: the smallest of 4 / 6 / 8 rows that makes one round, 4 where nothing does.
-static int geom_rows_per_workgroup(long rows)
+// workgroup slots of the device at `waves` waves per SIMD (two-wave workgroups)
+static long geom_slots(int waves, int threads = GEOM_ROW_THREADS)
 {
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, cus = 0;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
             cus = 256;
         (void)hipGetLastError();
-        slots = cus * (GORT_GEOM_WAVES * 4 / (GEOM_ROW_THREADS / 64));
     }
+    return (long)cus * (waves * 4 / (threads / 64));
+}
+
+static int geom_rows_per_workgroup(long rows)
+{
+    const long slots = geom_slots(GORT_GEOM_WAVES);
     for (int per : {4, 6, 8})
         if ((rows + per - 1) / per <= slots) return per;
     return 4;
@@ -222,15 +264,32 @@ static int geom_rows_per_workgroup(long rows)
 static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long rows, double *coef_dev,
                                     int compact, const double *L_dev, int nw, double *rsurf_dev, void *stream)
 {
-    const int per = geom_rows_per_workgroup(rows), mirror = grid_mirrors(g) ? 1 : 0;
-    const dim3 grid((unsigned)((rows + per - 1) / per)), block(GEOM_ROW_THREADS);
+    const int mirror = grid_mirrors(g) ? 1 : 0;
+    const dim3 block(GEOM_ROW_THREADS);
     hipStream_t s = (hipStream_t)stream;
-    if (per == 4)
-        hipLaunchKernelGGL(geometry_grid_kernel<4>, grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
-    else if (per == 6)
-        hipLaunchKernelGGL(geometry_grid_kernel<6>, grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
-    else
-        hipLaunchKernelGGL(geometry_grid_kernel<8>, grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
+    const long rows_per_member = (long)g.nsza * g.nvza;
+    static const bool by_rows = getenv("GORT_GRID_BY_ROWS") && atoi(getenv("GORT_GRID_BY_ROWS")) != 0;      // tests: the general form for everything
+    if (!by_rows && row_begin / rows_per_member == (row_begin + rows - 1) / rows_per_member) {
+        // one member: partitioned by nodes.  One round of the machine's slots (four waves per SIMD, two per workgroup) where the
+        // launch has two node rounds per workgroup to give; a workgroup's span stays within GEOM_SPAN_ROWS rows (six row
+        // lengths of nodes touch at most seven rows), so the biggest grids take more, equally long, workgroups instead.
+        const int per_row = mirror ? (g.nphi + 1) / 2 : g.nphi;
+        const long total = rows * per_row, slots = geom_slots(4, GEOM_SPAN_THREADS), span_max = (long)(GEOM_SPAN_ROWS - 2) * per_row;
+        long G = (total + 2 * GEOM_SPAN_THREADS - 1) / (2 * GEOM_SPAN_THREADS);
+        if (G > slots) G = slots;
+        if (const char *v = getenv("GORT_GRID_WGS")) { if (atol(v) > 0) G = atol(v); }      // experiments (tools/shape_scan.py --grid)
+        if ((total + G - 1) / G > span_max) G = (total + span_max - 1) / span_max;
+        hipLaunchKernelGGL((geometry_grid_kernel<GEOM_SPAN_ROWS, true>), dim3((unsigned)G), dim3(GEOM_SPAN_THREADS), 0, s, canopy_dev, g, row_begin, rows,
+                           coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
+        return check_launch("geometry_grid_kernel");
+    }
+    const int per = geom_rows_per_workgroup(rows);
+    const dim3 grid((unsigned)((rows + per - 1) / per));
+#define GORT_GRID_LAUNCH(ROWS) hipLaunchKernelGGL((geometry_grid_kernel<ROWS, false>), grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror)
+    if (per == 4) GORT_GRID_LAUNCH(4);
+    else if (per == 6) GORT_GRID_LAUNCH(6);
+    else GORT_GRID_LAUNCH(8);
+#undef GORT_GRID_LAUNCH
     return check_launch("geometry_grid_kernel");
 }
 

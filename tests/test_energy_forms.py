@@ -68,8 +68,17 @@ def test_row_terms_once_per_zenith_node_same_bits():
             os.environ.pop("GORT_ENERGY_SHARE_ROWS")
     for k in (0, 1):
         a, b = res["1"][k], res["0"][k]
-        bad = np.flatnonzero((_bits(a) != _bits(b)).any(axis=(1, 2)) & ~(np.isnan(a).all(axis=(1, 2)) & np.isnan(b).all(axis=(1, 2))))
-        assert bad.size == 0, (k, bad[:10], (c4 if k == 0 else stream)[bad[:3]], a[bad[:1], :2], b[bad[:1], :2])
+        ang = c4 if k == 0 else stream
+        # a sun exactly on the horizon: albedo and favegt are NaN by either form, fasoil (sun terms only) is finite, and the
+        # round-3 form takes the reference's own route there (gort_device.h: near_horizon) where the shared-row form, which
+        # hands out reflectances only, does not: equal to rounding, not in bits
+        horizon = np.abs(ang[:, 2]) == 90.0
+        assert horizon.sum() == 1
+        assert np.isnan(a[horizon, :, :2]).all() and np.isnan(b[horizon, :, :2]).all()
+        np.testing.assert_allclose(a[horizon, :, 2], b[horizon, :, 2], rtol=1e-13, atol=0)
+        differ = (_bits(a) != _bits(b)).any(axis=(1, 2)) & ~(np.isnan(a).all(axis=(1, 2)) & np.isnan(b).all(axis=(1, 2))) & ~horizon
+        bad = np.flatnonzero(differ)
+        assert bad.size == 0, (k, bad[:10], ang[bad[:3]], a[bad[:1], :2], b[bad[:1], :2])
     assert np.isnan(res["1"][1][9]).all() and np.isfinite(res["1"][1][:5]).all()
     assert np.abs(res["1"][0][:90].sum(axis=2) - 1.0).max() < 1e-12        # albedo + favegt + fasoil = 1
 
