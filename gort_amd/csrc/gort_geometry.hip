@@ -268,7 +268,8 @@ static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_gr
     const dim3 block(GEOM_ROW_THREADS);
     hipStream_t s = (hipStream_t)stream;
     const long rows_per_member = (long)g.nsza * g.nvza;
-    static const bool by_rows = getenv("GORT_GRID_BY_ROWS") && atoi(getenv("GORT_GRID_BY_ROWS")) != 0;      // tests: the general form for everything
+    const char *br = getenv("GORT_GRID_BY_ROWS");                      // tests: the general form for everything (read per call)
+    const bool by_rows = br && atoi(br) != 0;
     if (!by_rows && row_begin / rows_per_member == (row_begin + rows - 1) / rows_per_member) {
         // one member: partitioned by nodes.  One round of the machine's slots (four waves per SIMD, two per workgroup) where the
         // launch has two node rounds per workgroup to give; a workgroup's span stays within GEOM_SPAN_ROWS rows (six row
