@@ -272,7 +272,7 @@ def configs_block():
         return min(ts)
 
     def valu_frac(key, waves, t):
-        per_wave = counts.get(key)
+        per_wave = counts.get(key)                      # "..._per_launch" keys: the launch's total, waves = 1
         return None if not per_wave else per_wave * waves * 4.0 / (1024 * 2.4e9 * t)
 
     eng = api.Engine()
@@ -289,9 +289,8 @@ def configs_block():
     g = api.hemisphere_grid(); rows = g.nsza * g.nvza
     lut = torch.empty((rows * g.nphi, 1), dtype=torch.float64, device="cuda")
     t = best(lambda: eng.rsurf_grid_dev(g, 0, rows, lut), eng)
-    wg = (rows + 5) // 6
     out["C3"] = {"workload": "91x91x361 angles x 1 band, LUT entry point", "us": t * 1e6, "samples_per_s": rows * g.nphi / t,
-                 "bound": "fp64_valu", "frac": valu_frac("geometry_grid_kernel<6>@c3", 2 * wg, t),
+                 "bound": "fp64_valu", "frac": valu_frac("geometry_grid_kernel<12,true>@c3_per_launch", 1, t),
                  "hbm_frac": rows * g.nphi * 8 / t / 8e12}
     del lut
     # C4: albedo / fAPAR table, 91 sun zeniths x 2101 bands
@@ -302,8 +301,8 @@ def configs_block():
     t = best(lambda: eng.energy_stream_dev(sza, en), eng)
     out["C4"] = {"workload": "91 sun zeniths x 2101 bands x (albedo, fAPAR, soil absorption)", "us": t * 1e6,
                  "brdf_evaluations_per_s": 91 * 512 * wl.size / t, "bound": "latency",
-                 "note": "91 workgroups on 256 CUs: one serial chain of row terms + node geometry + quadrature per workgroup",
-                 "frac_fp64_valu": valu_frac("energy_kernel<true>@c4", 8 * 91, t)}
+                 "note": "182 workgroups (two band ranges per sun zenith) on 256 CUs: one serial chain of row terms + node geometry + quadrature per workgroup",
+                 "frac_fp64_valu": valu_frac("energy_kernel<true>@c4_per_launch", 1, t)}
     # the streams a user of the reference's command line has: a million lines x 7 bands (MODIS-like) and x 100 bands
     rng = np.random.default_rng(0)
     n = 1000000
