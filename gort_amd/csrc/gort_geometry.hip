@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 }
 
 // grid nodes generated from indices; identical to streaming "vza phi sza 0" (SURVEY 8d, C3).
-// One workgroup per GEOM_ROWS (4, 6 or 8: geom_rows_per_workgroup) LUT rows, a row = (member, sun zenith, view zenith): the azimuth-independent terms
-// of each row are evaluated ONCE into LDS, the rows side by side on the first lanes of one wavefront (the ~25
+// A workgroup takes GEOM_ROWS LUT rows (4, 6 or 8: geom_rows_per_workgroup) or, in single-member launches, a span of nodes
+// (below); a row = (member, sun zenith, view zenith): the azimuth-independent terms of each of its rows are evaluated ONCE into LDS, the rows side by side on the first lanes of one wavefront (the ~25
 // transcendentals of a row are a serial chain: four rows cost the issue time of one), then the lanes walk the
 // GEOM_ROWS x nphi azimuth nodes.  With 361 nodes per row this removes ~70 % of the transcendentals of the
 // per-tuple form.
@@ -81,7 +81,7 @@ constexpr int GEOM_SPAN_ROWS = GEOM_SPAN_THREADS / 32 + 4;          // rows such
 // its coefficients - no 128-B record per node written and read back (383 MB each way for the hemisphere grid,
 // more than the arithmetic costs) - with the same sun_terms()/dot5() as the two-kernel path: same bits.
 #ifndef GORT_GEOM_WAVES
-#define GORT_GEOM_WAVES 3      // 168 VGPRs instead of 171: a third wave per SIMD, C3 133 -> 125 us; 4 would spill to scratch
+#define GORT_GEOM_WAVES 3      // the row-partitioned form: 131 VGPRs, three waves per SIMD (the node-partitioned one: 120, four)
 #endif
 // ONE_MEMBER: every row of the launch belongs to one member (any single-canopy grid: BASELINE configs 1, 3 and a rank's
 // slab of the metric grid).  Two things follow.  (1) Its canopy and the first band's constants are uniform and are read
