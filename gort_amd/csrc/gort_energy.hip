@@ -216,6 +216,106 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_kernel(const go
     }
 }
 
+// The same list in BATCHES of ENERGY_BATCH lines per workgroup pass (round 4).  Stamps of the line-after-line form (BASELINE
+// config 4, s_memrealtime): 4.5 us of row terms on sixteen lanes of one wave with seven waves waiting at the barrier, 1.9 us
+// of node geometry, 1.9 us of reductions, 4.5 us of band passes that each wait for eleven band constants - a chain of
+// latencies per line, two lines in flight per CU.  Here one wave evaluates the row terms of the batch's four lines, sixteen
+// lanes each (four chains for the issue slots of one), every thread then finishes its node for each of the lines
+// (independent work back to back), and the band passes load a band's constants ONCE for the four lines.  Same functions
+// on the same numbers, the partial sums added in the same order: the same numbers as energy_line(), bit for bit
+// (tests/test_energy_forms.py compares the two).  A million lines, every one its own sun: 36.5 -> 27 ms at 2101 bands,
+// 22.7 -> 16 ms at 7 - the latter is the fp64 issue time of the geometry (8300 wave instructions per line: 15 ms).
+constexpr int ENERGY_BATCH = 4;                   // x ENERGY_ZENITH_NODES = the lanes of one wave
+struct EnergySharedBatch {
+    double part[ENERGY_BATCH][5][ENERGY_THREADS / 64];
+    double abar[ENERGY_BATCH][5];
+    double sun[ENERGY_BATCH][6];
+    RowTerms row[ENERGY_BATCH][ENERGY_ZENITH_NODES];
+};
+
+__global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(const gort_canopy *__restrict__ canopies,
+                                                                              const double *__restrict__ Lall, int nw,
+                                                                              const double *__restrict__ angles, long nA,
+                                                                              const double *__restrict__ nodes,
+                                                                              double *__restrict__ energy_all,
+                                                                              const unsigned *__restrict__ uniq)
+{
+    __shared__ EnergySharedBatch sh;
+    const long member = blockIdx.y;
+    const gort_canopy &c = canopies[member];
+    const double *__restrict__ L = Lall + member * L_NSLOT * nw;
+    double *__restrict__ energy = energy_all + member * nA * nw * 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long n_lines = uniq[0];
+    const double node_vaa = nodes[3 * tid], w = nodes[3 * tid + 2];
+    const double row_vza = nodes[3 * (lane & (ENERGY_ZENITH_NODES - 1)) + 1];        // the zenith node whose row this lane evaluates
+    for (long base = (long)blockIdx.x * ENERGY_BATCH; base < n_lines; base += (long)gridDim.x * ENERGY_BATCH) {
+        asm volatile("" ::: "memory");                       // keeps the body's loads where they are used (see energy_list_kernel)
+        const int lines_here = n_lines - base < ENERGY_BATCH ? (int)(n_lines - base) : ENERGY_BATCH;
+        // ---- row terms: ONE wave, sixteen lanes per line of the batch (the 4 x 16 chains cost the issue slots of one) ----
+        if (wave == 0 && (lane >> 4) < lines_here) {
+            const long a = (long)uniq[1 + base + (lane >> 4)];
+            double vza, sza, saa, raa;
+            normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
+            row_terms(c, row_vza, sza, sh.row[lane >> 4][lane & (ENERGY_ZENITH_NODES - 1)], false);
+        }
+        __syncthreads();
+        // ---- every thread its node, line after line ----
+        for (int b = 0; b < lines_here; ++b) {
+            const long a = (long)uniq[1 + base + b];
+            double vza, sza, saa, raa;
+            normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
+            {
+#pragma clang fp contract(off)
+                raa = saa - node_vaa;
+                raa = fabs((raa - 2 * PI * (int)(0.5 + raa * INV_PI * 0.5)));
+            }
+            GeomOut g;
+            finish_angle(c, sh.row[b][tid & (ENERGY_ZENITH_NODES - 1)], raa, g);
+            double rec[GORT_COEF_STRIDE];
+            store_coef(rec, c, g);
+            double part[5] = {w * rec[A_C], w * rec[A_B], w * rec[A_Z], w * rec[A_G], w * rec[A_T]};
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                part[k] = wave_sum(part[k]);
+                if (lane == 0) sh.part[b][k][wave] = part[k];
+            }
+            if (tid == 0) {
+                sh.sun[b][0] = g.sun.fd;  sh.sun[b][1] = g.sun.mu;  sh.sun[b][2] = g.sun.t0;
+                sh.sun[b][3] = g.sun.tp0; sh.sun[b][4] = g.sun.eps; sh.sun[b][5] = g.sun.pn0;
+            }
+        }
+        __syncthreads();
+        if (tid < 5 * ENERGY_BATCH) {                        // the order of energy_line()'s adding threads
+            const int b = tid / 5, k = tid - 5 * b;
+            double x = 0.0;
+            for (int q = 0; q < ENERGY_THREADS / 64; ++q) x += sh.part[b][k][q];
+            sh.abar[b][k] = x;
+        }
+        __syncthreads();
+        // ---- band passes: a band's constants once for the lines of the batch ----
+        for (int i = tid; i < nw; i += ENERGY_THREADS) {
+            const BandTerms t = load_band(L, nw, i);
+            for (int b = 0; b < lines_here; ++b) {
+                const double *abar = sh.abar[b];
+                SunScalars s;
+                s.fd = sh.sun[b][0];  s.mu = sh.sun[b][1];  s.t0 = sh.sun[b][2];  s.tp0 = sh.sun[b][3];  s.eps = sh.sun[b][4];  s.pn0 = sh.sun[b][5];
+                const SunTerms bt = sun_terms(t, s, c.k_open, c.k_openep);
+                const double albedo = dot5(abar[0], abar[1], abar[2], abar[3], abar[4], bt.C0, bt.B, bt.Z, bt.G, bt.T);
+                const double rs = t.rs;
+                // energy balance, Lambertian background (gortt_albedo.c:39-52)
+                const double Fu2 = bt.G * s.pn0 + bt.Z * (1. - s.pn0);
+                const double Fd2 = s.pn0 + bt.Z * (1. - s.pn0) / rs;
+                double *o = energy + ((long)uniq[1 + base + b] * nw + i) * 3;
+                o[0] = albedo;
+                o[1] = 1. - albedo - Fd2 + Fu2;
+                o[2] = Fd2 - Fu2;
+            }
+        }
+        __syncthreads();                                     // rows, sums and sun scalars are done with
+    }
+}
+
 // rows of the lines that share another line's sun direction: energy[line] = energy[rep[line]].  The output is walked as
 // ONE flat array in 1-KiB chunks aligned in absolute address (rows of 3 nw doubles start on 8-byte boundaries only, and
 // HBM wants whole lines per wave store: DESIGN.md 5.1 step 2), in PANELS of K steps x W waves like the flat expansion
@@ -367,7 +467,12 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     if ((rc = check_launch("energy_rep_kernel"))) return rc;
     const unsigned *rep = slot_of;
     const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
-    if (share_rows)
+    const char *pl = getenv("GORT_ENERGY_BATCH");            // 0: one line after the other (tests compare the two)
+    const unsigned batches = (unsigned)((nA + ENERGY_BATCH - 1) / ENERGY_BATCH);
+    if (share_rows && !(pl && atoi(pl) == 0))
+        hipLaunchKernelGGL(energy_list_batched_kernel, dim3(batches < wgs ? batches : wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev,
+                           nw, angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
+    else if (share_rows)
         hipLaunchKernelGGL(energy_list_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
                            angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
     else

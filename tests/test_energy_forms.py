@@ -46,6 +46,13 @@ def _bits(x):
     return np.ascontiguousarray(x).view(np.int64)
 
 
+def _same_bits_nan_for_nan(a, b):
+    """Equal bit for bit where a number stands, NaN where NaN stands (sign and payload of a NaN follow the operand order of
+    the instruction that made it, which differs between the forms)."""
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(_bits(a)[~na], _bits(b)[~nb])
+
+
 def test_row_terms_once_per_zenith_node_same_bits():
     """BASELINE config 4's 91 sun zeniths (the per-line kernel) and a 3000-line stream in which every line has its own sun
     direction (the list kernel behind the sun-direction table), a sun on the horizon and a NaN line among them."""
@@ -81,6 +88,32 @@ def test_row_terms_once_per_zenith_node_same_bits():
         assert bad.size == 0, (k, bad[:10], ang[bad[:3]], a[bad[:1], :2], b[bad[:1], :2])
     assert np.isnan(res["1"][1][9]).all() and np.isfinite(res["1"][1][:5]).all()
     assert np.abs(res["1"][0][:90].sum(axis=2) - 1.0).max() < 1e-12        # albedo + favegt + fasoil = 1
+
+
+@pytest.mark.parametrize("nw,n", [(61, 3001), (2101, 702), (5, 129), (513, 1003)])
+def test_batched_list_kernel_same_bits(nw, n):
+    """energy_list_batched_kernel (four lines per workgroup pass: their row terms side by side on four waves, a band's
+    constants loaded once for the four) against the line-after-line loop (GORT_ENERGY_BATCH=0): every line its own sun, a
+    sun on the horizon, a NaN line, line counts that leave ragged last batches, band counts around one pass of 512."""
+    import torch
+    wl = np.linspace(400.0, 2500.0, nw)
+    rng = np.random.default_rng(nw + n)
+    stream = np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), rng.uniform(0, 89.9, n), rng.uniform(-400, 400, n)], 1)
+    stream[3, 2] = 90.0
+    stream[7, 2] = np.nan
+    stream[n - 1, 2] = 0.0
+    res = {}
+    for pipe in ("1", "0"):
+        os.environ["GORT_ENERGY_BATCH"] = pipe
+        try:
+            e = _engine(wl)
+            res[pipe] = _energy(e, stream, nw, torch, offset=1)
+            e.close()
+        finally:
+            os.environ.pop("GORT_ENERGY_BATCH")
+    assert not (res["1"] == -7.0).any()
+    assert np.isnan(res["1"][7]).all() and np.isfinite(res["1"][:3]).all()
+    assert _same_bits_nan_for_nan(res["1"], res["0"])
 
 
 @pytest.mark.parametrize("nw,n", [(43, 4001), (128, 1501), (2101, 333), (7, 5001)])
