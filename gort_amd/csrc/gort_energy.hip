@@ -249,9 +249,12 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
     const long n_lines = uniq[0];
     const double node_vaa = nodes[3 * tid], w = nodes[3 * tid + 2];
     const double row_vza = nodes[3 * (lane & (ENERGY_ZENITH_NODES - 1)) + 1];        // the zenith node whose row this lane evaluates
-    for (long base = (long)blockIdx.x * ENERGY_BATCH; base < n_lines; base += (long)gridDim.x * ENERGY_BATCH) {
+    // lines per pass: four where that still leaves two workgroups' worth of batches per CU, fewer for short lists (a
+    // million lines of 91 sun directions are a list of 91: one line per workgroup, as many workgroups as lines)
+    const int per_pass = n_lines >= 4 * 512 ? ENERGY_BATCH : (n_lines >= 2 * 512 ? 2 : 1);
+    for (long base = (long)blockIdx.x * per_pass; base < n_lines; base += (long)gridDim.x * per_pass) {
         asm volatile("" ::: "memory");                       // keeps the body's loads where they are used (see energy_list_kernel)
-        const int lines_here = n_lines - base < ENERGY_BATCH ? (int)(n_lines - base) : ENERGY_BATCH;
+        const int lines_here = n_lines - base < per_pass ? (int)(n_lines - base) : per_pass;
         // ---- row terms: ONE wave, sixteen lanes per line of the batch (the 4 x 16 chains cost the issue slots of one) ----
         if (wave == 0 && (lane >> 4) < lines_here) {
             const long a = (long)uniq[1 + base + (lane >> 4)];
@@ -468,9 +471,8 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     const unsigned *rep = slot_of;
     const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
     const char *pl = getenv("GORT_ENERGY_BATCH");            // 0: one line after the other (tests compare the two)
-    const unsigned batches = (unsigned)((nA + ENERGY_BATCH - 1) / ENERGY_BATCH);
     if (share_rows && !(pl && atoi(pl) == 0))
-        hipLaunchKernelGGL(energy_list_batched_kernel, dim3(batches < wgs ? batches : wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev,
+        hipLaunchKernelGGL(energy_list_batched_kernel, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev,
                            nw, angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
     else if (share_rows)
         hipLaunchKernelGGL(energy_list_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,

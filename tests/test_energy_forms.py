@@ -90,11 +90,12 @@ def test_row_terms_once_per_zenith_node_same_bits():
     assert np.abs(res["1"][0][:90].sum(axis=2) - 1.0).max() < 1e-12        # albedo + favegt + fasoil = 1
 
 
-@pytest.mark.parametrize("nw,n", [(61, 3001), (2101, 702), (5, 129), (513, 1003)])
+@pytest.mark.parametrize("nw,n", [(61, 3001), (2101, 702), (5, 129), (513, 1503)])
 def test_batched_list_kernel_same_bits(nw, n):
     """energy_list_batched_kernel (four lines per workgroup pass: their row terms side by side on four waves, a band's
     constants loaded once for the four) against the line-after-line loop (GORT_ENERGY_BATCH=0): every line its own sun, a
-    sun on the horizon, a NaN line, line counts that leave ragged last batches, band counts around one pass of 512."""
+    sun on the horizon, a NaN line, list lengths that take four, two and one line per pass and leave ragged last batches, band
+    counts around one pass of 512."""
     import torch
     wl = np.linspace(400.0, 2500.0, nw)
     rng = np.random.default_rng(nw + n)
