@@ -438,7 +438,6 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
         }
         long splits = (nw + ENERGY_THREADS - 1) / ENERGY_THREADS;
         if (splits * nA * n_members > (long)cus) splits = (long)cus / (nA * n_members);
-        if (const char *v = getenv("GORT_ENERGY_BAND_SPLITS")) splits = atol(v);         // tests, experiments
         if (splits < 1) splits = 1;
         if (splits > 64) splits = 64;
         const dim3 grid((unsigned)nA, (unsigned)n_members, (unsigned)splits);

@@ -278,7 +278,6 @@ static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_gr
         const long total = rows * per_row, slots = geom_slots(4, GEOM_SPAN_THREADS), span_max = (long)(GEOM_SPAN_ROWS - 2) * per_row;
         long G = (total + 2 * GEOM_SPAN_THREADS - 1) / (2 * GEOM_SPAN_THREADS);
         if (G > slots) G = slots;
-        if (const char *v = getenv("GORT_GRID_WGS")) { if (atol(v) > 0) G = atol(v); }      // experiments (tools/shape_scan.py --grid)
         if ((total + G - 1) / G > span_max) G = (total + span_max - 1) / span_max;
         hipLaunchKernelGGL((geometry_grid_kernel<GEOM_SPAN_ROWS, true>), dim3((unsigned)G), dim3(GEOM_SPAN_THREADS), 0, s, canopy_dev, g, row_begin, rows,
                            coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
