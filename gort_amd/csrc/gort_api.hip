@@ -672,7 +672,7 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
         e->stream_form = 0;
         return rc;
     }
-    if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, large ? 1 : 0, e->stream))) return rc;
+    if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, large ? 1 : 0, e->stream, K_dev != nullptr || scomp_dev != nullptr))) return rc;
     GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
     rc = launch_expand_stream(c, e->L.as<double>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw, coef, nA, rsurf_dev,
                               scomp_dev, xcd_slots, e->stream, false);

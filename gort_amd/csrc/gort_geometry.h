@@ -197,11 +197,22 @@ __device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa
 }
 
 // areal proportions + hot spot for one normalised geometry
-__device__ void geometry_core(const gort_canopy &c, double vza, double sza, double raa, GeomOut &o)
+__device__ void geometry_core(const gort_canopy &c, double vza, double sza, double raa, GeomOut &o,
+                              bool reference_route_at_horizon = true)
 {
     RowTerms r;
-    row_terms(c, vza, sza, r);
+    row_terms(c, vza, sza, r, reference_route_at_horizon);
     finish_angle(c, r, raa, o);
+}
+
+// May a stream line skip the reference's route at the horizon?  Where the line was typed with a zenith of exactly +-90
+// degrees and only its reflectances leave the kernel: those are NaN by either route (see row_terms), and the route's
+// library calls cost the whole wave of such a line 10 us (BASELINE config 2 is the principal plane from -90 to 90: two of
+// its three waves held one such lane each and took 15 us where the third took 4.3).  Lines merely NEAR the horizon keep the
+// route, and so does every line whose viewed proportions or component spectra are asked for (finite at 90 degrees).
+__device__ __forceinline__ bool stream_line_takes_reference_route(const double *__restrict__ angle_line, bool proportions_wanted)
+{
+    return proportions_wanted || !(fabs(angle_line[0]) == 90.0 || fabs(angle_line[2]) == 90.0);
 }
 
 __device__ inline void store_coef(double *rec, const gort_canopy &c, const GeomOut &g)

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
                                                                const double *__restrict__ angles, long nA,
                                                                double *__restrict__ coef, double *__restrict__ K,
                                                                int layout, const double *__restrict__ L, int nw,
-                                                               double *__restrict__ rsurf)
+                                                               double *__restrict__ rsurf, int proportions_wanted)
 {
     const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= nA) return;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
     GeomOut g;
-    geometry_core(c, vza, sza, raa, g);
+    geometry_core(c, vza, sza, raa, g, stream_line_takes_reference_route(angles + 4 * a, K != nullptr || proportions_wanted != 0));
     if (FUSED) {
         double rec[GORT_COEF_STRIDE];
         store_coef(rec, c, g);
@@ -196,13 +196,13 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
 
 // n_members > 1: blockIdx.z = member, canopy_dev[m], records coef_dev[m][nA][16], proportions K_dev[m][nA][4]
 int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const double *angles_dev, long nA,
-                           double *coef_dev, double *K_dev, int layout, void *stream)
+                           double *coef_dev, double *K_dev, int layout, void *stream, bool proportions_wanted)
 {
     if (nA <= 0 || n_members <= 0) return GORT_OK;
     if (n_members > 65535) return fail(GORT_EINVAL, "geometry: %d members in one launch (max 65535)", n_members);
     hipLaunchKernelGGL(geometry_stream_kernel<false>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
                        (hipStream_t)stream, canopy_dev, angles_dev, nA, coef_dev, K_dev, layout, (const double *)nullptr, 0,
-                       (double *)nullptr);
+                       (double *)nullptr, proportions_wanted ? 1 : 0);
     return check_launch("geometry_stream_kernel");
 }
 
@@ -220,7 +220,7 @@ int launch_geometry_stream_fused(const gort_canopy *canopy_dev, int n_members, c
     if (nA <= 0 || nw < 0 || n_members <= 0 || (nw == 0 && !K_dev)) return GORT_OK;      // nw = 0: the proportions K alone
     if (n_members > 65535) return fail(GORT_EINVAL, "geometry: %d members in one launch (max 65535)", n_members);
     hipLaunchKernelGGL(geometry_stream_kernel<true>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
-                       (hipStream_t)stream, canopy_dev, angles_dev, nA, (double *)nullptr, K_dev, 0, L_dev, nw, rsurf_dev);
+                       (hipStream_t)stream, canopy_dev, angles_dev, nA, (double *)nullptr, K_dev, 0, L_dev, nw, rsurf_dev, 0);
     return check_launch("geometry_stream_kernel<fused>");
 }
 

@@ -75,7 +75,9 @@ void interface_transmissivity_tables(const double **t12, const double **talf);  
 // layout 0: classic records (CoefSlot); 1: the stream family's LineTerms (gort_device.h), what the stream
 // expansions of large streams read (stream_is_large)
 int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const double *angles_dev, long nA,
-                           double *coef_dev, double *K_dev, int layout, void *stream);
+                           double *coef_dev, double *K_dev, int layout, void *stream, bool proportions_wanted);
+// proportions_wanted: the records feed component spectra or printed proportions - every line near the horizon takes the
+// reference's route; false: reflectances only, lines typed at exactly +-90 degrees skip it (gort_geometry.h)
 // streams of few bands without component spectra: geometry and samples in ONE launch, no records (same bits as the
 // two-kernel path: the same functions on the same record, kept in registers)
 bool stream_fuses(int nw, bool want_scomp);

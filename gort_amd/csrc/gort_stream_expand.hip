@@ -257,7 +257,7 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
     if (n_members > 65535) return fail(GORT_EINVAL, "members stream: %d members in one launch (max 65535)", n_members);
     if (stream_fuses(nw, false))
         return launch_geometry_stream_fused(canopies_dev, n_members, L_dev, nw, angles_dev, nA, rsurf_dev, nullptr, stream);
-    int rc = launch_geometry_stream(canopies_dev, n_members, angles_dev, nA, coef_dev, nullptr, 0, stream);
+    int rc = launch_geometry_stream(canopies_dev, n_members, angles_dev, nA, coef_dev, nullptr, 0, stream, false);
     if (rc) return rc;
     hipLaunchKernelGGL(expand_stream_kernel<false>, dim3((unsigned)((n + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
                        (hipStream_t)stream, canopies_dev, L_dev, nw, coef_dev, n, rsurf_dev, (double *)nullptr, 0);

@@ -61,3 +61,27 @@ def test_node_partition_equals_row_partition(name, nw):
         assert not (out["0"] == -7.0).any()
         assert np.array_equal(out["0"].view(np.int64), out["1"].view(np.int64)), (name, nw, r0, r1)
     e.close()
+
+
+def test_one_member_of_an_ensemble_takes_the_node_partition_with_its_own_canopy():
+    """A launch that covers exactly member 1 of three is a single-member launch (partitioned by nodes, its canopy and band
+    table read once): the same bits as that member's window of the launch over all three (partitioned by rows)."""
+    import torch
+    g = _grid((0.0, 15.0, 5), (0.0, 10.0, 8), (0.0, 2.0, 181))
+    rows = g.nsza * g.nvza
+    wl = np.linspace(400.0, 2500.0, 130)                      # member grids need >= 128 bands (records + LUT kernel)
+    members = [api.gap_probabilities(api.make_canopy(lai=x)) for x in (1.5, 3.0, 4.5)]
+    spectra = np.stack([np.stack(api.spectra(wl)) * f for f in (1.0, 0.9, 0.8)])
+    e = api.Engine()
+    e.set_members(members, spectra)
+    per = rows * g.nphi * wl.size
+    every = torch.empty((3 * per,), dtype=torch.float64, device="cuda")
+    e.rsurf_members_grid_dev(g, 0, 3, every)
+    one = torch.full((per + 8,), -7.0, dtype=torch.float64, device="cuda")
+    e.rsurf_members_grid_dev(g, 1, 2, one[:per])
+    e.synchronize()
+    assert float(one[per:].max()) == -7.0
+    a, b = one[:per].cpu().numpy(), every[per:2 * per].cpu().numpy()
+    assert np.array_equal(a.view(np.int64), b.view(np.int64))
+    assert not np.array_equal(a, every[:per].cpu().numpy())
+    e.close()

@@ -217,3 +217,36 @@ def test_flat_kernel_panel_shapes_write_the_same_bits():
         assert line, run.stdout.decode()[-500:]
         digests[str(shape)] = line[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+@pytest.mark.parametrize("nw", [1, 40, 300])
+def test_lines_typed_at_90_degrees_skip_the_reference_route_only_for_reflectances(nw):
+    """A line whose zenith was typed as exactly +-90 degrees has NaN reflectances by either arithmetic, and its wave does not
+    walk the reference's route when nothing but reflectances is asked for (gort_geometry.h,
+    stream_line_takes_reference_route): the principal plane of BASELINE config 2 with and without the viewed proportions
+    - the same bits wherever a number stands, NaN where NaN stands, and the proportions of the 90-degree lines finite as
+    the reference prints them (gortt.c:424-449; the `horizon` CLI golden holds their digits).  Fused (1 band), line kernel
+    (40) and records + flat kernel (300)."""
+    import torch
+    wl = np.linspace(450.0, 2400.0, nw)
+    e = api.Engine()
+    e.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
+    e.set_spectra(*api.spectra(wl))
+    n = 4096 if nw == 40 else (20000 if nw == 300 else 181)          # enough samples for the form the band count names
+    vza = np.resize(np.arange(-90.0, 91.0), n)
+    ang = np.stack([vza, np.zeros(n), np.full(n, 30.0), np.zeros(n)], 1)
+    ang[5, 2] = 90.0                                                  # a sun on the horizon too
+    a = torch.as_tensor(ang, device="cuda")
+    plain = torch.empty((n, nw), dtype=torch.float64, device="cuda")
+    with_k = torch.empty((n, nw), dtype=torch.float64, device="cuda")
+    K = torch.empty((n, 4), dtype=torch.float64, device="cuda")
+    e.rsurf_stream_dev(a, plain)
+    e.rsurf_stream_dev(a, with_k, None, K)
+    e.synchronize()
+    p, q, k = plain.cpu().numpy(), with_k.cpu().numpy(), K.cpu().numpy()
+    at90 = (np.abs(ang[:, 0]) == 90.0) | (ang[:, 2] == 90.0)
+    assert np.isnan(p[at90]).all() and np.isnan(q[at90]).all()
+    assert np.isfinite(p[~at90]).all()
+    assert np.array_equal(p[~at90].view(np.int64), q[~at90].view(np.int64))
+    assert np.isfinite(k[np.abs(ang[:, 0]) == 90.0]).all()
+    e.close()
