@@ -232,7 +232,7 @@ def test_lines_typed_at_90_degrees_skip_the_reference_route_only_for_reflectance
     e = api.Engine()
     e.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
     e.set_spectra(*api.spectra(wl))
-    n = 4096 if nw == 40 else (20000 if nw == 300 else 181)          # enough samples for the form the band count names
+    n = 8192 if nw == 40 else (20000 if nw == 300 else 181)          # enough samples for the form the band count names
     vza = np.resize(np.arange(-90.0, 91.0), n)
     ang = np.stack([vza, np.zeros(n), np.full(n, 30.0), np.zeros(n)], 1)
     ang[5, 2] = 90.0                                                  # a sun on the horizon too
