@@ -1,6 +1,7 @@
 """Build libgort_amd.so (HIP kernels + C ABI, gfx950) and the `gortt` drop-in executable.
 
     python -m gort_amd.build [--force]
+    python -m gort_amd.build --stamps        (a measuring build, gort_amd/libgort_amd_stamps.so: csrc/gort_stamps.h)
 
 hipcc cross-compiles for gfx950 without a GPU.  Everything is built in-tree:
 gort_amd/libgort_amd.so and gort_amd/bin/gortt travel to the GPU box with the
@@ -57,6 +58,24 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+def build_stamps():
+    """gort_amd/libgort_amd_stamps.so: the same library with -DGORT_STAMPS (csrc/gort_stamps.h; tools/stamps.py) - a
+    measuring build beside the product library, never loaded unless GORT_AMD_LIB names it."""
+    obj = os.path.join(SRC, "build_stamps")
+    os.makedirs(obj, exist_ok=True)
+    cc = hipcc()
+    common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-DGORT_STAMPS", "-I" + os.path.join(ROOT, "include"),
+              "-I" + SRC, "--offload-arch=" + ARCH]
+    objs = []
+    for src, extra in UNITS:
+        o = os.path.join(obj, os.path.splitext(src)[0] + ".o")
+        _run([cc] + common + extra + ["-c", os.path.join(SRC, src), "-o", o])
+        objs.append(o)
+    lib = os.path.join(PKG, "libgort_amd_stamps.so")
+    _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs + ["-ldl"])
+    return lib
+
+
 def build(force=False, verbose_resources=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
@@ -86,4 +105,7 @@ def build(force=False, verbose_resources=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose_resources="--resources" in sys.argv)
+    if "--stamps" in sys.argv:
+        build_stamps()
+    else:
+        build(force="--force" in sys.argv, verbose_resources="--resources" in sys.argv)

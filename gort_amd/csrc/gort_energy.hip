@@ -7,6 +7,10 @@
 #include "gort_flat.h"
 #include "gort_geometry.h"
 
+#include "gort_stamps.h"
+
+GORT_STAMPS_DEFINE(energy)
+
 namespace gort {
 namespace {
 
@@ -117,6 +121,8 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
                                             double *__restrict__ energy, long a, EnergyShared &sh, int band_begin, int band_end)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    GORT_STAMPS_BEGIN();
+    GORT_STAMP(0);
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
     // node geometry (gortt_albedo.c:91-105): vaa = pi + pi x_i in (0, 2pi); vza = acos(x_j)
@@ -134,6 +140,7 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
         // as long as the others (8.8 against 4.5 us of row terms), and a launch ends with its longest line
         if (tid < ENERGY_ZENITH_NODES) row_terms(c, nodes[3 * tid + 1], sza, sh.row[tid], false);
         __syncthreads();
+        GORT_STAMP(1);                                       // row terms
         finish_angle(c, sh.row[tid & (ENERGY_ZENITH_NODES - 1)], raa, g);
     } else {
         geometry_core(c, nodes[3 * tid + 1], sza, raa, g);
@@ -141,6 +148,8 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     double rec[GORT_COEF_STRIDE];
     store_coef(rec, c, g);
     double part[5] = {w * rec[A_C], w * rec[A_B], w * rec[A_Z], w * rec[A_G], w * rec[A_T]};
+    GORT_STAMP_ANCHOR(part[4]);
+    GORT_STAMP(2);                                           // this thread's node
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         part[k] = wave_sum(part[k]);
@@ -157,6 +166,7 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
         sh.abar[tid] = t;
     }
     __syncthreads();
+    GORT_STAMP(3);                                           // the five sums
     SunScalars s;
     s.fd = sh.sun[0];  s.mu = sh.sun[1];  s.t0 = sh.sun[2];  s.tp0 = sh.sun[3];  s.eps = sh.sun[4];  s.pn0 = sh.sun[5];
     const double aC = sh.abar[0], aB = sh.abar[1], aZ = sh.abar[2], aG = sh.abar[3], aT = sh.abar[4];
@@ -172,6 +182,8 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
         o[1] = 1. - albedo - Fd2 + Fu2;
         o[2] = Fd2 - Fu2;
     }
+    GORT_STAMP(4);                                           // band passes
+    GORT_STAMPS_END(energy, a, tid == 0 && band_begin == 0);
 }
 
 // blockIdx.x = angle line, blockIdx.y = ensemble member (its canopy and band tables); the nA angle lines are shared by
@@ -252,8 +264,10 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
     // lines per pass: four where that still leaves two workgroups' worth of batches per CU, fewer for short lists (a
     // million lines of 91 sun directions are a list of 91: one line per workgroup, as many workgroups as lines)
     const int per_pass = n_lines >= 4 * 512 ? ENERGY_BATCH : (n_lines >= 2 * 512 ? 2 : 1);
+    GORT_STAMPS_BEGIN();
     for (long base = (long)blockIdx.x * per_pass; base < n_lines; base += (long)gridDim.x * per_pass) {
         asm volatile("" ::: "memory");                       // keeps the body's loads where they are used (see energy_list_kernel)
+        GORT_STAMP(0);
         const int lines_here = n_lines - base < per_pass ? (int)(n_lines - base) : per_pass;
         // ---- row terms: ONE wave, sixteen lanes per line of the batch (the 4 x 16 chains cost the issue slots of one) ----
         if (wave == 0 && (lane >> 4) < lines_here) {
@@ -263,6 +277,7 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
             row_terms(c, row_vza, sza, sh.row[lane >> 4][lane & (ENERGY_ZENITH_NODES - 1)], false);
         }
         __syncthreads();
+        GORT_STAMP(1);                                       // row terms of the batch
         // ---- every thread its node, line after line ----
         for (int b = 0; b < lines_here; ++b) {
             const long a = (long)uniq[1 + base + b];
@@ -289,6 +304,7 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
             }
         }
         __syncthreads();
+        GORT_STAMP(2);                                       // nodes of the batch
         if (tid < 5 * ENERGY_BATCH) {                        // the order of energy_line()'s adding threads
             const int b = tid / 5, k = tid - 5 * b;
             double x = 0.0;
@@ -296,6 +312,7 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
             sh.abar[b][k] = x;
         }
         __syncthreads();
+        GORT_STAMP(3);                                       // sums
         // ---- band passes: a band's constants once for the lines of the batch ----
         for (int i = tid; i < nw; i += ENERGY_THREADS) {
             const BandTerms t = load_band(L, nw, i);
@@ -315,6 +332,8 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
                 o[2] = Fd2 - Fu2;
             }
         }
+        GORT_STAMP(4);                                       // band passes
+        GORT_STAMPS_END(energy, base / per_pass, tid == 0 && blockIdx.y == 0);
         __syncthreads();                                     // rows, sums and sun scalars are done with
     }
 }

@@ -13,6 +13,9 @@
 #include <cstdlib>
 
 #include "gort_geometry.h"
+#include "gort_stamps.h"
+
+GORT_STAMPS_DEFINE(geometry)
 
 namespace gort {
 namespace {
@@ -32,14 +35,20 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
                                                                double *__restrict__ rsurf, int proportions_wanted)
 {
     const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    GORT_STAMPS_BEGIN();
+    GORT_STAMP(0);
     if (a >= nA) return;
     // blockIdx.z = ensemble member: its canopy, its nA records (the angle lines are shared)
     const long member = blockIdx.z;
     const gort_canopy &c = canopy[member];
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
+    GORT_STAMP_ANCHOR(raa);
+    GORT_STAMP(1);                                           // the angle line is there
     GeomOut g;
     geometry_core(c, vza, sza, raa, g, stream_line_takes_reference_route(angles + 4 * a, K != nullptr || proportions_wanted != 0));
+    GORT_STAMP_ANCHOR(g.A);
+    GORT_STAMP(2);                                           // geometry
     if (FUSED) {
         double rec[GORT_COEF_STRIDE];
         store_coef(rec, c, g);
@@ -61,6 +70,8 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
         double *k = K + 4 * (member * nA + a);
         k[0] = g.Kc;  k[1] = g.Kg;  k[2] = g.Kt;  k[3] = g.Kz;
     }
+    GORT_STAMP(3);                                           // samples / record stored
+    GORT_STAMPS_END(geometry, a >> 6, (a & 63) == 0);
 }
 
 // grid nodes generated from indices; identical to streaming "vza phi sza 0" (SURVEY 8d, C3).
@@ -109,6 +120,8 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
     // gortt_brdf.c:23-100, 118-169, 650-666): node l' = nphi - 1 - l is the mirror image of node l.  Half the nodes
     // are evaluated and each result is written twice (the device's cos of 2 pi - x and of x differ in the last place,
     // as the reference's do: the images agree with their own evaluation to rounding, 1e-15).
+    GORT_STAMPS_BEGIN();
+    GORT_STAMP(0);
     const int per_row = mirror ? (g.nphi + 1) / 2 : g.nphi;
     long first;                                                         // first row of this block, relative to row_begin
     int rows_here, rel0, rel1;                                          // its nodes, counted from node 0 of row `first`
@@ -139,6 +152,7 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         s_sza_deg[threadIdx.x] = sza_deg;
     }
     __syncthreads();
+    GORT_STAMP(1);                                           // row terms
     // ONE_MEMBER: what the node loop reads of the canopy and (fused form) the first band's constants, once, ahead of the loop
     const gort_canopy &c0 = canopies[member0];
     const double ko0 = c0.k_open, kep0 = c0.k_openep;
@@ -188,6 +202,8 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
             if (i2 >= 0) store_coef(coef + i2 * GORT_COEF_STRIDE, c, o);
         }
     }
+    GORT_STAMP(2);                                           // nodes
+    GORT_STAMPS_END(geometry, (long)blockIdx.x * 4 + (threadIdx.x >> 6), (threadIdx.x & 63) == 0);
 }
 
 }  // namespace

@@ -27,6 +27,10 @@
 
 #include "gort_geometry.h"
 
+#include "gort_stamps.h"
+
+GORT_STAMPS_DEFINE(lines)
+
 namespace gort {
 namespace {
 
@@ -86,6 +90,8 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
 {
     extern __shared__ __attribute__((aligned(16))) double s_ring[];
     const int lane = threadIdx.x;
+    GORT_STAMPS_BEGIN();
+    GORT_STAMP(0);
     const long a0 = (long)blockIdx.x * 64;
     const int lines_here = nA - a0 < 64 ? (int)(nA - a0) : 64;
     const bool live = lane < lines_here;
@@ -109,6 +115,8 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         }
     }
 
+    GORT_STAMP_ANCHOR(l.alpha);
+    GORT_STAMP(1);                                           // the line's geometry and terms
     // ---- where the wave's span lies: positions are relative to `origin`, a 256-B aligned address at or below its
     // first element (never dereferenced below `out`)
     const int base_off = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & (RING - 1));
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         band_wait(A);                                          // the last request may still be on its way
     }
     emit_full(m - 1);
+    GORT_STAMP(2);                                           // band blocks and their cache lines
 
     // ---- the cache lines between rows: my head completes the line my predecessor's tail began
     {
@@ -228,6 +237,8 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
             emit_cache_line<NT>(s_ring, 0, pitch, hi - 16, g0, hi, q, origin);
         }
     }
+    GORT_STAMP(3);                                           // seams
+    GORT_STAMPS_END(lines, blockIdx.x, lane == 0);
 }
 
 }  // namespace
