@@ -87,7 +87,7 @@ DECLARED_SYMBOLS = [
 
 #: include/gort_amd_tuning.h: measurement and tuning hooks, not part of the drop-in boundary
 TUNING_SYMBOLS = [
-    "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_stream_form",
+    "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_time_streams", "gort_engine_stream_form",
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
     "gort_engine_probe_store_pattern", "gort_selftest_index_math",
 ]
@@ -140,6 +140,7 @@ def lib():
         L.gort_pipe_destroy.argtypes = [C.c_void_p]
         L.gort_pipe_destroy.restype = None
         L.gort_engine_stream_form.argtypes = [C.c_void_p]
+        L.gort_engine_time_streams.argtypes = [C.c_void_p, C.c_int]
         L.gort_engine_last_stream_ms.argtypes = [C.c_void_p]
         L.gort_engine_last_stream_ms.restype = D
         L.gort_engine_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -601,6 +602,10 @@ class Engine:
         if m < 0:
             _check(m)
         return {0: "narrow", 1: "flat", 2: "lines"}[m]
+
+    def time_streams(self, on=True):
+        """Record the two events last_stream_ms() reads around the expansion stage of every stream call (6 us per call)."""
+        _check(lib().gort_engine_time_streams(self.h, 1 if on else 0))
 
     def last_stream_ms(self):
         return lib().gort_engine_last_stream_ms(self.h)

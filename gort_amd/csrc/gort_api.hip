@@ -75,7 +75,8 @@ struct gort_engine {
     DevBuf edup;                         // sun-direction table of the energy path (gort_energy.hip)
     bool energy_dedup = true;            // GORT_ENERGY_DEDUP=0: every line evaluated (tests compare the two)
     int stream_form = 0;                 // kernel family of the last stream call: 0 narrow, 1 flat panels (gort_amd_tuning.h)
-    hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call
+    hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call, if asked for
+    bool time_streams = false;           // gort_engine_time_streams: the two events cost a short call 6 us of its 18
     char *stage = nullptr;               // pinned staging of the setters' small uploads (stage_begin / stage_h2d)
     size_t stage_cap = 0, stage_off = 0;
     hipEvent_t ev_stage = nullptr;
@@ -643,14 +644,15 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     if ((rc = require_ready(e, "gort_rsurf_stream_dev"))) return rc;
     if (nA < 0 || (nA > 0 && (!angles_dev || !rsurf_dev))) return fail(GORT_EINVAL, "gort_rsurf_stream_dev: bad argument");
     if (nA == 0) return GORT_OK;
-    for (int i = 0; i < 2; ++i)
+    const bool timed = e->time_streams;
+    for (int i = 0; timed && i < 2; ++i)
         if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
     // 17 ... ~250 bands (all the reference's command line can read): one kernel from the angle line to its row
     if (stream_takes_lines_kernel(e->nw, nA, scomp_dev != nullptr)) {
-        GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
+        if (timed) GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
         rc = launch_stream_lines(e->canopy.as<gort_canopy>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw,
                                  angles_dev, nA, rsurf_dev, K_dev, e->stream);
-        GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
+        if (timed) GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
         e->stream_form = 2;
         return rc;
     }
@@ -666,17 +668,17 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     const gort_canopy *c = e->canopy.as<gort_canopy>();          // member 0
     const bool large = stream_is_large(e->nw, nA, scomp_dev != nullptr);
     if (stream_fuses(e->nw, scomp_dev != nullptr)) {
-        GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
+        if (timed) GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
         rc = launch_geometry_stream_fused(c, 1, e->L.as<double>(), e->nw, angles_dev, nA, rsurf_dev, K_dev, e->stream);
-        GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
+        if (timed) GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
         e->stream_form = 0;
         return rc;
     }
     if ((rc = launch_geometry_stream(c, 1, angles_dev, nA, coef, K_dev, large ? 1 : 0, e->stream, K_dev != nullptr || scomp_dev != nullptr))) return rc;
-    GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
+    if (timed) GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
     rc = launch_expand_stream(c, e->L.as<double>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw, coef, nA, rsurf_dev,
                               scomp_dev, xcd_slots, e->stream, false);
-    GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
+    if (timed) GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
     e->stream_form = large ? 1 : 0;
     return rc;
 }
@@ -821,9 +823,16 @@ extern "C" int gort_engine_stream_form(gort_engine *e)
     return e->stream_form;
 }
 
+extern "C" int gort_engine_time_streams(gort_engine *e, int on)
+{
+    if (!e) return fail(GORT_EINVAL, "gort_engine_time_streams: null engine");
+    e->time_streams = on != 0;
+    return GORT_OK;
+}
+
 extern "C" double gort_engine_last_stream_ms(gort_engine *e)
 {
-    if (!e || !e->ev_stream[1]) return -1.0;
+    if (!e || !e->time_streams || !e->ev_stream[1]) return -1.0;
     float ms = 0.f;
     if (hipEventSynchronize(e->ev_stream[1]) != hipSuccess ||
         hipEventElapsedTime(&ms, e->ev_stream[0], e->ev_stream[1]) != hipSuccess)

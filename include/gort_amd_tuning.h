@@ -19,7 +19,11 @@ extern "C" {
 /* average duration (ms) of the LUT expansion kernel (expand_flat_kernel) over the launches since the last call
  * (up to 512 are kept); <0 if none */
 double gort_engine_last_expand_ms(gort_engine *e);
-/* duration (ms) of the expansion stage of the last gort_rsurf_stream[_dev] call; <0 if none */
+/* duration (ms) of the expansion stage of the last gort_rsurf_stream[_dev] call; <0 if none, or if the engine was not asked
+ * to time its stream calls: the two events around the stage cost every call 6 us on the device's queue (an empty kernel:
+ * launch + synchronisation 12.1 us, with an event in front and behind 18.2, tools/probes/clock_probe.hip) - a third of a
+ * short call like BASELINE config 2 - so they are recorded only after gort_engine_time_streams(e, 1) */
+int    gort_engine_time_streams(gort_engine *e, int on);
 double gort_engine_last_stream_ms(gort_engine *e);
 
 /* ---- which kernel family expanded the last gort_rsurf_stream[_dev] call ----

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 __global__ __launch_bounds__(256) void chain_kernel(double *out, long long *ticks, int chain, int ilp)
@@ -42,8 +43,39 @@ __global__ __launch_bounds__(256) void chain_kernel(double *out, long long *tick
     if (blockIdx.x == 0 && threadIdx.x == 0) { ticks[0] = t1 - t0;  ticks[1] = w1 - w0; }
 }
 
+__global__ void empty_kernel(long long *t) { if (t && threadIdx.x == 0) t[2] = wall_clock64(); }
+
+// the floor under every short call: one empty kernel on a non-blocking stream, launch to the return of the synchronisation
+static void launch_floor()
+{
+    hipStream_t s;
+    hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);  hipEventCreate(&e1);
+    long long *t;
+    hipMalloc(&t, 64);
+    for (int variant = 0; variant < 3; ++variant) {
+        std::vector<double> us;
+        for (int i = 0; i < 2200; ++i) {
+            const auto l0 = std::chrono::steady_clock::now();
+            if (variant == 2) hipEventRecord(e0, s);
+            hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, t);
+            if (variant == 2) hipEventRecord(e1, s);
+            if (variant == 1) hipStreamSynchronize(0);          // a second, idle stream synchronised first
+            hipStreamSynchronize(s);
+            const auto l1 = std::chrono::steady_clock::now();
+            if (i >= 200) us.push_back(std::chrono::duration<double>(l1 - l0).count() * 1e6);
+        }
+        std::sort(us.begin(), us.end());
+        printf("empty kernel, launch + stream synchronisation%s: min %.1f  median %.1f  p90 %.1f us\n",
+               variant == 0 ? "" : (variant == 1 ? " (an idle stream synchronised first)" : " (an event recorded in front and behind)"),
+               us[0], us[us.size() / 2], us[us.size() * 9 / 10]);
+    }
+}
+
 int main(int argc, char **argv)
 {
+    launch_floor();
     const int chain = argc > 1 ? atoi(argv[1]) : 8192;
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);

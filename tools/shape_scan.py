@@ -33,8 +33,12 @@ for n, nw in ((1000000, 4), (1000000, 7), (1000000, 16), (1000000, 17), (1000000
         eng.rsurf_stream_dev(a, out)
         eng.synchronize()
     ex, wall = [], []
+    eng.time_streams(False)                    # the call as a user has it: no events around the expansion stage
     for _ in range(15):
-        t0 = time.perf_counter(); eng.rsurf_stream_dev(a, out); eng.synchronize(); wall.append(time.perf_counter() - t0); ex.append(eng.last_stream_ms() * 1e-3)
+        t0 = time.perf_counter(); eng.rsurf_stream_dev(a, out); eng.synchronize(); wall.append(time.perf_counter() - t0)
+    eng.time_streams(True)                     # the stage alone, by the engine's events (they cost the call 6 us)
+    for _ in range(15):
+        eng.rsurf_stream_dev(a, out); eng.synchronize(); ex.append(eng.last_stream_ms() * 1e-3)
     e, w = float(np.median(ex)), float(np.median(wall))
     b = n * nw * 8 + n * 32
     # expansion-equivalent: the samples' bytes over what the call takes beyond the geometry stage of as many lines

@@ -4,7 +4,7 @@ measuring build of the library (python -m gort_amd.build --stamps -> gort_amd/li
 the kernels record the 100 MHz wall clock at their phase boundaries, per workgroup or wave, with the XCC and HW_ID of the
 writing wave) and prints the phases and how the units of a launch lie in time.
 
-    python tools/stamps.py [c2] [c3] [c4] [energy] [lines]          (default: all; output kept in profiles/r04/stamps.log)
+    python tools/stamps.py [c2] [c3] [c4] [energy] [lines] [narrow]        (default: all; output kept in profiles/r04/stamps.log)
 
 The product library has none of this compiled in; the numbers of a stamped kernel are a few per cent above the product's."""
 import collections
@@ -176,7 +176,25 @@ def run_lines():
         del out
 
 
+def run_narrow():
+    n = 1000000
+    rng = np.random.default_rng(0)
+    a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), rng.uniform(0, 360, n)], 1), device="cuda")
+    for nw in (7, 16):
+        eng = api.Engine(); eng.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
+        eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
+        out = torch.empty((n, nw), dtype=torch.float64, device="cuda")
+        us, b = once(lambda: eng.rsurf_stream_dev(a, out), eng, "geometry")
+        print("== stream, %d lines x %d bands (geometry_stream_kernel<fused>, unit = wave): call %.1f us, %d waves" % (n, nw, us, len(b)))
+        t = phases(b, ["angle line", "geometry", "samples + stores"])
+        life = t[:, -1] - t[:, 0]
+        cu, simd = placement(b)
+        print("   the lives fill %.0f %% of the wave slots (16 per CU) over the kernel's span" % (100.0 * life.sum() / (len(set(cu.tolist())) * 16 * t[:, -1].max())))
+        eng.close()
+        del out
+
+
 if __name__ == "__main__":
-    want = [w for w in sys.argv[1:] if not w.startswith("-")] or ["c2", "c3", "c4", "energy", "lines"]
+    want = [w for w in sys.argv[1:] if not w.startswith("-")] or ["c2", "c3", "c4", "energy", "lines", "narrow"]
     for w in want:
-        {"c2": run_c2, "c3": run_c3, "c4": run_c4, "energy": run_energy, "lines": run_lines}[w]()
+        {"c2": run_c2, "c3": run_c3, "c4": run_c4, "energy": run_energy, "lines": run_lines, "narrow": run_narrow}[w]()
