@@ -54,7 +54,7 @@ static void launch_floor()
     hipEventCreate(&e0);  hipEventCreate(&e1);
     long long *t;
     hipMalloc(&t, 64);
-    for (int variant = 0; variant < 3; ++variant) {
+    for (int variant = 0; variant < 6; ++variant) {
         std::vector<double> us;
         for (int i = 0; i < 2200; ++i) {
             const auto l0 = std::chrono::steady_clock::now();
@@ -62,13 +62,17 @@ static void launch_floor()
             hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s, t);
             if (variant == 2) hipEventRecord(e1, s);
             if (variant == 1) hipStreamSynchronize(0);          // a second, idle stream synchronised first
-            hipStreamSynchronize(s);
+            if (variant == 3) { while (hipStreamQuery(s) == hipErrorNotReady) { } }
+            else if (variant == 4) { hipEventRecord(e1, s); while (hipEventQuery(e1) == hipErrorNotReady) { } }
+            else if (variant == 5) { hipEventRecord(e1, s); hipEventSynchronize(e1); }
+            else hipStreamSynchronize(s);
             const auto l1 = std::chrono::steady_clock::now();
             if (i >= 200) us.push_back(std::chrono::duration<double>(l1 - l0).count() * 1e6);
         }
         std::sort(us.begin(), us.end());
         printf("empty kernel, launch + stream synchronisation%s: min %.1f  median %.1f  p90 %.1f us\n",
-               variant == 0 ? "" : (variant == 1 ? " (an idle stream synchronised first)" : " (an event recorded in front and behind)"),
+               variant == 0 ? "" : (variant == 1 ? " (an idle stream synchronised first)" : (variant == 2 ? " (an event recorded in front and behind)" :
+               (variant == 3 ? " (hipStreamQuery polled instead)" : (variant == 4 ? " (an event behind it, hipEventQuery polled)" : " (an event behind it, hipEventSynchronize)")))),
                us[0], us[us.size() / 2], us[us.size() * 9 / 10]);
     }
 }
