@@ -18,7 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 STAMPS_LIB = os.path.join(ROOT, "gort_amd", "libgort_amd_stamps.so")
-if not os.path.exists(STAMPS_LIB):
+if not os.path.exists(STAMPS_LIB):                         # (after a change of the sources: python -m gort_amd.build --stamps)
     from gort_amd import build
     build.build_stamps()
 os.environ["GORT_AMD_LIB"] = STAMPS_LIB
