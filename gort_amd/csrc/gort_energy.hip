@@ -135,10 +135,9 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     const double w = nodes[3 * tid + 2];
     GeomOut g;
     if (SHARE_ROWS) {
-        // reflectances only leave this kernel, and with the sun on the horizon they are NaN by either route (the view zeniths
-        // are Gauss nodes, never on it): no reference route here - it made the 90-degree line of BASELINE config 4 twice
-        // as long as the others (8.8 against 4.5 us of row terms), and a launch ends with its longest line
-        if (tid < ENERGY_ZENITH_NODES) row_terms(c, nodes[3 * tid + 1], sza, sh.row[tid], false);
+        // reflectances only leave this kernel (gort_geometry.h, row_terms: the 90-degree sun of BASELINE config 4 walked the
+        // reference's route for 8.8 us where the other lines' row terms take 4.5, and a launch ends with its longest line)
+        if (tid < ENERGY_ZENITH_NODES) row_terms(c, nodes[3 * tid + 1], sza, sh.row[tid], true);
         __syncthreads();
         GORT_STAMP(1);                                       // row terms
         finish_angle(c, sh.row[tid & (ENERGY_ZENITH_NODES - 1)], raa, g);
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
             const long a = (long)uniq[1 + base + (lane >> 4)];
             double vza, sza, saa, raa;
             normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
-            row_terms(c, row_vza, sza, sh.row[lane >> 4][lane & (ENERGY_ZENITH_NODES - 1)], false);
+            row_terms(c, row_vza, sza, sh.row[lane >> 4][lane & (ENERGY_ZENITH_NODES - 1)], true);
         }
         __syncthreads();
         GORT_STAMP(1);                                       // row terms of the batch

@@ -131,15 +131,28 @@ __device__ void row_terms_with(const gort_canopy &c, double vza, double sza, Row
 // (gortt_brdf.c:650-666): the reference's value follows the last bit of glibc's sin and cos, which the library's
 // reproduce (both are correctly rounded almost always) and a 1-ulp kernel does not - 24 reference hot-spot rows of
 // tests/golden/fuzz_canopies.npz moved by up to 5e-8 with it.  Two calls per line, ~80 instructions more than the kernels.
-// reference_route_at_horizon = false: the caller's output is the reflectance alone, which is NaN at a zenith of 90 degrees by
-// either route (EPgap is 0 there and Kuusk's term 0 x inf, gortt_brdf.c:638-702; asserted for every node of the
-// hemisphere grid in tests/test_gpu_parity.py) - the LUT kernels, whose grids hold both horizons in every launch and whose
-// workgroups would otherwise wait for the few that walk the library's code.
-__device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms &r, bool reference_route_at_horizon = true)
+// reflectances_only = true: nothing but the reflectance leaves the caller (LUT kernels, the albedo quadrature, a stream
+// without -prnprop / -prnspec).  Then a line with a zenith of EXACTLY 90 degrees - the cosine of the double nearest pi/2
+// is 6e-17; "exactly" is |cos| < 1e-15 - need not walk the reference's route: its reflectance is NaN by either arithmetic,
+// because EPgap is 0 there and Kuusk's term 0 x inf (gortt_brdf.c:638-702; asserted for every node of the hemisphere grid
+// in tests/test_gpu_parity.py and for six kinds of canopy in tests/test_stream_forms.py).  Not so for a Q08 canopy, whose
+// closed-form gap probabilities leave the reference finite numbers on the horizon (-q08_pn_kopen: those take the route
+// whatever is asked for), nor for lines merely NEAR the horizon.  What it buys: the route's library calls cost the whole
+// wave of such a lane 10 us - hemisphere grids hold both horizons in every launch and waited for the few workgroups that
+// walked it (C3 69 -> 55 us), the 90-degree sun of BASELINE config 4 took twice as long as the other 90 lines, and config 2
+// is the principal plane from -90 to 90 degrees: two of its three waves held one such lane each (15 us against 5).
+__device__ __forceinline__ bool takes_reference_route(const gort_canopy &c, double cos_vz, double cos_sz, bool reflectances_only)
+{
+    if (!near_horizon(cos_vz, cos_sz)) return false;
+    const bool exactly = fabs(cos_vz) < 1e-15 || fabs(cos_sz) < 1e-15;
+    return !(reflectances_only && exactly && !c.use_q08);
+}
+
+__device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms &r, bool reflectances_only = false)
 {
     sincos(vza, &r.sin_vz, &r.cos_vz);
     sincos(sza, &r.sin_sz, &r.cos_sz);
-    r.horizon = reference_route_at_horizon && near_horizon(r.cos_vz, r.cos_sz) ? 1 : 0;
+    r.horizon = takes_reference_route(c, r.cos_vz, r.cos_sz, reflectances_only) ? 1 : 0;
     if (__builtin_expect(r.horizon, 0)) row_terms_with<LibMath>(c, vza, sza, r);
     else row_terms_with<FastMath>(c, vza, sza, r);
 }
@@ -198,21 +211,11 @@ __device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa
 
 // areal proportions + hot spot for one normalised geometry
 __device__ void geometry_core(const gort_canopy &c, double vza, double sza, double raa, GeomOut &o,
-                              bool reference_route_at_horizon = true)
+                              bool reflectances_only = false)
 {
     RowTerms r;
-    row_terms(c, vza, sza, r, reference_route_at_horizon);
+    row_terms(c, vza, sza, r, reflectances_only);
     finish_angle(c, r, raa, o);
-}
-
-// May a stream line skip the reference's route at the horizon?  Where the line was typed with a zenith of exactly +-90
-// degrees and only its reflectances leave the kernel: those are NaN by either route (see row_terms), and the route's
-// library calls cost the whole wave of such a line 10 us (BASELINE config 2 is the principal plane from -90 to 90: two of
-// its three waves held one such lane each and took 15 us where the third took 4.3).  Lines merely NEAR the horizon keep the
-// route, and so does every line whose viewed proportions or component spectra are asked for (finite at 90 degrees).
-__device__ __forceinline__ bool stream_line_takes_reference_route(const double *__restrict__ angle_line, bool proportions_wanted)
-{
-    return proportions_wanted || !(fabs(angle_line[0]) == 90.0 || fabs(angle_line[2]) == 90.0);
 }
 
 __device__ inline void store_coef(double *rec, const gort_canopy &c, const GeomOut &g)

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
     GORT_STAMP_ANCHOR(raa);
     GORT_STAMP(1);                                           // the angle line is there
     GeomOut g;
-    geometry_core(c, vza, sza, raa, g, stream_line_takes_reference_route(angles + 4 * a, K != nullptr || proportions_wanted != 0));
+    geometry_core(c, vza, sza, raa, g, K == nullptr && proportions_wanted == 0);      // reflectances only: gort_geometry.h, row_terms
     GORT_STAMP_ANCHOR(g.A);
     GORT_STAMP(2);                                           // geometry
     if (FUSED) {
@@ -146,7 +146,7 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
         double vza, sza, saa, raa;
         normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
-        row_terms(canopies[ONE_MEMBER ? member0 : member], vza, sza, s_row[threadIdx.x], false);      // a LUT holds reflectances only: NaN at the horizon by either route
+        row_terms(canopies[ONE_MEMBER ? member0 : member], vza, sza, s_row[threadIdx.x], true);       // a LUT holds reflectances only
         s_member[threadIdx.x] = (int)member;
         s_vza_deg[threadIdx.x] = vza_deg;
         s_sza_deg[threadIdx.x] = sza_deg;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         double vza, sza, saa, raa;
         normalise_angles(ap[0], ap[1], ap[2], ap[3], vza, sza, saa, raa);
         GeomOut g;
-        geometry_core(c, vza, sza, raa, g, stream_line_takes_reference_route(ap, K != nullptr));
+        geometry_core(c, vza, sza, raa, g, K == nullptr);              // reflectances only: gort_geometry.h, row_terms
         double rec[GORT_COEF_STRIDE];
         store_coef(rec, c, g);
         l = line_terms_of_record(rec, c.k_openep, c.k_open);

@@ -85,3 +85,55 @@ def test_one_member_of_an_ensemble_takes_the_node_partition_with_its_own_canopy(
     assert np.array_equal(a.view(np.int64), b.view(np.int64))
     assert not np.array_equal(a, every[:per].cpu().numpy())
     e.close()
+
+
+def test_q08_canopy_on_the_horizon_matches_the_reference_restatement():
+    """The closed-form gap probabilities of -q08_pn_kopen leave the reference FINITE reflectances at a zenith of 90 degrees
+    (the tabulated ones make it NaN there): lines, LUT nodes and albedo lines of such a canopy take the reference's route on
+    the horizon whatever is asked for (gort_geometry.h, takes_reference_route).  Grid (node partition, 1 band fused and 130
+    bands through records + the LUT kernel), stream with and without the viewed proportions, and the albedo quadrature with
+    the sun on the horizon, against the oracle on the same gap tables."""
+    import torch
+    from conftest import relerr
+    from oracle import oracle as O
+    c = api.gap_probabilities(api.make_canopy(lai=2.0, q08=True))
+    o = O.make_canopy(favd=c.favd, r=c.r, b=c.b, h1=c.h1, h2=c.h2, lam=c.lambda_, gaps=False)
+    O.set_gap_tables(o, np.array(c.p_n0), np.array(c.epgap), c.k_open, c.k_openep)     # the same gap tables: isolates the BRDF kernels
+    g = _grid((0.0, 45.0, 3), (0.0, 30.0, 4), (0.0, 90.0, 5))             # sza 0 45 90; vza 0 30 60 90; full circle in 90-degree steps
+    rows = g.nsza * g.nvza
+    ang = np.array([[g.vza0 + (r % g.nvza) * g.dvza, g.phi0 + l * g.dphi, g.sza0 + (r // g.nvza) * g.dsza, 0.0]
+                    for r in range(rows) for l in range(g.nphi)])
+    at90 = (ang[:, 0] == 90.0) | (ang[:, 2] == 90.0)
+    for nw in (1, 130):
+        wl = np.linspace(500.0, 2300.0, nw)
+        rs, rl, tl = api.spectra(wl)
+        want = O.rsurf_stream(o, ang, rs, rl, tl, want_K=False)[0]
+        assert np.isfinite(want[at90]).any()                             # the point of the test: numbers on the horizon
+        e = api.Engine()
+        e.set_canopy(c)
+        e.set_spectra(rs, rl, tl)
+        lut = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
+        e.rsurf_grid_dev(g, 0, rows, lut)
+        a = torch.as_tensor(ang, device="cuda")
+        plain = torch.empty((ang.shape[0], nw), dtype=torch.float64, device="cuda")
+        with_k = torch.empty_like(plain)
+        K = torch.empty((ang.shape[0], 4), dtype=torch.float64, device="cuda")
+        e.rsurf_stream_dev(a, plain)
+        e.rsurf_stream_dev(a, with_k, None, K)
+        e.synchronize()
+        for name, got in (("grid", lut.cpu().numpy()), ("stream", plain.cpu().numpy()), ("stream with K", with_k.cpu().numpy())):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (name, nw)
+            assert relerr(got, want, floor=1e-12) <= 1e-9, (name, nw, relerr(got, want, floor=1e-12))
+        e.close()
+    # the albedo quadrature with the sun on the horizon (and beside it)
+    wl = np.array([450.0, 800.0, 1650.0])
+    rs, rl, tl = api.spectra(wl)
+    sun = np.array([[0.0, 0.0, s, 0.0] for s in (90.0, 89.0, 30.0, -90.0)])
+    want = O.energy_stream(o, sun, rs, rl, tl)
+    e = api.Engine()
+    e.set_canopy(c)
+    e.set_spectra(rs, rl, tl)
+    got = e.energy_stream(sun)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert relerr(got, want, floor=1e-12) <= 1e-9, relerr(got, want, floor=1e-12)
+    e.close()
