@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
 // GEOM_ROWS x nphi azimuth nodes.  With 361 nodes per row this removes ~70 % of the transcendentals of the
 // per-tuple form.
 constexpr int GEOM_ROW_THREADS = 128;
+constexpr int GEOM_FUSED_MAX_BANDS = 8;      // the fused form serves grids of up to this many bands (gort_api.hip: grid_rows)
 #ifndef GORT_GEOM_SPAN_THREADS
 #define GORT_GEOM_SPAN_THREADS 256
 #endif
@@ -111,6 +112,7 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           double *__restrict__ rsurf, int mirror)
 {
     __shared__ RowTerms s_row[GEOM_ROWS];
+    __shared__ double s_sun_terms[GEOM_ROWS][GEOM_FUSED_MAX_BANDS][5];      // fused form: C0, B, Z, G, T per (row, band)
     __shared__ int s_member[GEOM_ROWS];
     __shared__ double s_vza_deg[GEOM_ROWS], s_sza_deg[GEOM_ROWS];
     const long rows_per_member = (long)g.nsza * g.nvza;
@@ -154,11 +156,18 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
     __syncthreads();
     GORT_STAMP(1);                                           // row terms
     // ONE_MEMBER: what the node loop reads of the canopy and (fused form) the first band's constants, once, ahead of the loop
-    const gort_canopy &c0 = canopies[member0];
-    const double ko0 = c0.k_open, kep0 = c0.k_openep;
-    BandTerms band0 = {};
-    if (ONE_MEMBER && compact == 2) {
-        band0 = load_band(Lall + member0 * L_NSLOT * nw, nw, 0);
+    // fused form: the five (sun zenith, band) terms of the sample depend on the row and the band only - once per (row, band)
+    // here instead of once per node (sun_terms() is ~50 of a node's ~560 instructions)
+    if (compact == 2) {
+        if ((int)threadIdx.x < rows_here * nw) {
+            const int r = (int)threadIdx.x / nw, b = (int)threadIdx.x - r * nw;
+            const long member = ONE_MEMBER ? member0 : (long)s_member[r];
+            const gort_canopy &c = canopies[member];
+            const SunTerms t = sun_terms(Lall + member * L_NSLOT * nw, nw, b, s_row[r].sun, c.k_open, c.k_openep);
+            double *o = s_sun_terms[r][b];
+            o[0] = t.C0;  o[1] = t.B;  o[2] = t.Z;  o[3] = t.G;  o[4] = t.T;
+        }
+        __syncthreads();
     }
     constexpr int THREADS = ONE_MEMBER ? GEOM_SPAN_THREADS : GEOM_ROW_THREADS;
     for (int n = rel0 + (int)threadIdx.x; n < rel1; n += THREADS) {
@@ -175,12 +184,9 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         if (compact == 2) {
             double rec[GORT_COEF_STRIDE];
             store_coef(rec, c, o);
-            const double *__restrict__ L = Lall + member * L_NSLOT * nw;
-            const SunScalars sun = load_sun(rec);
             for (int b = 0; b < nw; ++b) {
-                const SunTerms t = ONE_MEMBER ? sun_terms(b == 0 ? band0 : load_band(L, nw, b), sun, ko0, kep0)
-                                              : sun_terms(L, nw, b, sun, c.k_open, c.k_openep);
-                const double v = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t.C0, t.B, t.Z, t.G, t.T);
+                const double *t = s_sun_terms[r][b];
+                const double v = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t[0], t[1], t[2], t[3], t[4]);
                 rsurf[i * nw + b] = v;
                 if (i2 >= 0) rsurf[i2 * nw + b] = v;
             }
