@@ -170,6 +170,56 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         __syncthreads();
     }
     constexpr int THREADS = ONE_MEMBER ? GEOM_SPAN_THREADS : GEOM_ROW_THREADS;
+    if (compact == 1) {
+        // LUT path: the five expansion coefficients of a node, one 64-B record - and its image's.  A lane holding its record
+        // would store it as four 16-B pieces 64 B apart: every store instruction a quarter of 32 cache lines.  The wave
+        // turns its 64 records through LDS instead, four lanes to a record: an instruction then writes 16 whole records.
+        __shared__ dbl2 s_rec[THREADS / 64][64][4];
+        __shared__ long s_at[THREADS / 64][64][2];
+        const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+        for (int n0 = rel0 + (wave << 6); n0 < rel1; n0 += THREADS) {       // wave-uniform bounds: every lane takes part in the turn
+            const int n = n0 + lane;
+            long i = -1, i2 = -1;
+            dbl2 piece[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+            if (n < rel1) {
+                const int r = n / per_row, l = n - r * per_row;
+                const gort_canopy &c = canopies[ONE_MEMBER ? member0 : (long)s_member[r]];
+                double vza, sza, saa, raa;
+                normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
+                GeomOut o;
+                finish_angle(c, s_row[r], raa, o);
+                i = (first + r) * g.nphi + l;
+                const int l2 = g.nphi - 1 - l;
+                i2 = (mirror && l2 != l) ? (first + r) * g.nphi + l2 : -1;
+                double rec[GORT_COEF_STRIDE];
+                store_coef(rec, c, o);
+                piece[0].x = rec[A_C];  piece[0].y = rec[A_B];
+                piece[1].x = rec[A_Z];  piece[1].y = rec[A_G];
+                piece[2].x = rec[A_T];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) s_rec[wave][lane][p] = piece[p];
+            s_at[wave][lane][0] = i;
+            s_at[wave][lane][1] = i2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int q = 16 * p + (lane >> 2);                      // the record this lane stores a quarter of
+                    const long at = s_at[wave][q][k];
+                    if (at >= 0) reinterpret_cast<dbl2 *>(coef + at * 8)[lane & 3] = s_rec[wave][q][lane & 3];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                  // before the next round overwrites the records
+        }
+        GORT_STAMP(2);
+        GORT_STAMPS_END(geometry, (long)blockIdx.x * 4 + (threadIdx.x >> 6), (threadIdx.x & 63) == 0);
+        return;
+    }
     for (int n = rel0 + (int)threadIdx.x; n < rel1; n += THREADS) {
         const int r = n / per_row, l = n - r * per_row;
         const long member = ONE_MEMBER ? member0 : (long)s_member[r];
@@ -189,19 +239,6 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                 const double v = dot5(rec[A_C], rec[A_B], rec[A_Z], rec[A_G], rec[A_T], t[0], t[1], t[2], t[3], t[4]);
                 rsurf[i * nw + b] = v;
                 if (i2 >= 0) rsurf[i2 * nw + b] = v;
-            }
-        } else if (compact) {
-            // LUT path: only the five expansion coefficients, one 64-B record per node
-            double rec[GORT_COEF_STRIDE];
-            store_coef(rec, c, o);
-            for (int k = 0; k < 2; ++k) {
-                const long at = k ? i2 : i;
-                if (at < 0) break;
-                double2 *dst = reinterpret_cast<double2 *>(coef + at * 8);
-                dst[0] = make_double2(rec[A_C], rec[A_B]);
-                dst[1] = make_double2(rec[A_Z], rec[A_G]);
-                dst[2] = make_double2(rec[A_T], 0.0);
-                dst[3] = make_double2(0.0, 0.0);
             }
         } else {
             store_coef(coef + i * GORT_COEF_STRIDE, c, o);
