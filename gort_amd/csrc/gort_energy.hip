@@ -344,12 +344,23 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
 // a grid-stride loop of long-lived waves wrote 4.85 TB/s here) - and the few source rows stay in L2.  A chunk of 128
 // doubles lies in at most two rows when a row has >= 128 doubles (ROWS2: their representatives are two wave-uniform
 // loads, the chunk's row and offset advance incrementally); shorter rows (a handful of bands) take the per-element form.
+// Which of the two broadcasts works is decided on the device, by the number of owner lines the table found (the host never
+// waits for it): both kernels are launched, one returns at once.  1M lines x 2101 bands: the chunk form costs 3 ms when
+// nothing is to be copied (it walks every chunk of the output) and 9.3 ms when everything is (0.71 of the roofline); the
+// row form 0.1 ms and 10.3 ms - by rows while fewer than ~72 % of the lines are copies.
+__device__ __forceinline__ bool broadcast_goes_by_rows(const unsigned *__restrict__ uniq, long nA)
+{
+    return uniq && 100L * (long)uniq[0] >= 28L * nA;
+}
+
 template <bool ROWS2>
 __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row, double *__restrict__ energy_all,
                                                                 const unsigned *__restrict__ rep, int shift, long chunks,
                                                                 int K, unsigned W, long dq, int dr, int xcd_static,
-                                                                XcdDuty duty, long useful_blocks)
+                                                                XcdDuty duty, long useful_blocks,
+                                                                const unsigned *__restrict__ uniq_if_rows_may_take_it)
 {
+    if (broadcast_goes_by_rows(uniq_if_rows_may_take_it, nA)) return;
     // member y's slab starts y nA row doubles further on: its own offset against the 1-KiB chunk grid (else an odd nA row
     // would leave every other member's 16-byte stores on 8-byte boundaries and its chunks off the grid they are cut for)
     const long n_total = nA * (long)row;
@@ -418,6 +429,70 @@ __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row,
             if (put[0]) energy[e0] = v[0];
             if (put[1]) energy[e0 + 1] = v[1];
         }
+    }
+}
+
+// The same broadcast ROW BY ROW (round 4).  The chunk form above keeps one store in flight per wave: a lane's load and its
+// store share the one in-order counter (vmcnt), so a wave that waits for its next load has waited for its last store too,
+// and 8192 resident waves x 1 KiB over a ~1.5 us round trip are the 5.7 TB/s it writes.  Here a workgroup takes a whole
+// destination row at a time: every thread requests ALL its 16-B pieces of the source row (a dozen loads in flight, from
+// L2: the few source rows are read over and over), waits once, and then has a dozen stores in flight.  Stores are laid on
+// the absolute 128-B grid of the destination (the row's head up to the first boundary and a last odd double go singly);
+// the source is read at whatever 8-B alignment it has.  Workgroups take blocks of 256 lines off a counter and copy those
+// of them that stand for another line.
+constexpr int ROWCOPY_BATCH = 13;                 // pieces a thread holds: 13 x 256 x 16 B = 53 KB >= a row of 2101 bands
+__global__ __launch_bounds__(256) void energy_broadcast_rows_kernel(long nA, int row, double *__restrict__ energy_all,
+                                                                     const unsigned *__restrict__ rep, unsigned *__restrict__ counters,
+                                                                     const unsigned *__restrict__ uniq, int always)
+{
+    if (!always && !broadcast_goes_by_rows(uniq, nA)) return;
+    __shared__ long s_base;
+    __shared__ int s_n;
+    __shared__ unsigned s_line[256];
+    const int tid = threadIdx.x;
+    double *__restrict__ energy = energy_all + (long)blockIdx.y * nA * row;
+    unsigned *counter = counters + blockIdx.y;
+    for (;;) {
+        if (tid == 0) {
+            s_base = (long)atomicAdd(counter, 256u);
+            s_n = 0;
+        }
+        __syncthreads();
+        const long base = s_base;
+        if (base >= nA) break;
+        const long l = base + tid;
+        if (l < nA && rep[l] != (unsigned)l) s_line[atomicAdd(&s_n, 1)] = (unsigned)l;
+        __syncthreads();
+        const int n = s_n;
+        for (int j = 0; j < n; ++j) {
+            const long line = s_line[j];
+            double *d = energy + line * row;
+            const double *src = energy + (long)rep[line] * row;
+            int h = (int)((16 - ((reinterpret_cast<uintptr_t>(d) >> 3) & 15)) & 15);     // doubles to the next 128-B boundary
+            if (h > row) h = row;
+            if (tid < h) d[tid] = src[tid];
+            const int pieces = (row - h) >> 1;
+            dbl2 *d2 = reinterpret_cast<dbl2 *>(d + h);
+            const double *s1 = src + h;
+            for (int p0 = 0; p0 < pieces; p0 += 256 * ROWCOPY_BATCH) {
+                dbl2 v[ROWCOPY_BATCH];
+#pragma unroll
+                for (int b = 0; b < ROWCOPY_BATCH; ++b) {
+                    const int p = p0 + b * 256 + tid;
+                    if (p < pieces) {
+                        v[b].x = s1[2 * p];
+                        v[b].y = s1[2 * p + 1];
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < ROWCOPY_BATCH; ++b) {
+                    const int p = p0 + b * 256 + tid;
+                    if (p < pieces) __builtin_nontemporal_store(v[b], d2 + p);
+                }
+            }
+            if (((row - h) & 1) && tid == 0) d[row - 1] = src[row - 1];
+        }
+        __syncthreads();                                      // the list is done with
     }
 }
 
@@ -499,6 +574,31 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
                            angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
     if ((rc = check_launch("energy_list_kernel"))) return rc;
     const int row = 3 * nw;
+    // rows of at least a KiB, and counters that fit the table's memory (done with by now): the row-by-row form is launched
+    // too, and the number of owner lines decides on the device which of the two works (broadcast_goes_by_rows)
+    const char *bf = getenv("GORT_ENERGY_BROADCAST");        // "chunks" / "rows": one form for everything (tests compare the two)
+    const bool rows_possible = row >= CHUNK && (size_t)n_members * sizeof(unsigned) <= cap * sizeof(unsigned long long) &&
+                               !(bf && bf[0] == 'c');
+    const bool rows_always = rows_possible && bf && bf[0] == 'r';
+    if (rows_possible) {
+        unsigned *counters = reinterpret_cast<unsigned *>(tab);
+        if (hipMemsetAsync(counters, 0, (size_t)n_members * sizeof(unsigned), s) != hipSuccess)
+            return fail(GORT_ENODEVICE, "energy: cannot clear the broadcast counters");
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+                cus = 256;
+            (void)hipGetLastError();
+        }
+        long wg = (nA + 255) / 256;                           // blocks of lines there are
+        if (wg > 7L * cus) wg = 7L * cus;                    // 66 VGPRs: seven of these four-wave workgroups per CU
+        hipLaunchKernelGGL(energy_broadcast_rows_kernel, dim3((unsigned)wg, (unsigned)n_members), dim3(256), 0, s, nA, row, energy_dev, rep,
+                           counters, (const unsigned *)uniq, rows_always ? 1 : 0);
+        if ((rc = check_launch("energy_broadcast_rows_kernel"))) return rc;
+        if (rows_always) return GORT_OK;
+    }
+    const unsigned *uniq_for_choice = rows_possible ? uniq : nullptr;
     const int shift = (int)((reinterpret_cast<uintptr_t>(energy_dev) / sizeof(double)) % CHUNK);
     const long chunks = (nA * (long)row + shift + CHUNK - 1) / CHUNK;         // member 0; the others derive theirs (one more at most)
     // panels of 16 steps x 2048 waves (32 MB), XCD-contiguous where the dispatch is round-robin.  1M lines x 2101 bands, 91
@@ -516,10 +616,10 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     const int dr = (int)((long)W * CHUNK - dq * row);
     if (row >= CHUNK)
         hipLaunchKernelGGL(energy_broadcast_kernel<true>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks, K, W, dq, dr,
-                           xcd_round_robin ? 1 : 0, duty, useful);
+                           xcd_round_robin ? 1 : 0, duty, useful, uniq_for_choice);
     else
         hipLaunchKernelGGL(energy_broadcast_kernel<false>, grid, dim3(256), 0, s, nA, row, energy_dev, rep, shift, chunks, K, W, dq, dr,
-                           xcd_round_robin ? 1 : 0, duty, useful);
+                           xcd_round_robin ? 1 : 0, duty, useful, uniq_for_choice);
     return check_launch("energy_broadcast_kernel");
 }
 

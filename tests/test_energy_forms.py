@@ -119,8 +119,9 @@ def test_batched_list_kernel_same_bits(nw, n):
 
 @pytest.mark.parametrize("nw,n", [(43, 4001), (128, 1501), (2101, 333), (7, 5001)])
 def test_broadcast_of_shared_rows_same_bits(nw, n):
-    """Rows of 3 nw doubles copied from the line that owns their sun direction: 43 bands are the first to take the form
-    with two rows per 1-KiB chunk (incremental row / offset carry, chunks that straddle rows, front and back edges), 128
+    """Rows of 3 nw doubles copied from the line that owns their sun direction, by either broadcast (chunk by chunk of the
+    output, row by row of the lines; which one works is chosen on the device by the share of owner lines): 43 bands are the
+    first to take the chunk form with two rows per 1-KiB chunk (incremental row / offset carry, chunks that straddle rows, front and back edges), 128
     and 2101 bands its long rows, 7 bands the per-element form.  Odd nA x row, an output that starts off the chunk grid,
     sentinels on both sides."""
     import torch
@@ -133,13 +134,19 @@ def test_broadcast_of_shared_rows_same_bits(nw, n):
     ang[-1, 2] = 41.0                                                       # the last line owns its direction: nothing copied into the back edge
     assert nw % 2 == 0 or (n * nw * 3) % 2 == 1
     res = {}
-    for dedup in ("1", "0"):
-        e = _engine(wl, dedup)
-        res[dedup] = [_energy(e, ang, nw, torch, offset=off) for off in (0, 5)]
-        e.close()
-    for k in (0, 1):
-        assert not (res["1"][k] == -7.0).any()
-        assert np.array_equal(_bits(res["1"][k]), _bits(res["0"][k])), (nw, k)
+    for form in ("every line", "chunks", "rows", "chosen on the device"):
+        if form in ("chunks", "rows"):
+            os.environ["GORT_ENERGY_BROADCAST"] = form       # read per call (gort_energy.hip, launch_energy)
+        try:
+            e = _engine(wl, "0" if form == "every line" else "1")
+            res[form] = [_energy(e, ang, nw, torch, offset=off) for off in (0, 5)]
+            e.close()
+        finally:
+            os.environ.pop("GORT_ENERGY_BROADCAST", None)
+    for form in ("chunks", "rows", "chosen on the device"):
+        for k in (0, 1):
+            assert not (res[form][k] == -7.0).any(), (form, k)
+            assert np.array_equal(_bits(res[form][k]), _bits(res["every line"][k])), (nw, form, k)
 
 
 def test_member_batched_broadcast_same_bits():
