@@ -440,7 +440,10 @@ __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row,
 // the absolute 128-B grid of the destination (the row's head up to the first boundary and a last odd double go singly);
 // the source is read at whatever 8-B alignment it has.  Workgroups take blocks of 256 lines off a counter and copy those
 // of them that stand for another line.
-constexpr int ROWCOPY_BATCH = 13;                 // pieces a thread holds: 13 x 256 x 16 B = 53 KB >= a row of 2101 bands
+typedef double dbl2_align8 __attribute__((ext_vector_type(2), aligned(8)));
+// ROWCOPY_BATCH pieces per thread and pass: 13 x 256 x 16 B = 53 KB hold a row of 2101 bands in one pass; shorter rows take
+// the smallest of 1 / 2 / 4 / 8 / 13 that does
+template <int ROWCOPY_BATCH>
 __global__ __launch_bounds__(256) void energy_broadcast_rows_kernel(long nA, int row, double *__restrict__ energy_all,
                                                                      const unsigned *__restrict__ rep, unsigned *__restrict__ counters,
                                                                      const unsigned *__restrict__ uniq, int always)
@@ -474,21 +477,19 @@ __global__ __launch_bounds__(256) void energy_broadcast_rows_kernel(long nA, int
             const int pieces = (row - h) >> 1;
             dbl2 *d2 = reinterpret_cast<dbl2 *>(d + h);
             const double *s1 = src + h;
+            // straight-line: a piece beyond the row's last is the last one again (the same 16 B written once more) - a branch
+            // around a load or a store would make the compiler wait for everything in flight at every join
             for (int p0 = 0; p0 < pieces; p0 += 256 * ROWCOPY_BATCH) {
                 dbl2 v[ROWCOPY_BATCH];
+                int at[ROWCOPY_BATCH];
 #pragma unroll
                 for (int b = 0; b < ROWCOPY_BATCH; ++b) {
                     const int p = p0 + b * 256 + tid;
-                    if (p < pieces) {
-                        v[b].x = s1[2 * p];
-                        v[b].y = s1[2 * p + 1];
-                    }
+                    at[b] = p < pieces ? p : pieces - 1;
+                    v[b] = *reinterpret_cast<const dbl2_align8 *>(s1 + 2 * at[b]);      // 16 B at 8-B alignment: one load
                 }
 #pragma unroll
-                for (int b = 0; b < ROWCOPY_BATCH; ++b) {
-                    const int p = p0 + b * 256 + tid;
-                    if (p < pieces) __builtin_nontemporal_store(v[b], d2 + p);
-                }
+                for (int b = 0; b < ROWCOPY_BATCH; ++b) __builtin_nontemporal_store(v[b], d2 + at[b]);
             }
             if (((row - h) & 1) && tid == 0) d[row - 1] = src[row - 1];
         }
@@ -593,8 +594,14 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
         }
         long wg = (nA + 255) / 256;                           // blocks of lines there are
         if (wg > 7L * cus) wg = 7L * cus;                    // 66 VGPRs: seven of these four-wave workgroups per CU
-        hipLaunchKernelGGL(energy_broadcast_rows_kernel, dim3((unsigned)wg, (unsigned)n_members), dim3(256), 0, s, nA, row, energy_dev, rep,
-                           counters, (const unsigned *)uniq, rows_always ? 1 : 0);
+        const int passes_of_one = (row / 2 + 255) / 256;      // 16-B pieces of a row over the 256 threads
+#define GORT_ROWS_LAUNCH(B) hipLaunchKernelGGL(energy_broadcast_rows_kernel<B>, dim3((unsigned)wg, (unsigned)n_members), dim3(256), 0, s, nA, row, energy_dev, rep, counters, (const unsigned *)uniq, rows_always ? 1 : 0)
+        if (passes_of_one <= 1) GORT_ROWS_LAUNCH(1);
+        else if (passes_of_one <= 2) GORT_ROWS_LAUNCH(2);
+        else if (passes_of_one <= 4) GORT_ROWS_LAUNCH(4);
+        else if (passes_of_one <= 8) GORT_ROWS_LAUNCH(8);
+        else GORT_ROWS_LAUNCH(13);
+#undef GORT_ROWS_LAUNCH
         if ((rc = check_launch("energy_broadcast_rows_kernel"))) return rc;
         if (rows_always) return GORT_OK;
     }
