@@ -432,10 +432,8 @@ __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row,
     }
 }
 
-// The same broadcast ROW BY ROW (round 4).  The chunk form above keeps one store in flight per wave: a lane's load and its
-// store share the one in-order counter (vmcnt), so a wave that waits for its next load has waited for its last store too,
-// and 8192 resident waves x 1 KiB over a ~1.5 us round trip are the 5.7 TB/s it writes.  Here a workgroup takes a whole
-// destination row at a time: every thread requests ALL its 16-B pieces of the source row (a dozen loads in flight, from
+// The same broadcast ROW BY ROW (round 4), for lists with few copies: the chunk form above walks every chunk of the output
+// (3 ms for a million rows of 2101 bands with nothing to copy).  Here a workgroup takes a whole destination row at a time: every thread requests ALL its 16-B pieces of the source row (a dozen loads in flight, from
 // L2: the few source rows are read over and over), waits once, and then has a dozen stores in flight.  Stores are laid on
 // the absolute 128-B grid of the destination (the row's head up to the first boundary and a last odd double go singly);
 // the source is read at whatever 8-B alignment it has.  Workgroups take blocks of 256 lines off a counter and copy those
