@@ -383,7 +383,40 @@ __global__ __launch_bounds__(256) void energy_broadcast_kernel(long nA, int row,
         line_c = c0 / row;
         off_c = (int)(c0 - line_c * row);
     }
-    for (int k = 0; k < K && ch < chunks; ++k, ch += W, c0 += (long)W * CHUNK) {
+    int k = 0;
+    constexpr int PIPE_STEPS = 16, PIPE_AHEAD = 4, PIPE_MAX_ROW = 1536;
+    if (ROWS2 && K == PIPE_STEPS && row <= PIPE_MAX_ROW && ch + (PIPE_STEPS - 1L) * W < chunks && c0 >= 0 &&
+        c0 + (PIPE_STEPS - 1L) * W * CHUNK + CHUNK <= n_total) {
+        // All sixteen chunks of the wave lie inside the output: ONE straight line of code in which the loads run four steps
+        // ahead of the stores - L0 L1 L2 L3, L4 S0, L5 S1, ... - so that a store never waits for more than its own load
+        // (the counter is in order: the loads it waits for are older than the stores still in flight).  Step by step, with
+        // a branch around every load and store, the compiler waits for everything at the top of each step and the kernel
+        // is a chain of load and store latencies.  Every element is copied here, an owner line's onto itself - the same bits.
+        // A million lines, all copies (profiles/r04/energy_stream.log): 128 bands 0.80 against 0.88 ms, 400 bands 1.85 against
+        // 2.18 - but 2101 bands 9.6 against 9.3 (where the same stores without any load take 7.8 and with loads that never
+        // leave one KiB per row 9.1: it is the loads' presence, not their latency or their bytes, that the long rows pay for):
+        // rows of up to PIPE_MAX_ROW doubles take this path.
+        dbl2 x[PIPE_STEPS];
+#pragma unroll
+        for (int i = 0; i < PIPE_STEPS + PIPE_AHEAD; ++i) {
+            if (i < PIPE_STEPS) {
+                const long line0 = line_c;
+                const int off0 = off_c;
+                off_c += dr;
+                line_c += dq;
+                if (off_c >= row) { off_c -= row; ++line_c; }
+                const long rep0 = (long)rep[line0], rep1 = (long)rep[line0 + 1 < nA ? line0 + 1 : line0];
+                const int t = off0 + EPL * lane;
+                const bool second0 = t >= row, second1 = t + 1 >= row;
+                x[i].x = energy[(second0 ? rep1 : rep0) * row + (second0 ? t - row : t)];
+                x[i].y = energy[(second1 ? rep1 : rep0) * row + (second1 ? t + 1 - row : t + 1)];
+            }
+            if (i >= PIPE_AHEAD)
+                __builtin_nontemporal_store(x[i - PIPE_AHEAD], reinterpret_cast<dbl2 *>(energy + c0 + (long)(i - PIPE_AHEAD) * W * CHUNK + EPL * lane));
+        }
+        return;
+    }
+    for (; k < K && ch < chunks; ++k, ch += W, c0 += (long)W * CHUNK) {
         const long e0 = c0 + EPL * lane;                              // first of this lane's two elements
         double v[EPL];
         bool put[EPL];
