@@ -117,11 +117,12 @@ def test_batched_list_kernel_same_bits(nw, n):
     assert _same_bits_nan_for_nan(res["1"], res["0"])
 
 
-@pytest.mark.parametrize("nw,n", [(43, 4001), (128, 1501), (2101, 333), (7, 5001)])
+@pytest.mark.parametrize("nw,n", [(43, 4001), (128, 1501), (2101, 333), (7, 5001), (128, 100003), (47, 300007)])
 def test_broadcast_of_shared_rows_same_bits(nw, n):
     """Rows of 3 nw doubles copied from the line that owns their sun direction, by either broadcast (chunk by chunk of the
     output, row by row of the lines; which one works is chosen on the device by the share of owner lines): 43 bands are the
-    first to take the chunk form with two rows per 1-KiB chunk (incremental row / offset carry, chunks that straddle rows, front and back edges), 128
+    first to take the chunk form with two rows per 1-KiB chunk (the two long streams: enough chunks for its straight-line
+    path of sixteen steps per wave, which short outputs never reach) (incremental row / offset carry, chunks that straddle rows, front and back edges), 128
     and 2101 bands its long rows, 7 bands the per-element form.  Odd nA x row, an output that starts off the chunk grid,
     sentinels on both sides."""
     import torch
