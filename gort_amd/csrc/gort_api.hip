@@ -1100,7 +1100,7 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
     } else {
         // the window is (most of) the buffer: separate allocations, alive together (a freed candidate's memory would
         // come straight back) as far as the device has room for them beside 8 GiB for everybody else
-        const int draws = select ? (max_draws < 4 ? max_draws : 4) : 1;
+        const int draws = select ? (max_draws < 5 ? max_draws : 5) : 1;
         for (; n < draws; ++n) {
             size_t free_b = 0, total_b = 0;
             if (n > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30))) {

@@ -161,7 +161,7 @@ int   gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
  *     6.1-6.3 TB/s between them; a scan finds a plateau, a few random draws mostly do not).  Where the scan is flat
  *     (the allocation lies inside one physical extent) it is repeated, twice at most, on a new allocation made behind a
  *     blocker of a few GiB.  The slack stays allocated until gort_lut_free; the pointer returned may be interior.
- *   - else: up to min(max_draws, 4) separate allocations, alive together as far as the device keeps 8 GiB free beside
+ *   - else: up to min(max_draws, 5) separate allocations, alive together as far as the device keeps 8 GiB free beside
  *     them, the rest freed (on some boxes every second 50 GB allocation runs the LUT kernel 11 % slower than the others,
  *     for its whole life; the probe tells them apart: profiles/r04/placement_select.log).
  * It stops early at 0.985 x the best rate this engine has measured for the size class.  Windows below 1 GiB and
