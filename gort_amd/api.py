@@ -60,10 +60,10 @@ class Grid(C.Structure):
 class PipeChunk(C.Structure):
     """struct gort_pipe_chunk"""
     _fields_ = [("n", C.c_long), ("angles", C.POINTER(D)), ("rsurf", C.POINTER(D)), ("scomp", C.POINTER(D)),
-                ("K", C.POINTER(D)), ("energy", C.POINTER(D))]
+                ("K", C.POINTER(D)), ("energy", C.POINTER(D)), ("energy_index", C.POINTER(C.c_uint32)), ("energy_rows", C.c_long)]
 
 
-PIPE_SCOMP, PIPE_ENERGY, PIPE_ENERGY_ONLY = 1, 2, 4
+PIPE_SCOMP, PIPE_ENERGY, PIPE_ENERGY_ONLY, PIPE_ENERGY_INDEXED = 1, 2, 4, 8
 
 DECLARED_SYMBOLS = [
     "gort_last_error", "gort_version", "gort_canopy_defaults", "gort_leaf_soil_defaults",
@@ -81,6 +81,7 @@ DECLARED_SYMBOLS = [
     "gort_rsurf_members_grid_dev", "gort_rsurf_members_stream", "gort_rsurf_members_stream_dev",
     "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
+    "gort_energy_stream_indexed", "gort_energy_stream_indexed_dev",
     "gort_host_malloc", "gort_host_free", "gort_set_device", "gort_get_device",
     "gort_pipe_create", "gort_pipe_acquire", "gort_pipe_submit", "gort_pipe_wait", "gort_pipe_release", "gort_pipe_destroy",
 ]
@@ -170,6 +171,8 @@ def lib():
         L.gort_energy_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
         L.gort_energy_stream_dev.argtypes = L.gort_energy_stream.argtypes
         L.gort_energy_members_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]
+        L.gort_energy_stream_indexed.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.POINTER(C.c_long)]
+        L.gort_energy_stream_indexed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
         L.gort_gap_probabilities.argtypes = [C.c_void_p, C.c_int]
         L.gort_gap_cache_stats.argtypes = [C.POINTER(C.c_long)] * 3
         L.gort_gap_cache_stats.restype = None
@@ -364,8 +367,10 @@ class Pipe:
         _check(lib().gort_pipe_wait(self.h, C.byref(c)))
         n, nw = c.n, self.nw
         v = lambda p, shape: np.ctypeslib.as_array(p, shape=shape) if p and n > 0 else None
+        rows = c.energy_rows
         return {"n": n, "angles": v(c.angles, (n, 4)), "rsurf": v(c.rsurf, (n, nw)), "scomp": v(c.scomp, (n, nw, 4)),
-                "K": v(c.K, (n, 4)), "energy": v(c.energy, (n, nw, 3))}
+                "K": v(c.K, (n, 4)), "energy": v(c.energy, (rows, nw, 3)) if rows > 0 else None,
+                "energy_index": v(c.energy_index, (n,)), "energy_rows": rows}
 
     def release(self):
         _check(lib().gort_pipe_release(self.h))
@@ -667,6 +672,22 @@ class Engine:
         out = np.zeros((ang.shape[0], self.nw, 3))
         _check(lib().gort_energy_stream(self.h, _ptr(ang), ang.shape[0], _ptr(out)))
         return out
+
+    def energy_stream_indexed(self, angles_deg, rows_cap=None):
+        """(rows[n_rows][nw][3], index[nA]): the distinct albedo rows of the stream in order of first appearance and each
+        line's row (gort_energy_stream_indexed); rows_cap: room offered, default one row per line."""
+        ang = _f64(angles_deg).reshape(-1, 4)
+        cap = ang.shape[0] if rows_cap is None else int(rows_cap)
+        rows = np.zeros((cap, self.nw, 3))
+        index = np.zeros(ang.shape[0], dtype=np.uint32)
+        n_rows = C.c_long()
+        _check(lib().gort_energy_stream_indexed(self.h, _ptr(ang), ang.shape[0], _ptr(rows), cap, _ptr(index), C.byref(n_rows)))
+        return rows[:n_rows.value], index
+
+    def energy_stream_indexed_dev(self, angles_t, rows_t, index_t, n_rows_t):
+        """rows_t[rows_cap][nw][3] float64, index_t[nA] and n_rows_t[1] 32-bit on the device; asynchronous."""
+        _check(lib().gort_energy_stream_indexed_dev(self.h, _ptr(angles_t), angles_t.shape[0], _ptr(rows_t), rows_t.shape[0],
+                                                    _ptr(index_t), _ptr(n_rows_t)))
 
     def energy_stream_dev(self, angles_t, energy_t):
         _check(lib().gort_energy_stream_dev(self.h, _ptr(angles_t), angles_t.shape[0], _ptr(energy_t)))

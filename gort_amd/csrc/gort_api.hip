@@ -1291,6 +1291,74 @@ extern "C" int gort_energy_stream_dev(gort_engine *e, const double *angles_dev, 
                          e->nodes.as<double>(), energy_dev, ws, e->xcd_round_robin == 1, e->stream);
 }
 
+// ---- the indexed form: distinct rows + one index per line ----
+
+int gort_engine_energy_table(gort_engine *e, const double *angles_dev, long nA, void *ws_dev, uint32_t *n_rows_dev, void *stream)
+{
+    if (!e || nA < 0 || (nA > 0 && (!angles_dev || !ws_dev))) return fail(GORT_EINVAL, "gort_engine_energy_table: bad argument");
+    return launch_energy_table(angles_dev, nA, ws_dev, n_rows_dev, stream);
+}
+
+int gort_engine_energy_rows(gort_engine *e, const double *angles_dev, long nA, const void *ws_dev, long n_rows, double *rows_dev)
+{
+    int rc = require_ready(e, "gort_engine_energy_rows");
+    if (rc) return rc;
+    if (nA <= 0 || n_rows <= 0) return GORT_OK;
+    if ((rc = ensure_nodes(e))) return rc;
+    return launch_energy_rows(e->canopy.as<gort_canopy>(), 1, e->L.as<double>(), e->nw, angles_dev, nA, e->nodes.as<double>(),
+                              rows_dev, n_rows, ws_dev, n_rows, e->stream);
+}
+
+extern "C" int gort_energy_stream_indexed_dev(gort_engine *e, const double *angles_dev, long nA, double *rows_dev, long rows_cap,
+                                              uint32_t *index_dev, uint32_t *n_rows_dev)
+{
+    int rc = require_ready(e, "gort_energy_stream_indexed_dev");
+    if (rc) return rc;
+    if (nA < 0 || rows_cap < 0 || (nA > 0 && (!angles_dev || !index_dev || (rows_cap > 0 && !rows_dev))))
+        return fail(GORT_EINVAL, "gort_energy_stream_indexed_dev: bad argument");
+    if (nA == 0) {
+        if (n_rows_dev) GORT_HIP(hipMemsetAsync(n_rows_dev, 0, sizeof(uint32_t), e->stream));
+        return GORT_OK;
+    }
+    if ((rc = ensure_nodes(e))) return rc;
+    if ((rc = e->edup.reserve(energy_table_workspace(nA)))) return rc;
+    if ((rc = launch_energy_table(angles_dev, nA, e->edup.p, n_rows_dev, e->stream))) return rc;
+    GORT_HIP(hipMemcpyAsync(index_dev, energy_table_index(e->edup.p, nA), sizeof(uint32_t) * (size_t)nA, hipMemcpyDeviceToDevice, e->stream));
+    return launch_energy_rows(e->canopy.as<gort_canopy>(), 1, e->L.as<double>(), e->nw, angles_dev, nA, e->nodes.as<double>(),
+                              rows_dev, rows_cap, e->edup.p, -1, e->stream);
+}
+
+extern "C" int gort_energy_stream_indexed(gort_engine *e, const double *angles, long nA, double *rows, long rows_cap,
+                                          uint32_t *index, long *n_rows)
+{
+    int rc = require_ready(e, "gort_energy_stream_indexed");
+    if (rc) return rc;
+    if (n_rows) *n_rows = 0;
+    if (nA < 0 || rows_cap < 0 || !n_rows || (nA > 0 && (!angles || !index || (rows_cap > 0 && !rows))))
+        return fail(GORT_EINVAL, "gort_energy_stream_indexed: bad argument");
+    if (nA == 0) return GORT_OK;
+    const size_t n = (size_t)nA, row_bytes = sizeof(double) * 3 * (size_t)e->nw;
+    if ((rc = ensure_nodes(e))) return rc;
+    if ((rc = e->angles.reserve(sizeof(double) * 4 * n))) return rc;
+    if ((rc = e->edup.reserve(energy_table_workspace(nA)))) return rc;
+    GORT_HIP(hipMemcpyAsync(e->angles.p, angles, sizeof(double) * 4 * n, hipMemcpyHostToDevice, e->stream));
+    if ((rc = launch_energy_table(e->angles.as<double>(), nA, e->edup.p, nullptr, e->stream))) return rc;
+    unsigned count = 0;
+    GORT_HIP(hipMemcpyAsync(&count, energy_table_count(e->edup.p, nA), sizeof count, hipMemcpyDeviceToHost, e->stream));
+    GORT_HIP(hipMemcpyAsync(index, energy_table_index(e->edup.p, nA), sizeof(uint32_t) * n, hipMemcpyDeviceToHost, e->stream));
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    *n_rows = (long)count;
+    if ((long)count > rows_cap)
+        return fail(GORT_ERANGE, "gort_energy_stream_indexed: %u distinct sun directions, room for %ld rows", count, rows_cap);
+    if ((rc = e->out.reserve(row_bytes * count))) return rc;
+    if ((rc = launch_energy_rows(e->canopy.as<gort_canopy>(), 1, e->L.as<double>(), e->nw, e->angles.as<double>(), nA,
+                                 e->nodes.as<double>(), e->out.as<double>(), (long)count, e->edup.p, (long)count, e->stream)))
+        return rc;
+    GORT_HIP(hipMemcpyAsync(rows, e->out.p, row_bytes * count, hipMemcpyDeviceToHost, e->stream));
+    GORT_HIP(hipStreamSynchronize(e->stream));
+    return GORT_OK;
+}
+
 extern "C" int gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
                                        int member_end, double *energy_dev)
 {

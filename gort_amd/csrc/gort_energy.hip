@@ -88,17 +88,86 @@ __device__ inline long energy_rep(const double *__restrict__ angles, long line, 
 }
 
 // one thread per line, behind energy_key_kernel: slot_of[line] becomes rep[line] (in place: a line reads its own slot
-// only), and the lines that stand for themselves enter the list the evaluation walks (uniq[0] = their number; the order
-// of the list depends on the run, what is computed for a line does not)
-__global__ __launch_bounds__(256) void energy_rep_kernel(const double *__restrict__ angles, long nA,
-                                                          const unsigned *__restrict__ owner, unsigned *__restrict__ slot_of,
-                                                          unsigned *__restrict__ uniq)
+// only), and every block of 256 lines counts its lines that stand for themselves
+constexpr int TABLE_THREADS = 256;
+__global__ __launch_bounds__(TABLE_THREADS) void energy_rep_kernel(const double *__restrict__ angles, long nA,
+                                                                    const unsigned *__restrict__ owner, unsigned *__restrict__ slot_of,
+                                                                    unsigned *__restrict__ blocks)
+{
+    const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool own = false;
+    if (line < nA) {
+        const long rep = energy_rep(angles, line, owner, slot_of);
+        slot_of[line] = (unsigned)rep;
+        own = rep == line;
+    }
+    const int n = __syncthreads_count(own ? 1 : 0);
+    if (threadIdx.x == 0) blocks[blockIdx.x] = (unsigned)n;
+}
+
+// ONE workgroup: blocks[0 .. n_blocks) becomes its exclusive prefix sum, the total goes to uniq[0] (and to *n_rows_out,
+// if the caller wants the number of distinct rows on the device).  The rows of the indexed output are numbered by it:
+// in the order in which their sun directions first appear in the stream, whatever the order the lines were hashed in.
+constexpr int SCAN_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void energy_scan_kernel(unsigned *__restrict__ blocks, long n_blocks,
+                                                                    unsigned *__restrict__ uniq, unsigned *__restrict__ n_rows_out)
+{
+    __shared__ unsigned s_wave[SCAN_THREADS / 64];
+    __shared__ unsigned s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (long base = 0; base < n_blocks; base += SCAN_THREADS) {
+        const long i = base + tid;
+        const unsigned v = i < n_blocks ? blocks[i] : 0u;
+        unsigned x = v;                                       // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        unsigned before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < n_blocks) blocks[i] = before + x - v;
+        __syncthreads();
+        if (tid == SCAN_THREADS - 1) s_carry = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uniq[0] = s_carry;
+        if (n_rows_out) *n_rows_out = s_carry;
+    }
+}
+
+// one thread per line, the blocks of energy_rep_kernel: a line that stands for itself takes the next place of the list
+// (uniq[1 + place] = line; place = lines of that kind in front of it: the list is in line order) and notes it in idx[line]
+__global__ __launch_bounds__(TABLE_THREADS) void energy_place_kernel(long nA, const unsigned *__restrict__ rep,
+                                                                      const unsigned *__restrict__ blocks,
+                                                                      unsigned *__restrict__ uniq, unsigned *__restrict__ idx)
+{
+    __shared__ unsigned s_wave[TABLE_THREADS / 64];
+    const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool own = line < nA && rep[line] == (unsigned)line;
+    const unsigned long long m = __ballot(own ? 1 : 0);
+    if (lane == 0) s_wave[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (!own) return;
+    unsigned place = blocks[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) place += s_wave[w];
+    uniq[1 + place] = (unsigned)line;
+    idx[line] = place;
+}
+
+// idx[line] of the other lines: the place of the line they share their row with
+__global__ __launch_bounds__(TABLE_THREADS) void energy_index_kernel(long nA, const unsigned *__restrict__ rep, unsigned *__restrict__ idx)
 {
     const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nA) return;
-    const long rep = energy_rep(angles, line, owner, slot_of);
-    slot_of[line] = (unsigned)rep;
-    if (rep == line) uniq[1 + atomicAdd(&uniq[0], 1u)] = (unsigned)line;
+    const unsigned r = rep[line];
+    if (r != (unsigned)line) idx[line] = idx[r];
 }
 
 // The evaluation of ONE line by one 512-thread workgroup (thread = quadrature node); energy = this member's [nA][nw][3].
@@ -118,7 +187,8 @@ struct EnergyShared {
 template <bool SHARE_ROWS>
 __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *__restrict__ L, int nw,
                                             const double *__restrict__ angles, const double *__restrict__ nodes,
-                                            double *__restrict__ energy, long a, EnergyShared &sh, int band_begin, int band_end)
+                                            double *__restrict__ energy, long a, long out_row, EnergyShared &sh, int band_begin,
+                                            int band_end)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     GORT_STAMPS_BEGIN();
@@ -176,7 +246,7 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
         // energy balance, Lambertian background (gortt_albedo.c:39-52)
         const double Fu2 = b.G * s.pn0 + b.Z * (1. - s.pn0);
         const double Fd2 = s.pn0 + b.Z * (1. - s.pn0) / rs;
-        double *o = energy + (a * nw + i) * 3;
+        double *o = energy + (out_row * nw + i) * 3;
         o[0] = albedo;
         o[1] = 1. - albedo - Fd2 + Fu2;
         o[2] = Fd2 - Fu2;
@@ -200,21 +270,29 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_kernel(const gort_ca
     const long member = blockIdx.y;
     const int per = (nw + (int)gridDim.z - 1) / (int)gridDim.z, band_begin = (int)blockIdx.z * per;
     energy_line<SHARE_ROWS>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
-                            (long)blockIdx.x, sh, band_begin, band_begin + per < nw ? band_begin + per : nw);
+                            (long)blockIdx.x, (long)blockIdx.x, sh, band_begin, band_begin + per < nw ? band_begin + per : nw);
 }
 
-// the lines that stand for themselves (uniq[0] of them, uniq[1..]): workgroups stride over the list
+// the lines that stand for themselves (uniq[0] of them, uniq[1..]): workgroups stride over the list.
+// Where a list line's row goes (all list kernels): into the dense output at the line's own index, energy_all[member][nA][nw][3]
+// (rows_cap < 0) - or, the INDEXED output, to the line's place in the list, rows[member][rows_cap][nw][3], places beyond
+// rows_cap not evaluated.
+struct RowsOut {
+    long member_stride;                 // doubles between the members' outputs
+    long rows_cap;                      // < 0: dense
+};
 template <bool SHARE_ROWS>
 __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_kernel(const gort_canopy *__restrict__ canopies,
                                                                       const double *__restrict__ Lall, int nw,
                                                                       const double *__restrict__ angles, long nA,
                                                                       const double *__restrict__ nodes,
                                                                       double *__restrict__ energy_all,
-                                                                      const unsigned *__restrict__ uniq)
+                                                                      const unsigned *__restrict__ uniq, RowsOut ro)
 {
     __shared__ EnergyShared sh;
     const long member = blockIdx.y;
-    const long n_lines = uniq[0];
+    long n_lines = uniq[0];
+    if (ro.rows_cap >= 0 && n_lines > ro.rows_cap) n_lines = ro.rows_cap;
     for (long u = blockIdx.x; u < n_lines; u += gridDim.x) {
         __syncthreads();                                     // the shared arrays of the previous line are done with
         // A loop around the inlined body lets the compiler hoist the body's loop-invariant loads (canopy, nodes) in front
@@ -222,8 +300,9 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_kernel(const go
         // per CU where the per-line kernel has two).  Memory the compiler must assume changed keeps the loads where
         // they are used.
         asm volatile("" ::: "memory");
+        const long a = (long)uniq[1 + u];
         energy_line<SHARE_ROWS>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes,
-                                energy_all + member * nA * nw * 3, (long)uniq[1 + u], sh, 0, nw);
+                                energy_all + member * ro.member_stride, a, ro.rows_cap >= 0 ? u : a, sh, 0, nw);
     }
 }
 
@@ -249,15 +328,16 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
                                                                               const double *__restrict__ angles, long nA,
                                                                               const double *__restrict__ nodes,
                                                                               double *__restrict__ energy_all,
-                                                                              const unsigned *__restrict__ uniq)
+                                                                              const unsigned *__restrict__ uniq, RowsOut ro)
 {
     __shared__ EnergySharedBatch sh;
     const long member = blockIdx.y;
     const gort_canopy &c = canopies[member];
     const double *__restrict__ L = Lall + member * L_NSLOT * nw;
-    double *__restrict__ energy = energy_all + member * nA * nw * 3;
+    double *__restrict__ energy = energy_all + member * ro.member_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long n_lines = uniq[0];
+    long n_lines = uniq[0];
+    if (ro.rows_cap >= 0 && n_lines > ro.rows_cap) n_lines = ro.rows_cap;
     const double node_vaa = nodes[3 * tid], w = nodes[3 * tid + 2];
     const double row_vza = nodes[3 * (lane & (ENERGY_ZENITH_NODES - 1)) + 1];        // the zenith node whose row this lane evaluates
     // lines per pass: four where that still leaves two workgroups' worth of batches per CU, fewer for short lists (a
@@ -325,7 +405,7 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
                 // energy balance, Lambertian background (gortt_albedo.c:39-52)
                 const double Fu2 = bt.G * s.pn0 + bt.Z * (1. - s.pn0);
                 const double Fd2 = s.pn0 + bt.Z * (1. - s.pn0) / rs;
-                double *o = energy + ((long)uniq[1 + base + b] * nw + i) * 3;
+                double *o = energy + ((ro.rows_cap >= 0 ? base + b : (long)uniq[1 + base + b]) * nw + i) * 3;
                 o[0] = albedo;
                 o[1] = 1. - albedo - Fd2 + Fu2;
                 o[2] = Fd2 - Fu2;
@@ -530,14 +610,115 @@ __global__ __launch_bounds__(256) void energy_broadcast_rows_kernel(long nA, int
 
 }  // namespace
 
-// dedup workspace (bytes) for nA lines: hash table [cap] u64 + owner [cap] u32 + slot_of / rep [nA] u32 + the list of
-// self-standing lines [1 + nA] u32, cap = 2^k >= 2 nA
-size_t energy_dedup_workspace(long nA)
+// ---- the sun-direction table of nA lines (any nA >= 1) in ws_dev, energy_table_workspace(nA) bytes:
+// hash table [cap] u64 + owner [cap] u32 + slot_of / rep [nA] u32 + the list of self-standing lines [1 + nA] u32 + idx [nA] u32 +
+// per-block counts [blocks + 1] u32, cap = 2^k >= 2 nA
+namespace {
+struct EnergyTable {
+    unsigned long long *tab;
+    unsigned *owner, *rep, *uniq, *idx, *blocks;
+    size_t cap;
+    long n_blocks;
+};
+size_t table_cap(long nA)
 {
-    if (nA < ENERGY_DEDUP_MIN_LINES) return 0;
     size_t cap = 1024;
     while (cap < 2 * (size_t)nA) cap <<= 1;
-    return cap * (sizeof(unsigned long long) + sizeof(unsigned)) + (2 * (size_t)nA + 1) * sizeof(unsigned);
+    return cap;
+}
+EnergyTable carve_table(void *ws_dev, long nA)
+{
+    EnergyTable t;
+    t.cap = table_cap(nA);
+    t.n_blocks = (nA + TABLE_THREADS - 1) / TABLE_THREADS;
+    t.tab = static_cast<unsigned long long *>(ws_dev);
+    t.owner = reinterpret_cast<unsigned *>(t.tab + t.cap);
+    t.rep = t.owner + t.cap;
+    t.uniq = t.rep + nA;
+    t.idx = t.uniq + 1 + nA;
+    t.blocks = t.idx + nA;
+    return t;
+}
+}  // namespace
+
+size_t energy_table_workspace(long nA)
+{
+    if (nA < 1) return 0;
+    const size_t cap = table_cap(nA), blocks = (size_t)((nA + TABLE_THREADS - 1) / TABLE_THREADS);
+    return cap * (sizeof(unsigned long long) + sizeof(unsigned)) + (3 * (size_t)nA + 1 + blocks + 1) * sizeof(unsigned);
+}
+
+// the dense entry points build the table from ENERGY_DEDUP_MIN_LINES lines on
+size_t energy_dedup_workspace(long nA) { return nA < ENERGY_DEDUP_MIN_LINES ? 0 : energy_table_workspace(nA); }
+
+const unsigned *energy_table_index(const void *ws_dev, long nA) { return carve_table(const_cast<void *>(ws_dev), nA).idx; }
+const unsigned *energy_table_count(const void *ws_dev, long nA) { return carve_table(const_cast<void *>(ws_dev), nA).uniq; }
+
+// rep[line] = the first line of the stream with `line`'s normalised sun direction; the list of those first lines in line
+// order (uniq[0] = their number, also written to *n_rows_out_dev if given); idx[line] = the place of rep[line] in the list
+int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream)
+{
+    if (nA <= 0) return GORT_OK;
+    if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
+    if (!ws_dev) return fail(GORT_EINVAL, "energy: no workspace for the sun-direction table");
+    hipStream_t s = (hipStream_t)stream;
+    const EnergyTable t = carve_table(ws_dev, nA);
+    if (hipMemsetAsync(t.tab, 0, t.cap * sizeof(unsigned long long), s) != hipSuccess ||
+        hipMemsetAsync(t.owner, 0xff, t.cap * sizeof(unsigned), s) != hipSuccess)
+        return fail(GORT_ENODEVICE, "energy: cannot clear the sun-direction table");
+    const dim3 grid((unsigned)t.n_blocks), block(TABLE_THREADS);
+    hipLaunchKernelGGL(energy_key_kernel, grid, block, 0, s, angles_dev, nA, t.tab, t.owner, (unsigned)(t.cap - 1), t.rep);
+    int rc = check_launch("energy_key_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(energy_rep_kernel, grid, block, 0, s, angles_dev, nA, (const unsigned *)t.owner, t.rep, t.blocks);
+    if ((rc = check_launch("energy_rep_kernel"))) return rc;
+    hipLaunchKernelGGL(energy_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, t.blocks, t.n_blocks, t.uniq, n_rows_out_dev);
+    if ((rc = check_launch("energy_scan_kernel"))) return rc;
+    hipLaunchKernelGGL(energy_place_kernel, grid, block, 0, s, nA, (const unsigned *)t.rep, (const unsigned *)t.blocks, t.uniq, t.idx);
+    if ((rc = check_launch("energy_place_kernel"))) return rc;
+    hipLaunchKernelGGL(energy_index_kernel, grid, block, 0, s, nA, (const unsigned *)t.rep, t.idx);
+    return check_launch("energy_index_kernel");
+}
+
+// the list kernel behind a table: rows_cap < 0 dense (out_dev[member][nA][nw][3], the owners' rows only), else the indexed
+// form (out_dev[member][rows_cap][nw][3]); n_rows_known: the length of the list if the host has it (else -1: up to nA)
+static int launch_energy_list(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw, const double *angles_dev,
+                              long nA, const double *nodes_dev, double *out_dev, long rows_cap, const EnergyTable &t,
+                              long n_rows_known, hipStream_t s)
+{
+    const char *sr = getenv("GORT_ENERGY_SHARE_ROWS");       // read per call: the test switches it inside one process
+    const bool share_rows = !(sr && atoi(sr) == 0);
+    long most = n_rows_known >= 0 ? n_rows_known : nA;
+    if (rows_cap >= 0 && most > rows_cap) most = rows_cap;
+    if (most <= 0) return GORT_OK;
+    const unsigned wgs = (unsigned)(most < 8192 ? most : 8192);
+    RowsOut ro;
+    ro.rows_cap = rows_cap;
+    ro.member_stride = (rows_cap >= 0 ? rows_cap : nA) * (long)nw * 3;
+    const char *pl = getenv("GORT_ENERGY_BATCH");            // 0: one line after the other (tests compare the two)
+    if (share_rows && !(pl && atoi(pl) == 0))
+        hipLaunchKernelGGL(energy_list_batched_kernel, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev,
+                           nw, angles_dev, nA, nodes_dev, out_dev, (const unsigned *)t.uniq, ro);
+    else if (share_rows)
+        hipLaunchKernelGGL(energy_list_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
+                           angles_dev, nA, nodes_dev, out_dev, (const unsigned *)t.uniq, ro);
+    else
+        hipLaunchKernelGGL(energy_list_kernel<false>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
+                           angles_dev, nA, nodes_dev, out_dev, (const unsigned *)t.uniq, ro);
+    return check_launch("energy_list_kernel");
+}
+
+// INDEXED output: the distinct rows only, rows_dev[member][rows_cap][nw][3] in the order of the table's list (places beyond
+// rows_cap are not evaluated); ws_dev holds the table of these very lines (launch_energy_table, any stream ordered before `stream`)
+int launch_energy_rows(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw, const double *angles_dev,
+                       long nA, const double *nodes_dev, double *rows_dev, long rows_cap, const void *ws_dev, long n_rows_known,
+                       void *stream)
+{
+    if (nA <= 0 || nw <= 0 || n_members <= 0 || rows_cap <= 0) return GORT_OK;
+    if (n_members > 65535) return fail(GORT_EINVAL, "energy: %d members in one launch (max 65535)", n_members);
+    if (!ws_dev) return fail(GORT_EINVAL, "energy: no sun-direction table");
+    return launch_energy_list(canopies_dev, n_members, L_dev, nw, angles_dev, nA, nodes_dev, rows_dev, rows_cap,
+                              carve_table(const_cast<void *>(ws_dev), nA), n_rows_known, (hipStream_t)stream);
 }
 
 // ws_dev: energy_dedup_workspace(nA) bytes, or nullptr = every line evaluated (few lines; tests compare the two)
@@ -548,9 +729,9 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     if (nA <= 0 || nw <= 0 || n_members <= 0) return GORT_OK;
     if (n_members > 65535) return fail(GORT_EINVAL, "energy: %d members in one launch (max 65535)", n_members);
     hipStream_t s = (hipStream_t)stream;
-    const char *sr = getenv("GORT_ENERGY_SHARE_ROWS");       // read per call: the test switches it inside one process
-    const bool share_rows = !(sr && atoi(sr) == 0);
     if (!ws_dev || nA < ENERGY_DEDUP_MIN_LINES) {
+        const char *sr = getenv("GORT_ENERGY_SHARE_ROWS");   // read per call: the test switches it inside one process
+        const bool share_rows = !(sr && atoi(sr) == 0);
         if (nA >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld lines in one launch", nA);
         // band ranges: as many as give every range one pass, as far as every workgroup still has a CU of its own (two
         // per CU measured slower than none: C4 27.4 us unsplit, 25.8 in two ranges = 182 workgroups, 29.3 in three)
@@ -574,37 +755,14 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
                                canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
         return check_launch("energy_kernel");
     }
-    if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
-    size_t cap = 1024;
-    while (cap < 2 * (size_t)nA) cap <<= 1;
-    unsigned long long *tab = static_cast<unsigned long long *>(ws_dev);
-    unsigned *owner = reinterpret_cast<unsigned *>(tab + cap);
-    unsigned *slot_of = owner + cap;
-    unsigned *uniq = slot_of + nA;
-    if (hipMemsetAsync(tab, 0, cap * sizeof(unsigned long long), s) != hipSuccess ||
-        hipMemsetAsync(owner, 0xff, cap * sizeof(unsigned), s) != hipSuccess ||
-        hipMemsetAsync(uniq, 0, sizeof(unsigned), s) != hipSuccess)
-        return fail(GORT_ENODEVICE, "energy: cannot clear the sun-direction table");
-    hipLaunchKernelGGL(energy_key_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, angles_dev, nA, tab, owner,
-                       (unsigned)(cap - 1), slot_of);
-    int rc = check_launch("energy_key_kernel");
+    int rc = launch_energy_table(angles_dev, nA, ws_dev, nullptr, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(energy_rep_kernel, dim3((unsigned)((nA + 255) / 256)), dim3(256), 0, s, angles_dev, nA, (const unsigned *)owner,
-                       slot_of, uniq);
-    if ((rc = check_launch("energy_rep_kernel"))) return rc;
-    const unsigned *rep = slot_of;
-    const unsigned wgs = (unsigned)(nA < 8192 ? nA : 8192);
-    const char *pl = getenv("GORT_ENERGY_BATCH");            // 0: one line after the other (tests compare the two)
-    if (share_rows && !(pl && atoi(pl) == 0))
-        hipLaunchKernelGGL(energy_list_batched_kernel, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev,
-                           nw, angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
-    else if (share_rows)
-        hipLaunchKernelGGL(energy_list_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
-                           angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
-    else
-        hipLaunchKernelGGL(energy_list_kernel<false>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
-                           angles_dev, nA, nodes_dev, energy_dev, (const unsigned *)uniq);
-    if ((rc = check_launch("energy_list_kernel"))) return rc;
+    const EnergyTable t = carve_table(ws_dev, nA);
+    if ((rc = launch_energy_list(canopies_dev, n_members, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev, -1, t, -1, s))) return rc;
+    const unsigned *rep = t.rep;
+    const unsigned *uniq = t.uniq;
+    unsigned long long *tab = t.tab;
+    const size_t cap = t.cap;
     const int row = 3 * nw;
     // rows of at least a KiB, and counters that fit the table's memory (done with by now): the row-by-row form is launched
     // too, and the number of owner lines decides on the device which of the two works (broadcast_goes_by_rows)

@@ -154,9 +154,27 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
 // xcd_round_robin: workgroups b, b + 8, ... share an XCD (probe_xcd_dispatch): the row copy then gives every XCD one
 // contiguous run of its panels
 size_t energy_dedup_workspace(long nA);
+// ---- the sun-direction table by itself, and the INDEXED form of the output (gort_energy_stream_indexed*, GORT_PIPE_ENERGY_INDEXED)
+// ws_dev: energy_table_workspace(nA) bytes (any nA >= 1).  launch_energy_table leaves in it rep[line], the list of the lines
+// whose sun direction appears for the first time (in line order), and idx[line] = the place of line's row in that list;
+// *n_rows_out_dev (may be null) = the length of the list.  launch_energy_rows evaluates the list into
+// rows_dev[member][rows_cap][nw][3] (places beyond rows_cap are skipped; n_rows_known = the length if the host knows it, else -1).
+size_t energy_table_workspace(long nA);
+int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream);
+const unsigned *energy_table_index(const void *ws_dev, long nA);      // idx[nA]
+const unsigned *energy_table_count(const void *ws_dev, long nA);      // the length of the list
+int launch_energy_rows(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw, const double *angles_dev,
+                       long nA, const double *nodes_dev, double *rows_dev, long rows_cap, const void *ws_dev, long n_rows_known,
+                       void *stream);
 int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                   const double *angles_dev, long nA, const double *nodes_dev, double *energy_dev, void *ws_dev,
                   bool xcd_round_robin, void *stream);
 
 }  // namespace gort
+
+// the two halves of gort_energy_stream_indexed_dev for gort_pipe (gort_api.hip): the table of a chunk's lines on a stream of
+// the caller's choice into a workspace of its own (energy_table_workspace bytes), then - the caller has read the number of
+// rows - the rows on the engine's stream
+int gort_engine_energy_table(gort_engine *e, const double *angles_dev, long nA, void *ws_dev, uint32_t *n_rows_dev, void *stream);
+int gort_engine_energy_rows(gort_engine *e, const double *angles_dev, long nA, const void *ws_dev, long n_rows, double *rows_dev);
 #endif

@@ -37,8 +37,11 @@ namespace {
 struct Slot {
     double *h_ang = nullptr, *h_rsurf = nullptr, *h_scomp = nullptr, *h_K = nullptr, *h_energy = nullptr;   // pinned
     double *d_ang = nullptr, *d_rsurf = nullptr, *d_scomp = nullptr, *d_K = nullptr, *d_energy = nullptr;   // HBM
+    // GORT_PIPE_ENERGY_INDEXED: the sun-direction table of the chunk (device), its line index and row count (pinned host)
+    void *d_table = nullptr;
+    uint32_t *h_index = nullptr, *h_rows = nullptr;
     hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
-    long n = 0;
+    long n = 0, energy_rows = 0;
     int rc = GORT_OK;            // error raised while the chunk was submitted; reported by gort_pipe_wait
     std::string err;             // its message
 };
@@ -83,6 +86,9 @@ extern "C" void gort_pipe_destroy(gort_pipe *p)
     for (Slot &s : p->slots) {
         for (double *h : {s.h_ang, s.h_rsurf, s.h_scomp, s.h_K, s.h_energy}) if (h) (void)hipHostFree(h);
         for (double *d : {s.d_ang, s.d_rsurf, s.d_scomp, s.d_K, s.d_energy}) if (d) (void)hipFree(d);
+        if (s.d_table) (void)hipFree(s.d_table);
+        if (s.h_index) (void)hipHostFree(s.h_index);
+        if (s.h_rows) (void)hipHostFree(s.h_rows);
         for (hipEvent_t ev : {s.ev_in, s.ev_k, s.ev_out}) if (ev) (void)hipEventDestroy(ev);
     }
     if (p->s_in) (void)hipStreamDestroy(p->s_in);
@@ -111,6 +117,11 @@ static int pipe_alloc(gort_pipe *p)
         }
         if ((p->flags & GORT_PIPE_SCOMP) && (rc = both(&s.h_scomp, &s.d_scomp, D * 4 * n * nw))) return rc;
         if ((p->flags & GORT_PIPE_ENERGY) && (rc = both(&s.h_energy, &s.d_energy, D * 3 * n * nw))) return rc;
+        if (p->flags & GORT_PIPE_ENERGY_INDEXED) {
+            PIPE_HIP(hipMalloc(&s.d_table, energy_table_workspace(p->max_lines)));
+            PIPE_HIP(hipHostMalloc((void **)&s.h_index, sizeof(uint32_t) * n, hipHostMallocDefault));
+            PIPE_HIP(hipHostMalloc((void **)&s.h_rows, 64, hipHostMallocDefault));
+        }
         PIPE_HIP(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
         PIPE_HIP(hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming));
         PIPE_HIP(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming | hipEventBlockingSync));
@@ -125,6 +136,8 @@ extern "C" int gort_pipe_create(gort_engine *e, long max_lines, int depth, unsig
     if (!e || max_lines <= 0 || depth < 1 || depth > 16) return fail(GORT_EINVAL, "gort_pipe_create: bad argument");
     if ((flags & GORT_PIPE_ENERGY_ONLY) && (flags & GORT_PIPE_SCOMP)) return fail(GORT_EINVAL, "gort_pipe_create: ENERGY_ONLY with SCOMP");
     if (flags & GORT_PIPE_ENERGY_ONLY) flags |= GORT_PIPE_ENERGY;
+    if ((flags & GORT_PIPE_ENERGY_INDEXED) && !(flags & GORT_PIPE_ENERGY))
+        return fail(GORT_EINVAL, "gort_pipe_create: ENERGY_INDEXED without ENERGY or ENERGY_ONLY");
     gort_pipe *p = new (std::nothrow) gort_pipe();
     if (!p) return fail(GORT_ENOMEM, "gort_pipe_create: out of memory");
     p->e = e;
@@ -178,6 +191,7 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
         return s.rc;
     }
     s.n = n;
+    s.energy_rows = (p->flags & GORT_PIPE_ENERGY) && !(p->flags & GORT_PIPE_ENERGY_INDEXED) && p->nw > 0 ? n : 0;
     s.rc = GORT_OK;
     s.err.clear();
     (void)hipSetDevice(p->device);
@@ -189,12 +203,25 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
             return GORT_OK;
         }
         PIPE_HIP(hipMemcpyAsync(s.d_ang, s.h_ang, D * 4 * nn, hipMemcpyHostToDevice, p->s_in));
-        PIPE_HIP(hipEventRecord(s.ev_in, p->s_in));
-        PIPE_HIP(hipStreamWaitEvent(ks, s.ev_in, 0));
+        const bool indexed = s.d_table && nw > 0;
         int rc = GORT_OK;
+        if (indexed) {
+            // the chunk's sun directions are counted behind its copy in, on the copy-in stream - not behind the kernels of the
+            // chunks in front - and the host waits for the count: it sizes the evaluation and the copy out
+            const uint32_t *count_dev = energy_table_count(s.d_table, n);
+            if ((rc = gort_engine_energy_table(p->e, s.d_ang, n, s.d_table, nullptr, p->s_in))) return rc;
+            PIPE_HIP(hipMemcpyAsync(s.h_rows, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_in));
+        }
+        PIPE_HIP(hipEventRecord(s.ev_in, p->s_in));
+        if (indexed) {
+            PIPE_HIP(hipEventSynchronize(s.ev_in));
+            s.energy_rows = (long)*s.h_rows;
+        }
+        PIPE_HIP(hipStreamWaitEvent(ks, s.ev_in, 0));
         if (nw > 0 && s.d_rsurf) rc = gort_rsurf_stream_dev(p->e, s.d_ang, n, s.d_rsurf, s.d_scomp, s.d_K);
         else if (nw == 0 && s.d_K) rc = gort_rsurf_stream_dev(p->e, s.d_ang, n, nullptr, nullptr, s.d_K);   // proportions only
-        if (rc == GORT_OK && s.d_energy && nw > 0) rc = gort_energy_stream_dev(p->e, s.d_ang, n, s.d_energy);
+        if (rc == GORT_OK && indexed) rc = gort_engine_energy_rows(p->e, s.d_ang, n, s.d_table, s.energy_rows, s.d_energy);
+        else if (rc == GORT_OK && s.d_energy && nw > 0) rc = gort_energy_stream_dev(p->e, s.d_ang, n, s.d_energy);
         if (rc) return rc;
         PIPE_HIP(hipEventRecord(s.ev_k, ks));
         PIPE_HIP(hipStreamWaitEvent(p->s_out, s.ev_k, 0));
@@ -205,7 +232,10 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
                 PIPE_HIP(hipMemcpyAsync(s.h_K, s.d_K, D * 4 * nn, hipMemcpyDeviceToHost, p->s_out));
             }
             if (s.d_scomp) PIPE_HIP(hipMemcpyAsync(s.h_scomp, s.d_scomp, D * 4 * nn * nw, hipMemcpyDeviceToHost, p->s_out));
-            if (s.d_energy) PIPE_HIP(hipMemcpyAsync(s.h_energy, s.d_energy, D * 3 * nn * nw, hipMemcpyDeviceToHost, p->s_out));
+            if (s.d_energy && s.energy_rows > 0)
+                PIPE_HIP(hipMemcpyAsync(s.h_energy, s.d_energy, D * 3 * (size_t)s.energy_rows * nw, hipMemcpyDeviceToHost, p->s_out));
+            if (indexed)
+                PIPE_HIP(hipMemcpyAsync(s.h_index, energy_table_index(s.d_table, n), sizeof(uint32_t) * nn, hipMemcpyDeviceToHost, p->s_out));
         }
         PIPE_HIP(hipEventRecord(s.ev_out, p->s_out));
         return GORT_OK;
@@ -238,6 +268,8 @@ extern "C" int gort_pipe_wait(gort_pipe *p, gort_pipe_chunk *out)
     out->scomp = s.h_scomp;
     out->K = s.h_K;
     out->energy = s.h_energy;
+    out->energy_index = s.d_table && p->nw > 0 ? s.h_index : nullptr;
+    out->energy_rows = s.energy_rows;
     (void)hipSetDevice(p->device);
     if (s.rc) {
         // part of the chunk may have been queued before the failure (the copy in, some kernels): nothing of it may

@@ -104,7 +104,11 @@ int main(int argc, char **argv)
             std::fprintf(stderr, "%s: device %d asked for (--gpus / GORTT_DEVICES), this machine has %d\n", argv[0], d, gort_device_count());
             return EXIT_FAILURE;
         }
-    const size_t per_line_out = (size_t)nw * (1 + (o.prnspec ? 4 : 0) + (o.energy ? 3 : 0)) + 8;
+    // -energy: what gortt_energy computes depends on the line's sun direction only (gortt_albedo.c:62-138), so a chunk's albedo
+    // rows come from the device in the INDEXED form - each distinct row once + one index per line (GORT_PIPE_ENERGY_INDEXED) -
+    // and each is formatted once; GORTT_ENERGY_DENSE=1 keeps a row per line on the device, over PCIe and in the formatter
+    const bool energy_dense = o.energy && std::getenv("GORTT_ENERGY_DENSE") && std::atoi(std::getenv("GORTT_ENERGY_DENSE")) != 0;
+    const size_t per_line_out = (size_t)nw * (1 + (o.prnspec ? 4 : 0) + (energy_dense ? 3 : 0)) + 8;
     size_t chunk_mb = 48;                                        // GORTT_CHUNK_MB: output bytes per chunk
     if (const char *v = std::getenv("GORTT_CHUNK_MB")) { const long m = atol(v); if (m >= 1 && m <= 4096) chunk_mb = (size_t)m; }
     const bool verbose = std::getenv("GORTT_VERBOSE") != nullptr;   // stage timings on stderr
@@ -117,7 +121,8 @@ int main(int argc, char **argv)
     // small inputs: small pinned buffers and one slot (a stream longer than its header says still works, unpipelined)
     if (na_check > 0 && na_check < CHUNK) CHUNK = na_check < 256 ? 256 : na_check;
     const int depth = (na_check > 0 && na_check <= CHUNK) ? 1 : 3;
-    const unsigned pflags = (o.prnspec ? GORT_PIPE_SCOMP : 0u) | (o.energy ? GORT_PIPE_ENERGY : 0u);
+    const unsigned pflags = (o.prnspec ? GORT_PIPE_SCOMP : 0u) | (o.energy ? GORT_PIPE_ENERGY : 0u) |
+                            (o.energy && !energy_dense ? GORT_PIPE_ENERGY_INDEXED : 0u);
     struct Dev { gort_engine *eng = nullptr; gort_pipe *pipe = nullptr; int id = -1; };
     std::vector<Dev> devs(devices.size());
     for (size_t d = 0; d < devs.size(); ++d) {
@@ -140,6 +145,8 @@ int main(int argc, char **argv)
     bool producer_done = false;
     std::string consumer_error;
     long na = 0;
+    // the text of a chunk's distinct albedo rows, each formatted once (indexed form)
+    std::vector<Out> energy_text;
     auto format_lines = [&](const gort_pipe_chunk &c, long a0, long a1, Out &dst) {
         for (long a = a0; a < a1; ++a) {
             for (int q = 0; q < 4; ++q) dst.raw(c.angles[4 * a + q]);
@@ -158,7 +165,12 @@ int main(int argc, char **argv)
                 dst.nums(c.K + 4 * a, 4);            // without wavelengths too (`N 0`): gortt.c:424-449 run in front of the loop
                 dst.text("] ", 2);
             }
-            if (o.energy) dst.nums(c.energy + (size_t)a * nw * 3, 3L * nw);
+            if (o.energy && c.energy_index) {
+                const Out &row = energy_text[c.energy_index[a]];
+                dst.text(row.buf.data(), row.len);
+            } else if (o.energy) {
+                dst.nums(c.energy + (size_t)a * nw * 3, 3L * nw);
+            }
             dst.text("\n", 1);
         }
     };
@@ -192,7 +204,7 @@ int main(int argc, char **argv)
                 }
             }
             if (o.prnprop) add(c.K + 4 * a, 4);
-            if (o.energy) add(c.energy + (size_t)a * nw * 3, (size_t)nw * 3);
+            if (o.energy) add(c.energy + (size_t)(c.energy_index ? c.energy_index[a] : a) * nw * 3, (size_t)nw * 3);
             if (iov.size() + 8 + (o.prnspec ? 2 * (size_t)nw : 0) > 1024 && !flush()) return false;
         }
         return flush();
@@ -229,7 +241,29 @@ int main(int argc, char **argv)
             } else {
                 // text rows: the formatting (exact "%f", gort_format_f6) is the slowest stage of the whole program, so
                 // the lines of a chunk are formatted by several threads into their own buffers and written in order
-                const size_t per_line = 4 + (size_t)nw * (o.prnspec ? 5 : 1) + (o.prnprop ? 4 : 0) + (o.energy ? 3 * (size_t)nw : 0);
+                const bool indexed = o.energy && c.energy_index && nw > 0;
+                if (indexed) {
+                    // each distinct row once, by as many threads as the numbers are worth
+                    const long nr = c.energy_rows;
+                    if ((long)energy_text.size() < nr) energy_text.resize((size_t)nr);
+                    auto rows_text = [&](long r0, long r1) {
+                        for (long r = r0; r < r1; ++r) {
+                            energy_text[(size_t)r].len = 0;
+                            energy_text[(size_t)r].nums(c.energy + (size_t)r * nw * 3, 3L * nw);
+                        }
+                    };
+                    const unsigned rw = format_threads((size_t)nr * 3 * (size_t)nw);
+                    if (rw <= 1) {
+                        rows_text(0, nr);
+                    } else {
+                        std::vector<std::thread> pool;
+                        for (unsigned t = 0; t < rw; ++t) pool.emplace_back(rows_text, nr * (long)t / rw, nr * (long)(t + 1) / rw);
+                        for (auto &th : pool) th.join();
+                    }
+                }
+                // copying a formatted row costs about a tenth of formatting it
+                const size_t per_line = 4 + (size_t)nw * (o.prnspec ? 5 : 1) + (o.prnprop ? 4 : 0) +
+                                        (o.energy ? (indexed ? 3 * (size_t)nw / 8 : 3 * (size_t)nw) : 0);
                 const unsigned workers = format_threads((size_t)n * per_line);
                 if (workers <= 1) {
                     for (long a0 = 0; a0 < n; a0 += 4096) {

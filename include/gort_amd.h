@@ -299,6 +299,22 @@ int  gort_rsurf_members_stream_dev(gort_engine *e, const double *angles_dev, lon
  * viewing hemisphere.  energy[nA][nw][3] = albedo, favegt, fasoil (print order, gortt.c:323-324) */
 int  gort_energy_stream(gort_engine *e, const double *angles, long nA, double *energy);
 int  gort_energy_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *energy_dev);
+/* The same without the copies.  What gortt_energy computes for a line depends on the line's SUN direction only - the view
+ * angles are the quadrature nodes (gortt_albedo.c:62-138 overwrites g->vza and g->vaa; main() calls it once per line all the
+ * same, gortt.c:321-327) - so a stream holds as many DISTINCT rows as it has distinct normalised (sun zenith, sun azimuth)
+ * pairs: 91 for a million lines of a 1-degree sun grid.  The indexed form hands out each of them once:
+ *   rows[n_rows][nw][3]   the distinct rows, in the order in which their sun directions first appear in the stream
+ *   index[nA]             line a's row is rows[index[a]] - bit for bit the row gort_energy_stream writes for line a
+ *   n_rows                their number
+ * rows_cap = the room in `rows`, in rows (nA is always enough).  Host form: if the stream has more distinct rows than
+ * rows_cap nothing is evaluated, *n_rows says how many there are, index is filled in, and the call fails with GORT_ERANGE.
+ * Device form (asynchronous on the engine's stream like every *_dev entry point): rows beyond rows_cap are not evaluated,
+ * *n_rows_dev holds the full count - compare it with rows_cap after synchronising.  New surface: the reference prints the
+ * 3 nw numbers again for every line (gortt.c:323-324). */
+int  gort_energy_stream_indexed(gort_engine *e, const double *angles, long nA, double *rows, long rows_cap,
+                                uint32_t *index, long *n_rows);
+int  gort_energy_stream_indexed_dev(gort_engine *e, const double *angles_dev, long nA, double *rows_dev, long rows_cap,
+                                    uint32_t *index_dev, uint32_t *n_rows_dev);
 /* the same nA angle lines for ensemble members [member_begin, member_end): energy_dev[member][nA][nw][3] -
  * the reduced per-member product (albedo, fAPAR) an ensemble driver exchanges between GPUs */
 int  gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, int member_begin,
@@ -310,20 +326,28 @@ int  gort_energy_members_dev(gort_engine *e, const double *angles_dev, long nA, 
  * on streams of their own and ordered by events; the host is free to parse and format meanwhile.
  *   gort_pipe_create   slots of max_lines lines each for the engine's current band count (set canopy and spectra
  *                      first; do not change the band count while the pipe lives).  flags: GORT_PIPE_SCOMP (component
- *                      spectra, -prnspec), GORT_PIPE_ENERGY (albedo/fAPAR, -energy), GORT_PIPE_ENERGY_ONLY.
+ *                      spectra, -prnspec), GORT_PIPE_ENERGY (albedo/fAPAR, -energy), GORT_PIPE_ENERGY_ONLY;
+ *                      GORT_PIPE_ENERGY_INDEXED beside either of the last two: a chunk's albedo rows arrive in the indexed
+ *                      form of gort_energy_stream_indexed - `energy` holds the chunk's energy_rows DISTINCT rows
+ *                      [energy_rows][nw][3] and energy_index[n] says which one is a line's - so that rows that are copies
+ *                      are neither written, nor copied over PCIe, nor formatted again by the consumer (gort_pipe_submit
+ *                      then waits for the chunk's angles to arrive and its sun directions to be counted: tens of us).
  *                      Host buffers are pinned.
  *   gort_pipe_acquire  blocks until a slot is free; *angles = its pinned input buffer [max_lines][4] (degrees)
  *   gort_pipe_submit   n lines of the acquired slot: copy in, kernels, copy out are queued; returns at once
  *   gort_pipe_wait     blocks until the OLDEST submitted chunk has arrived on the host; its buffers stay valid
- *                      until gort_pipe_release (rsurf[n][nw], scomp[n][nw][4] or NULL, K[n][4], energy[n][nw][3] or NULL)
+ *                      until gort_pipe_release (rsurf[n][nw], scomp[n][nw][4] or NULL, K[n][4], energy[energy_rows][nw][3] or NULL)
  *   acquire/submit belong to one thread, wait/release to one (possibly another) thread. */
 #define GORT_PIPE_SCOMP  1u
 #define GORT_PIPE_ENERGY 2u
 #define GORT_PIPE_ENERGY_ONLY 4u     /* albedo/fAPAR without rsurf and K (those pointers of a chunk are NULL) */
+#define GORT_PIPE_ENERGY_INDEXED 8u  /* energy = the distinct rows, energy_index[n] = each line's row */
 typedef struct gort_pipe gort_pipe;
 typedef struct gort_pipe_chunk {
     long n;
     const double *angles, *rsurf, *scomp, *K, *energy;
+    const uint32_t *energy_index;    /* GORT_PIPE_ENERGY_INDEXED: [n], else NULL */
+    long energy_rows;                /* rows in `energy`: n without GORT_PIPE_ENERGY_INDEXED (0 without energy) */
 } gort_pipe_chunk;
 int  gort_pipe_create(gort_engine *e, long max_lines, int depth, unsigned flags, gort_pipe **out);
 int  gort_pipe_acquire(gort_pipe *p, double **angles);

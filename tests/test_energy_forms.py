@@ -179,3 +179,65 @@ def test_member_batched_broadcast_same_bits():
     assert (n * wl.size * 3) % 2 == 1
     assert not (res["1"] == -7.0).any()
     assert np.array_equal(_bits(res["1"]), _bits(res["0"]))
+
+
+@pytest.mark.parametrize("nw,n", [(61, 3001), (2101, 702), (5, 129), (43, 4001), (128, 100003), (7, 1), (513, 90)])
+def test_indexed_rows_equal_the_dense_output_bitwise(nw, n):
+    """gort_energy_stream_indexed_dev: rows[index[a]] is the row gort_energy_stream_dev writes for line a, bit for bit; the
+    rows are numbered in the order in which their normalised sun directions first appear (numpy's own first-occurrence
+    order of the same keys); a rows_cap below the count leaves the rows beyond it untouched and still reports the count.
+    The shapes of the tests above: every line its own sun (3001, 702; one of them NaN), few suns with -sza / saa + 180
+    twins, streams shorter than the dense path's table threshold (1 and 90 lines)."""
+    import torch
+    wl = np.linspace(400.0, 2500.0, nw)
+    rng = np.random.default_rng(1000 + nw + n)
+    if n in (3001, 702, 1):
+        ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), rng.uniform(0, 89.9, n), rng.uniform(-400, 400, n)], 1)
+        if n > 10:
+            ang[3, 2] = 90.0
+            ang[7, 2] = np.nan
+    else:
+        sza = (1.0 + rng.integers(0, 12, n)) * 7.0
+        saa = rng.choice(np.array([0.0, 77.5, 180.0]), n)
+        flip = rng.random(n) < 0.2
+        ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(-400, 400, n), np.where(flip, -sza, sza), np.where(flip, saa + 180.0, saa)], 1)
+    e = _engine(wl)
+    dense = _energy(e, ang, nw, torch, offset=1)
+    a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
+    cap = n + 2
+    rows = torch.full((cap, nw, 3), -7.0, dtype=torch.float64, device="cuda")
+    index = torch.full((n + 1,), 0x7fffffff, dtype=torch.int32, device="cuda")
+    count = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    e.energy_stream_indexed_dev(a, rows, index, count)
+    e.synchronize()
+    n_rows = int(count[0])
+    idx = index[:n].cpu().numpy()
+    assert int(index[n]) == 0x7fffffff and int(count[1]) == -1
+    r = rows.cpu().numpy()
+    assert (r[n_rows:] == -7.0).all() and not (r[:n_rows] == -7.0).any()
+    assert idx.min() == 0 and idx.max() == n_rows - 1
+    assert np.array_equal(_bits(r[idx]), _bits(dense))
+    # first-appearance order: the index of a line that opens a new row is one more than everything in front of it
+    first = np.full(n_rows, -1)
+    for line in range(n - 1, -1, -1):
+        first[idx[line]] = line
+    assert (np.diff(first) > 0).all() and np.array_equal(idx[first], np.arange(n_rows))
+    # no more rows than the input has distinct (sun zenith, sun azimuth) pairs as typed; every line its own sun: a row per line
+    typed = len({(x, y) for x, y in zip(ang[:, 2].tolist(), ang[:, 3].tolist())})
+    assert n_rows <= typed and (n_rows == n if n in (3001, 702, 1) else n_rows <= 72)
+    # too little room: the count is still the full one, the rows beyond the room are not touched
+    if n_rows > 2:
+        rows2 = torch.full((n_rows - 1, nw, 3), -7.0, dtype=torch.float64, device="cuda")
+        guard = torch.full((4 * nw,), -7.0, dtype=torch.float64, device="cuda")
+        e.energy_stream_indexed_dev(a, rows2[:n_rows - 2], index, count)
+        e.synchronize()
+        assert int(count[0]) == n_rows and float(rows2[n_rows - 2].max()) == -7.0 and float(guard.max()) == -7.0
+        assert np.array_equal(_bits(rows2[:n_rows - 2].cpu().numpy()), _bits(r[:n_rows - 2]))
+    # the host form: the same rows and index; too little room is GORT_ERANGE with the count
+    hrows, hidx = e.energy_stream_indexed(ang)
+    assert hrows.shape[0] == n_rows and np.array_equal(hidx, idx) and np.array_equal(_bits(hrows), _bits(r[:n_rows]))
+    if n_rows > 1:
+        with pytest.raises(api.GortError, match="%d distinct sun directions" % n_rows):
+            e.energy_stream_indexed(ang, rows_cap=n_rows - 1)
+    e.close()

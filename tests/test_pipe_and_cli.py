@@ -105,6 +105,77 @@ def test_host_entry_pinned_equals_staged_equals_oracle(eng):
     assert np.array_equal(e_big[:200].view(np.int64), e_small.view(np.int64))
 
 
+def test_pipe_indexed_energy_equals_dense_energy(eng):
+    """GORT_PIPE_ENERGY_INDEXED: a chunk's `energy` holds its distinct rows and energy_index[line] picks the line's; chunk
+    by chunk the same bits as the dense pipe, with and without the reflectances beside them, an empty chunk, a chunk of one
+    line, and chunks in which every line has its own sun."""
+    rng = np.random.default_rng(21)
+    wl = np.linspace(400.0, 2500.0, 333)
+    eng.set_spectra(*api.spectra(wl))
+    ang = _lines(rng, 5 * 700, distinct=False)
+    ang[700:1400, 2] = rng.uniform(0, 89, 700)                     # second chunk: nothing shared
+    ang[:, 3] = rng.choice([0.0, 123.0], ang.shape[0])
+    sizes = [700, 700, 0, 1, 700, 699]
+    for flags in (api.PIPE_ENERGY, api.PIPE_ENERGY_ONLY):
+        dense_pipe = api.Pipe(eng, 700, depth=2, flags=flags)
+        pipe = api.Pipe(eng, 700, depth=3, flags=flags | api.PIPE_ENERGY_INDEXED)
+        at = 0
+        for n in sizes:
+            for q in (dense_pipe, pipe):
+                a = q.acquire(); a[:n] = ang[at:at + n]; q.submit(n)
+            d, c = dense_pipe.wait(), pipe.wait()
+            assert c["n"] == n == d["n"]
+            if n == 0:
+                assert c["energy_rows"] == 0 and c["energy"] is None
+            else:
+                assert d["energy_index"] is None and d["energy_rows"] == n
+                assert 1 <= c["energy_rows"] <= n and c["energy"].shape == (c["energy_rows"], wl.size, 3)
+                assert c["energy_rows"] == (n if at == 700 else len({(x, y) for x, y in ang[at:at + n, 2:].tolist()}))
+                assert np.array_equal(c["energy"][c["energy_index"]].view(np.int64), d["energy"].view(np.int64))
+                if flags == api.PIPE_ENERGY:
+                    assert np.array_equal(c["rsurf"].view(np.int64), d["rsurf"].view(np.int64)) and np.array_equal(c["K"], d["K"])
+                else:
+                    assert c["rsurf"] is None
+            dense_pipe.release(); pipe.release()
+            at += n
+        dense_pipe.close(); pipe.close()
+    with pytest.raises(api.GortError, match="ENERGY_INDEXED without"):
+        api.Pipe(eng, 16, depth=1, flags=api.PIPE_ENERGY_INDEXED)
+
+
+def test_cli_energy_rows_formatted_once_equal_rows_formatted_per_line():
+    """`gortt -energy`: the indexed pipe (each distinct albedo row copied and formatted once per chunk) writes the bytes of
+    the dense path (GORTT_ENERGY_DENSE=1: a row per line, as gortt.c:321-327 evaluates them) - text over several chunks and
+    formatting threads, binary, with -prnprop and -prnspec beside it, every line its own sun, and an empty stream."""
+    rng = np.random.default_rng(22)
+    n, wl = 6000, np.linspace(400, 2500, 211).round(1)
+    ang = np.round(_lines(rng, n, distinct=False), 3)
+    ang[::7, 2] *= -1.0
+    ang[:, 3] = rng.choice([0.0, 45.0, 200.0], n)
+    head = ("%d %d %s\n" % (n, len(wl), " ".join("%g" % w for w in wl))).encode()
+    text = head + "".join("%.3f %.3f %.3f %.3f\n" % tuple(r) for r in ang).encode()
+    small = {"GORTT_CHUNK_MB": "1"}
+    for args in (["-energy"], ["-energy", "-prnprop"], ["-energy", "-prnspec"], ["-energy", "--binary-out"]):
+        rc, out, err = _gortt(["-LAI", "4.0"] + args, text, small)
+        rc2, out2, err2 = _gortt(["-LAI", "4.0"] + args, text, dict(small, GORTT_ENERGY_DENSE="1"))
+        assert rc == 0 and rc2 == 0 and err == b"" and err2 == b"", (args, err, err2)
+        assert out == out2, args
+        rc3, out3, _ = _gortt(["-LAI", "4.0"] + args, text, dict(small, GORTT_THREADS="3"))
+        assert rc3 == 0 and out3 == out
+    lines = out.split(b"\n") if False else None
+    # every line its own sun direction, one big chunk
+    ang2 = np.round(_lines(rng, 1500), 4)
+    text2 = ("%d 5 450 550 650 850 1600\n" % 1500).encode() + "".join("%.4f %.4f %.4f %.4f\n" % tuple(r) for r in ang2).encode()
+    rc, out, err = _gortt(["-LAI", "2.5", "-energy"], text2)
+    rc2, out2, err2 = _gortt(["-LAI", "2.5", "-energy"], text2, {"GORTT_ENERGY_DENSE": "1"})
+    assert rc == 0 and rc2 == 0 and out == out2 and out.count(b"\n") == 1501
+    # no lines at all; and no wavelengths (`N 0`: -energy prints nothing per line, gortt.c:323)
+    for stdin in (b"0 2 500 600\n", b"2 0\n10 0 30 0\n20 0 40 0\n"):
+        rc, out, err = _gortt(["-LAI", "4.0", "-energy"], stdin)
+        rc2, out2, err2 = _gortt(["-LAI", "4.0", "-energy"], stdin, {"GORTT_ENERGY_DENSE": "1"})
+        assert (rc, out, err) == (rc2, out2, err2) and rc == 0
+
+
 def _gortt(args, stdin_bytes, env=None):
     e = dict(os.environ)
     e.update(env or {})
