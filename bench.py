@@ -229,6 +229,75 @@ def measure_traffic(args, timeout_s=150):
          "bytes = (WRITE + 2 FETCH) x 1024)" % (kb["WRITE_SIZE"], kb["FETCH_SIZE"]))
 
 
+VALU_FALLBACK = os.path.join("profiles", "r05", "valu_counts.json")
+# which kernel carries a config's arithmetic: (substring of the kernel's name, least grid size in threads)
+VALU_KERNELS = {"C3": ("geometry_grid_kernel", 0), "C4": ("energy_kernel<true>", 0),
+                "stream_1M_x_7": ("geometry_stream_kernel<true>", 500000), "stream_1M_x_100": ("stream_lines_kernel", 500000)}
+
+
+def measure_valu(timeout_s=240):
+    """Vector instructions per launch of the kernels behind `configs`, counted in THIS run: one child pass of this script
+    (`--configs-only`: the configs block alone, two calls per shape) under `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES`.
+    Returns ({config: {"valu_insts_per_launch", "waves_per_launch", "launches"}} or None, how)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="gort_valu_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run([exe, "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "--output-format", "csv", "-d", d, "--", sys.executable,
+                            os.path.join(ROOT, "bench.py"), "--configs-only"], cwd="/tmp", env=env, capture_output=True, timeout=timeout_s)
+        per = {}                                          # (config, dispatch) -> {counter: value}
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                for cfg, (needle, min_grid) in VALU_KERNELS.items():
+                    if needle in row["Kernel_Name"].replace(", ", ",").replace("(anonymous namespace)::", "") and \
+                            float(row.get("Grid_Size") or 0) >= min_grid:
+                        c = per.setdefault((cfg, row["Dispatch_Id"]), {})
+                        c[row["Counter_Name"]] = c.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        out = {}
+        for cfg in VALU_KERNELS:
+            rows = [v for (c, _), v in per.items() if c == cfg and "SQ_INSTS_VALU" in v]
+            if rows:
+                out[cfg] = {"valu_insts_per_launch": sum(v["SQ_INSTS_VALU"] for v in rows) / len(rows),
+                            "waves_per_launch": sum(v.get("SQ_WAVES", 0.0) for v in rows) / len(rows), "launches": len(rows)}
+        if not out:
+            return None, "rocprofv3 --pmc SQ_INSTS_VALU: no counter rows (rc %d): %s" % (r.returncode, r.stderr.decode(errors="replace")[-200:])
+        return out, "measured in this run"
+    except Exception as ex:                                       # noqa: BLE001
+        return None, "rocprofv3 --pmc SQ_INSTS_VALU failed: %r" % (ex,)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def apply_valu(configs, valu, how):
+    """fp64-issue fractions of the `configs` block from instruction counts: vector instructions per launch x 4 cycles over
+    1024 SIMDs x 2.4 GHz x the call's time.  `valu` from measure_valu(); the committed counts of an earlier run of the same
+    kernels (VALU_FALLBACK) where the counter pass was not possible - each entry says which."""
+    committed = {}
+    try:
+        committed = json.load(open(os.path.join(ROOT, VALU_FALLBACK)))
+    except Exception:                                             # noqa: BLE001
+        pass
+    for cfg in VALU_KERNELS:
+        if cfg not in configs or not isinstance(configs[cfg], dict):
+            continue
+        n, src = None, None
+        if valu and cfg in valu:
+            n, src = valu[cfg]["valu_insts_per_launch"], "measured in this run"
+            configs[cfg]["valu_waves_per_launch"] = valu[cfg]["waves_per_launch"]
+        elif cfg in committed:
+            n, src = committed[cfg], "committed: %s (%s)" % (VALU_FALLBACK, how)
+        configs[cfg]["valu_insts_per_launch"] = n
+        configs[cfg]["valu_source"] = src
+        key = "frac_fp64_valu" if cfg == "C4" else "frac"
+        configs[cfg][key] = None if not n else n * 4.0 / (1024 * 2.4e9 * configs[cfg]["us"] * 1e-6)
+
+
 def oracle_rows(wl, grid, rows_idx, phi_idx):
     """rsurf rows of grid nodes (global row = isza * nvza + ivza, azimuth index) from the CPU restatement."""
     from oracle import oracle as O
@@ -248,32 +317,23 @@ def compare(got, ref, what):
             "tolerance": 1e-5, "rows": what}
 
 
-def configs_block():
+def configs_block(quick=False):
     """The other BASELINE configs and the two stream shapes a user of the reference's CLI has, timed in this run (< 1 s):
     device-resident inputs and outputs, best of 5 wall-clock times around a stream synchronisation after 0.15 s of the same
     call (clocks up).  Each with what bounds it and the achieved fraction of that bound: HBM bytes at 8 B per sample + 32 B
-    per line over 8 TB/s, or fp64 VALU issue - the kernels' vector instructions per wave from the committed SQ counter
-    passes (profiles/r04/valu_counts.json) x 4 cycles x waves over 1024 SIMDs x 2.4 GHz x time."""
+    per line over 8 TB/s, or fp64 VALU issue (apply_valu(): the kernels' vector instructions, counted in this run by
+    measure_valu()).  quick: two calls per shape and nothing else - the child pass under the counters."""
     import torch
     from gort_amd import api
-    counts = {}
-    try:
-        counts = json.load(open(os.path.join(ROOT, "profiles", "r04", "valu_counts.json")))
-    except Exception:                                   # noqa: BLE001
-        pass
 
     def best(fn, eng, reps=5):
         t_up = time.perf_counter()
-        while time.perf_counter() - t_up < 0.15:
+        while not quick and time.perf_counter() - t_up < 0.15:
             fn(); eng.synchronize()
         ts = []
-        for _ in range(reps):
+        for _ in range(2 if quick else reps):
             t0 = time.perf_counter(); fn(); eng.synchronize(); ts.append(time.perf_counter() - t0)
         return min(ts)
-
-    def valu_frac(key, waves, t):
-        per_wave = counts.get(key)                      # "..._per_launch" keys: the launch's total, waves = 1
-        return None if not per_wave else per_wave * waves * 4.0 / (1024 * 2.4e9 * t)
 
     eng = api.Engine()
     eng.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
@@ -290,8 +350,7 @@ def configs_block():
     lut = torch.empty((rows * g.nphi, 1), dtype=torch.float64, device="cuda")
     t = best(lambda: eng.rsurf_grid_dev(g, 0, rows, lut), eng)
     out["C3"] = {"workload": "91x91x361 angles x 1 band, LUT entry point", "us": t * 1e6, "samples_per_s": rows * g.nphi / t,
-                 "bound": "fp64_valu", "frac": valu_frac("geometry_grid_kernel<12,true>@c3_per_launch", 1, t),
-                 "hbm_frac": rows * g.nphi * 8 / t / 8e12}
+                 "bound": "fp64_valu", "frac": None, "hbm_frac": rows * g.nphi * 8 / t / 8e12}
     del lut
     # C4: albedo / fAPAR table, 91 sun zeniths x 2101 bands
     wl = np.arange(400.0, 2501.0)
@@ -301,23 +360,21 @@ def configs_block():
     t = best(lambda: eng.energy_stream_dev(sza, en), eng)
     out["C4"] = {"workload": "91 sun zeniths x 2101 bands x (albedo, fAPAR, soil absorption)", "us": t * 1e6,
                  "brdf_evaluations_per_s": 91 * 512 * wl.size / t, "bound": "latency",
-                 "note": "182 workgroups (two band ranges per sun zenith) on 256 CUs: one serial chain of row terms + node geometry + quadrature per workgroup",
-                 "frac_fp64_valu": valu_frac("energy_kernel<true>@c4_per_launch", 1, t)}
+                 "note": "182 workgroups (two band ranges per sun zenith) on 256 CUs: row terms split over lanes, node geometry, quadrature and band passes per workgroup",
+                 "frac_fp64_valu": None}
     # the streams a user of the reference's command line has: a million lines x 7 bands (MODIS-like) and x 100 bands
     rng = np.random.default_rng(0)
     n = 1000000
     a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), rng.uniform(0, 89, n), rng.uniform(0, 360, n)], 1), device="cuda")
-    for nw, key, kernel in ((7, "stream_1M_x_7", "geometry_stream_kernel<true>@7"), (100, "stream_1M_x_100", "stream_lines_kernel@100")):
+    for nw, key in ((7, "stream_1M_x_7"), (100, "stream_1M_x_100")):
         eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
         o = torch.empty((n, nw), dtype=torch.float64, device="cuda")
         t = best(lambda: eng.rsurf_stream_dev(a, o), eng)
         byts = n * nw * 8 + n * 32
         out[key] = {"workload": "1 000 000 random lines x %d bands, stream entry point (%s kernel)" % (nw, eng.stream_form()),
-                    "us": t * 1e6, "samples_per_s": n * nw / t, "bound": "fp64_valu", "frac": valu_frac(kernel, (n + 63) // 64, t),
-                    "hbm_frac": byts / t / 8e12}
+                    "us": t * 1e6, "samples_per_s": n * nw / t, "bound": "fp64_valu", "frac": None, "hbm_frac": byts / t / 8e12}
         del o
     eng.close()
-    out["valu_counts"] = "profiles/r04/valu_counts.json (SQ_INSTS_VALU / SQ_WAVES per kernel, rocprofv3 --pmc)" if counts else None
     return out
 
 
@@ -409,6 +466,10 @@ def main():
                          "printed all the same and the run exits non-zero")
     ap.add_argument("--inject-gather-error", action="store_true", help="test hook: the LUT all-gather raises")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (C2, C3, C4 and two stream shapes, < 1 s)")
+    ap.add_argument("--configs-only", action="store_true",
+                    help="the configs block alone, two calls per shape, one JSON line (the child pass of measure_valu under rocprofv3 --pmc)")
+    ap.add_argument("--no-valu", action="store_true",
+                    help="N = 1: do not count the configs' vector instructions with a rocprofv3 --pmc child pass (~40 s); the committed counts are used")
     ap.add_argument("--no-traffic", action="store_true",
                     help="N = 1: do not measure the kernel's HBM traffic with two rocprofv3 --pmc child passes (~30 s)")
     ap.add_argument("--traffic-gb", type=float, default=None,
@@ -418,6 +479,11 @@ def main():
     import torch
     from gort_amd import api
 
+    if args.configs_only:
+        torch.cuda.set_device(0)
+        api.set_device(0)
+        print(json.dumps({"configs": configs_block(quick=True)}), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -525,6 +591,27 @@ def main():
     # ---- (1) a plain first allocation, timed exactly like the record: what hipMalloc's first answer is worth ----
     first = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1)
     fd_dt, fd_kernel = timed_steps(first.at(window[0]), args.warmup, args.steps)
+    # ---- (1b) N = 1: does the allocator's probe rank placements the way the kernel does?  Up to --lut-draws plain
+    #           allocations alive together (the first one among them), each probed with gort_lut_alloc's own store-pattern
+    #           probe and then written by 2 steps of the real kernel; the record is `per_draw` ----
+    per_draw, peak_used_gb = None, None
+    if world == 1 and args.lut_draws > 1 and r1 > r0:
+        held, per_draw = [first], []
+        win_bytes = window[1] * 8
+        for i in range(min(args.lut_draws, 4)):
+            if i > 0:
+                free_b, total_b = torch.cuda.mem_get_info()
+                if free_b < buf_rows * row_elems * 8 + (64 << 30):          # >= 64 GB stay free beside the draws
+                    break
+                held.append(eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1))
+            b = held[i]
+            probe = eng.probe_store_pattern(b.at(window[0]), win_bytes)
+            _, k2 = timed_steps(b.at(window[0]), 1, 2)
+            free_b, total_b = torch.cuda.mem_get_info()
+            peak_used_gb = max(peak_used_gb or 0.0, (total_b - free_b) / 1e9)
+            per_draw.append({"probe_gbs": probe, "kernel_ms": k2})
+        for b in held[1:]:
+            b.free()
     first.free()
     # ---- (2) the product allocator of the C ABI (gort_lut_alloc: best of <= --lut-draws placements by a store-pattern
     #          probe of the window this rank writes); the number of record is measured on its buffer ----
@@ -620,16 +707,20 @@ def main():
                 comm.destroy()
             except Exception as ex:                        # noqa: BLE001
                 state["error"] = repr(ex)
+            # the ranks agree on the outcome BEFORE anybody reduces a time: a failure on some ranks only (dlopen, communicator)
+            # must not leave the others alone in a collective.  [failed anywhere?, slowest time] in one all-reduce.
+            bad, worst = reduce_max([0.0 if "s" in state else 1.0, state.get("s", 0.0)])
+            state["all_ok"], state["worst"] = bad == 0.0, worst
             return True
         done = guarded("all-gather of the LUT through the C ABI", gather_c_abi)
-        if done and "s" in state:
-            ag2 = reduce_max([state["s"]])[0]
+        if done and state.get("all_ok"):
+            ag2 = state["worst"]
             received = (buf_rows - buf_rows // world) * row_elems * 8
             allgather_c_abi = {"what": "gort_lut_allgather (include/gort_amd.h): ncclAllGather of librccl, in place, on the engine's stream",
                                "ms": ag2 * 1e3, "gbs_received_per_gpu": received / ag2 / 1e9,
                                "frac_of_xgmi_bound": received / ag2 / 1e9 / XGMI_BOUND_GBS}
         else:
-            allgather_c_abi = {"error": state.get("error") or (errors[-1] if errors else "skipped")}
+            allgather_c_abi = {"error": state.get("error") or (errors[-1] if errors else "failed on another rank")}
 
     # ---- parity spot checks (outside the timed region) against the CPU oracle: rows of this rank's window and, after
     #      the gather, rows that other ranks computed (rank 1's and the last rank's windows) ----
@@ -686,6 +777,10 @@ def main():
                                    % (world, buf_rows, buf_rows * row_elems * 8 / 1e9),
                        "allocation": "gort_lut_alloc, max_draws %d (the C ABI's allocator: placement of the rank's window measured; "
                                      "first_draw = plain allocation, same steps)" % args.lut_draws},
+            "per_draw": per_draw,
+            "per_draw_what": None if per_draw is None else
+                             "plain allocations alive together (peak %.0f GB of the device in use), draw 0 = first_draw's buffer: "
+                             "gort_lut_alloc's store-pattern probe of each, then 2 steps of the real kernel on it (HIP events)" % peak_used_gb,
             "first_draw": {"value": total_samples * args.steps / fd_dt, "ms_per_step": fd_dt / args.steps * 1e3,
                            "kernel_ms_slowest_rank": fd_kernel_max,
                            "what": "the same warm-up + steps on a plain first allocation (gort_lut_alloc with max_draws 1), max over ranks"},
@@ -717,6 +812,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_configs:
         try:
             out["configs"] = configs_block()
+            valu, how = (None, "--no-valu") if args.no_valu else measure_valu()
+            apply_valu(out["configs"], valu, how)
+            out["configs"]["valu_counts"] = how
         except Exception as ex:                           # noqa: BLE001
             out["configs"] = {"error": repr(ex)}
     if rank == 0 and world == 1 and not args.no_traffic and args.traffic_gb is None:

@@ -592,11 +592,17 @@ extern "C" int gort_engine_reserve_members(gort_engine *e, int n_members, int nw
     int rc = stage_begin(e, (sizeof(gort_canopy) + sizeof(gort_leaf_soil)) * (size_t)n_members + sizeof(double) * (size_t)nw + 1024);
     if (rc) return rc;
     if ((rc = ensure_spectral_tables(e))) return rc;
-    if ((rc = e->canopy.reserve(sizeof(gort_canopy) * (size_t)n_members))) return rc;
-    if ((rc = e->leaf.reserve(sizeof(gort_leaf_soil) * (size_t)n_members))) return rc;
-    if ((rc = e->wl.reserve(sizeof(double) * (size_t)nw))) return rc;
-    if ((rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw * (size_t)n_members))) return rc;
-    return e->L.reserve(sizeof(double) * lambda_table_doubles(nw, n_members));
+    // growing a buffer discards what it held (DevBuf::reserve frees and allocates): an engine that was configured before is
+    // "not ready" again until its canopies and spectra are set once more - never a stream of garbage
+    void *const held[3] = {e->canopy.p, e->spectra.p, e->L.p};
+    if ((rc = e->canopy.reserve(sizeof(gort_canopy) * (size_t)n_members)) == GORT_OK &&
+        (rc = e->leaf.reserve(sizeof(gort_leaf_soil) * (size_t)n_members)) == GORT_OK &&
+        (rc = e->wl.reserve(sizeof(double) * (size_t)nw)) == GORT_OK &&
+        (rc = e->spectra.reserve(sizeof(double) * 3 * (size_t)nw * (size_t)n_members)) == GORT_OK)
+        rc = e->L.reserve(sizeof(double) * lambda_table_doubles(nw, n_members));
+    if (held[0] != e->canopy.p || held[2] != e->L.p) e->have_canopy = false;
+    if (held[1] != e->spectra.p || held[2] != e->L.p) e->have_spectra = false;
+    return rc;
 }
 
 extern "C" int gort_engine_get_member(gort_engine *e, int member, gort_canopy *canopy, double *rsoil, double *rleaf,
@@ -897,14 +903,22 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     const gort_canopy *c = e->canopy.as<gort_canopy>();
     const bool few_bands = nw < 128;     // the aligned LUT kernel needs a chunk (128 doubles) to span at most two angles
     if (few_bands) {
-        // few bands: one thread per sample straight from the full angle records (single canopy only)
-        if (e->n_members != 1) return fail(GORT_EINVAL, "gort_rsurf_members_grid_dev: needs nw >= 128 bands");
-        // up to 8 bands (config 3 has one): no records at all, the geometry kernel writes the samples itself
+        // up to 8 bands (config 3 has one): no records at all, the geometry kernel writes the samples itself - every row with its
+        // own member's canopy and band constants (rows are global: member * rows_per_member + ...)
         static const bool fuse = !(getenv("GORT_GRID_FUSE") && atoi(getenv("GORT_GRID_FUSE")) == 0);
         if (nw <= 8 && fuse) return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream);
+        // 9 ... 127 bands: full angle records, then one thread per sample (the LUT family's five-term sample).  Several members:
+        // whole members only (what gort_rsurf_members_grid_dev asks for), member = blockIdx.z of the expansion
+        const long rpm = (long)g->nsza * g->nvza;
+        const long m0 = row_begin / rpm, m1 = (row_end - 1) / rpm + 1;
+        if (m1 - m0 > 1 && (row_begin != m0 * rpm || row_end != m1 * rpm))
+            return fail(GORT_EINVAL, "grid of %d bands: rows [%ld,%ld) are not whole members", nw, row_begin, row_end);
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
-        return launch_expand_stream(c, e->L.as<double>(), nullptr, nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr, e->stream, true);
+        const double *Lm = e->L.as<double>() + (size_t)m0 * L_NSLOT * nw;
+        if (m1 - m0 == 1)
+            return launch_expand_stream(c + m0, Lm, nullptr, nw, e->coef.as<double>(), nA, lut_dev, nullptr, nullptr, e->stream, true);
+        return launch_expand_grid_members(c + m0, Lm, nw, e->coef.as<double>(), nA / (m1 - m0), (int)(m1 - m0), lut_dev, e->stream);
     }
     // compact 64-B records, one pad record in front and a tail pad (see expand_flat_kernel).
     // Full-size slabs: ONE buffer, reused by every call - the 191 MB of records the geometry kernel writes are
@@ -997,7 +1011,14 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         win_bytes > bytes - win_offset)
         return fail(GORT_EINVAL, "gort_lut_alloc: bad argument");
     if (win_bytes == 0) { win_offset = 0; win_bytes = bytes / sizeof(double) * sizeof(double); }
-    GORT_HIP(hipSetDevice(e->device));                 // the engine's device, whatever the calling thread had current
+    // the engine's device, whatever the calling thread had current - and the caller's device again on every way out
+    struct DeviceGuard {
+        int prev = -1;
+        ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } guard;
+    if (hipGetDevice(&guard.prev) != hipSuccess) { (void)hipGetLastError(); guard.prev = -1; }
+    if (guard.prev == e->device) guard.prev = -1;      // nothing to restore
+    GORT_HIP(hipSetDevice(e->device));
     if (max_draws < 1) max_draws = 1;
     if (max_draws > GORT_LUT_MAX_DRAWS) max_draws = GORT_LUT_MAX_DRAWS;
     const long doubles = (long)(win_bytes / sizeof(double));
@@ -1150,8 +1171,12 @@ extern "C" int gort_lut_allgather_on(void *stream, void *lut_dev, size_t rows_pe
 extern "C" int gort_lut_allgather(gort_engine *e, void *lut_dev, size_t rows_per_rank, size_t row_bytes, int rank, int world, void *comm)
 {
     if (!e) return fail(GORT_EINVAL, "gort_lut_allgather: null engine");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
     GORT_HIP(hipSetDevice(e->device));
-    return gort_lut_allgather_on(e->stream, lut_dev, rows_per_rank, row_bytes, rank, world, comm);
+    const int rc = gort_lut_allgather_on(e->stream, lut_dev, rows_per_rank, row_bytes, rank, world, comm);
+    if (prev >= 0 && prev != e->device) (void)hipSetDevice(prev);      // the caller's device, as it was
+    return rc;
 }
 
 // the probe of gort_lut_alloc on memory the caller owns (contents destroyed): include/gort_amd_tuning.h

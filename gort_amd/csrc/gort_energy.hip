@@ -182,9 +182,13 @@ struct EnergyShared {
     double abar[5];
     double sun[6];
     RowTerms row[ENERGY_ZENITH_NODES];
+    RowScratch scr[ENERGY_ZENITH_NODES];
 };
 
-template <bool SHARE_ROWS>
+// PREFETCH (the per-line kernel, BASELINE config 4): the band constants of the thread's first band pass are requested in front
+// of the geometry and those of pass k + 1 in front of the arithmetic of pass k - by the stamps a band pass was a wait for its
+// eleven cold constants (the table is 185 KB and nobody has touched it) followed by forty instructions, 4.5 us for two passes
+template <bool SHARE_ROWS, bool PREFETCH = false>
 __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *__restrict__ L, int nw,
                                             const double *__restrict__ angles, const double *__restrict__ nodes,
                                             double *__restrict__ energy, long a, long out_row, EnergyShared &sh, int band_begin,
@@ -193,26 +197,35 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     GORT_STAMPS_BEGIN();
     GORT_STAMP(0);
+    // everything this thread reads of the node table, in front of the prefetch (the load counter is in order: a wait for a node
+    // behind the band constants would be a wait for the band constants); my_row = the row this thread serves in row_terms_split()
+    const double node_vaa = nodes[3 * tid], w = nodes[3 * tid + 2];
+    const int my_row = tid < 2 * ENERGY_ZENITH_NODES ? tid >> 1 : (tid - 64) & (ENERGY_ZENITH_NODES - 1);
+    const double row_vza = nodes[3 * my_row + 1], node_vza = nodes[3 * tid + 1];
+    BandTerms ahead;
+    if (PREFETCH) ahead = load_band(L, nw, band_begin + tid < band_end ? band_begin + tid : band_begin);
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
     // node geometry (gortt_albedo.c:91-105): vaa = pi + pi x_i in (0, 2pi); vza = acos(x_j)
     {
 #pragma clang fp contract(off)
-        const double vaa = nodes[3 * tid];
-        raa = saa - vaa;
+        raa = saa - node_vaa;
         raa = fabs((raa - 2 * PI * (int)(0.5 + raa * INV_PI * 0.5)));
     }
-    const double w = nodes[3 * tid + 2];
     GeomOut g;
     if (SHARE_ROWS) {
         // reflectances only leave this kernel (gort_geometry.h, row_terms: the 90-degree sun of BASELINE config 4 walked the
         // reference's route for 8.8 us where the other lines' row terms take 4.5, and a launch ends with its longest line)
-        if (tid < ENERGY_ZENITH_NODES) row_terms(c, nodes[3 * tid + 1], sza, sh.row[tid], true);
-        __syncthreads();
+        // split over lanes (gort_geometry.h, row_terms_split: the same numbers as row_terms())
+        row_terms_split(ENERGY_ZENITH_NODES, sh.row, sh.scr, true, [&](int, const gort_canopy *&ci, double &vz, double &sz) {
+            ci = &c;
+            vz = row_vza;                                    // asked for row my_row only
+            sz = sza;
+        });
         GORT_STAMP(1);                                       // row terms
         finish_angle(c, sh.row[tid & (ENERGY_ZENITH_NODES - 1)], raa, g);
     } else {
-        geometry_core(c, nodes[3 * tid + 1], sza, raa, g);
+        geometry_core(c, node_vza, sza, raa, g);
     }
     double rec[GORT_COEF_STRIDE];
     store_coef(rec, c, g);
@@ -240,9 +253,17 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     s.fd = sh.sun[0];  s.mu = sh.sun[1];  s.t0 = sh.sun[2];  s.tp0 = sh.sun[3];  s.eps = sh.sun[4];  s.pn0 = sh.sun[5];
     const double aC = sh.abar[0], aB = sh.abar[1], aZ = sh.abar[2], aG = sh.abar[3], aT = sh.abar[4];
     for (int i = band_begin + tid; i < band_end; i += ENERGY_THREADS) {
-        const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
+        BandTerms t;
+        if (PREFETCH) {
+            t = ahead;
+            const int next = i + ENERGY_THREADS;
+            ahead = load_band(L, nw, next < band_end ? next : i);
+        } else {
+            t = load_band(L, nw, i);
+        }
+        const SunTerms b = sun_terms(t, s, c.k_open, c.k_openep);
         const double albedo = dot5(aC, aB, aZ, aG, aT, b.C0, b.B, b.Z, b.G, b.T);
-        const double rs = L[L_RS * nw + i];
+        const double rs = t.rs;
         // energy balance, Lambertian background (gortt_albedo.c:39-52)
         const double Fu2 = b.G * s.pn0 + b.Z * (1. - s.pn0);
         const double Fd2 = s.pn0 + b.Z * (1. - s.pn0) / rs;
@@ -269,8 +290,8 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_kernel(const gort_ca
     __shared__ EnergyShared sh;
     const long member = blockIdx.y;
     const int per = (nw + (int)gridDim.z - 1) / (int)gridDim.z, band_begin = (int)blockIdx.z * per;
-    energy_line<SHARE_ROWS>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
-                            (long)blockIdx.x, (long)blockIdx.x, sh, band_begin, band_begin + per < nw ? band_begin + per : nw);
+    energy_line<SHARE_ROWS, true>(canopies[member], Lall + member * L_NSLOT * nw, nw, angles, nodes, energy_all + member * nA * nw * 3,
+                                  (long)blockIdx.x, (long)blockIdx.x, sh, band_begin, band_begin + per < nw ? band_begin + per : nw);
 }
 
 // the lines that stand for themselves (uniq[0] of them, uniq[1..]): workgroups stride over the list.
@@ -321,6 +342,7 @@ struct EnergySharedBatch {
     double abar[ENERGY_BATCH][5];
     double sun[ENERGY_BATCH][6];
     RowTerms row[ENERGY_BATCH][ENERGY_ZENITH_NODES];
+    RowScratch scr[ENERGY_BATCH][ENERGY_ZENITH_NODES];
 };
 
 __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(const gort_canopy *__restrict__ canopies,
@@ -339,7 +361,6 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
     long n_lines = uniq[0];
     if (ro.rows_cap >= 0 && n_lines > ro.rows_cap) n_lines = ro.rows_cap;
     const double node_vaa = nodes[3 * tid], w = nodes[3 * tid + 2];
-    const double row_vza = nodes[3 * (lane & (ENERGY_ZENITH_NODES - 1)) + 1];        // the zenith node whose row this lane evaluates
     // lines per pass: four where that still leaves two workgroups' worth of batches per CU, fewer for short lists (a
     // million lines of 91 sun directions are a list of 91: one line per workgroup, as many workgroups as lines)
     const int per_pass = n_lines >= 4 * 512 ? ENERGY_BATCH : (n_lines >= 2 * 512 ? 2 : 1);
@@ -348,14 +369,16 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
         asm volatile("" ::: "memory");                       // keeps the body's loads where they are used (see energy_list_kernel)
         GORT_STAMP(0);
         const int lines_here = n_lines - base < per_pass ? (int)(n_lines - base) : per_pass;
-        // ---- row terms: ONE wave, sixteen lanes per line of the batch (the 4 x 16 chains cost the issue slots of one) ----
-        if (wave == 0 && (lane >> 4) < lines_here) {
-            const long a = (long)uniq[1 + base + (lane >> 4)];
-            double vza, sza, saa, raa;
-            normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sza, saa, raa);
-            row_terms(c, row_vza, sza, sh.row[lane >> 4][lane & (ENERGY_ZENITH_NODES - 1)], true);
-        }
-        __syncthreads();
+        // ---- row terms of the batch's lines, sixteen rows per line, split over lanes (gort_geometry.h: two lanes per row on the
+        // first waves, then a lane per row and principal-plane azimuth beside a lane per row on the wave behind them) ----
+        row_terms_split(lines_here * ENERGY_ZENITH_NODES, &sh.row[0][0], &sh.scr[0][0], true,
+                        [&](int i, const gort_canopy *&ci, double &vz, double &sz) {
+                            const long a = (long)uniq[1 + base + (i >> 4)];
+                            double vza, saa, raa;
+                            normalise_angles(angles[4 * a], angles[4 * a + 1], angles[4 * a + 2], angles[4 * a + 3], vza, sz, saa, raa);
+                            ci = &c;
+                            vz = nodes[3 * (i & (ENERGY_ZENITH_NODES - 1)) + 1];
+                        });
         GORT_STAMP(1);                                       // row terms of the batch
         // ---- every thread its node, line after line ----
         for (int b = 0; b < lines_here; ++b) {

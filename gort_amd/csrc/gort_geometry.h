@@ -157,6 +157,143 @@ __device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms
     else row_terms_with<FastMath>(c, vza, sza, r);
 }
 
+// ---- the same row terms, SPLIT over lanes (round 5) -------------------------------------------------------------------
+// row_terms() is one chain of ~1100 dependent instructions per row, and a kernel that evaluates a handful of rows in front
+// of its nodes (the grid kernels, the albedo quadrature) spends it on a dozen lanes of ONE wave while every other wave of
+// the workgroup waits at the barrier: 2.5 us (hemisphere grid) to 4.5 us (albedo line) at the front of every workgroup with
+// the SIMDs a quarter busy.  But the chain is three chains that do not need each other ("Mi, theta_Mi on theta_s;
+// Mv, theta_Mv on theta_v"; gortt_brdf.c:118-238):
+//   stage 1, a lane per (row, zenith): the zenith's primed angle, its gap-table lookup, exp(-cov sec), M and the path length
+//            of Kuusk's hot spot - the view zenith's on one lane, the sun zenith's (with theta_Mi) on its neighbour;
+//   stage 2, a lane per (row, principal-plane azimuth 0 | pi): overlap, Kg and f F there - and meanwhile, on the lanes of
+//            ANOTHER wave (other issue slots), a lane per row: the sun's fd and t0, beta, and the hot spot's sqrt(ls lv).
+// The longest path is ~650 instructions.  Every number is formed by the expression row_terms_with() forms it by, from the
+// same operands (contraction off in both): the same bits (tests/test_grid_forms.py, tests/test_energy_forms.py).
+struct RowScratch { double Mv, Mi, theta_Mi; };
+
+// stage 1: thread `unit` of the workgroup's first 2 n_rows threads = (row unit >> 1, which = unit & 1: 0 view, 1 sun)
+template <class M>
+__device__ void row_unit_with(const gort_canopy &c, bool is_sun, double za, double sn, double cs, RowTerms &r, RowScratch &x)
+{
+#pragma clang fp contract(off)
+    const Primed p = M::prime(c.ell, M::div(sn, cs));
+    const double cov = c.lambda * PI * c.rr;
+    const double xx = cov * p.sec;
+    const double e = M::exp(-xx);
+    const double Mm = 1.0 - M::div(1.0 - e, xx);
+    double pn0, eps;
+    gap_lookup(c, za, pn0, eps);
+    const double l = M::div_ieee(-M::log(eps), is_sun ? c.k * c.favd : 0.5 * c.favd);
+    if (is_sun) {
+        r.s = p;  r.sin_sz = sn;  r.cos_sz = cs;  r.es = e;
+        r.sun.pn0 = pn0;  r.sun.eps = eps;  r.eps_s = eps;
+        r.kf = c.k * c.favd;
+        r.ls = l;
+        x.Mi = Mm;
+        x.theta_Mi = M::acos(1.0 - 2.0 * Mm);
+    } else {
+        r.v = p;  r.sin_vz = sn;  r.cos_vz = cs;  r.ev = e;
+        r.Gv = PI * c.rr * p.sec;
+        r.eps_v = eps;
+        r.lv = l;
+        x.Mv = Mm;
+    }
+}
+
+// stage 2, lane (row, q): f F on the principal plane at phi = 0 (q = 0) or pi (q = 1)
+template <class M>
+__device__ void row_plane_with(const gort_canopy &c, int q, double vza, double sza, RowTerms &r, const RowScratch &x)
+{
+#pragma clang fp contract(off)
+    const Primed v = r.v, s = r.s;
+    const double cov = c.lambda * PI * c.rr;
+    const double hb = M::div(c.h, c.b);
+    const double t1 = s.sec + v.sec;
+    const double cphi = q ? -1.0 : 1.0;
+    const double Oq = q ? overlap<M, true>(hb, s, v, -1.0, 1.2246467991473532e-16) : overlap<M, true>(hb, s, v, 1.0, 0.0);
+    const double Kgq = M::exp(-(cov * (t1 - Oq)));
+    const double Gv = r.Gv;
+    const bool view_steeper = fabs(vza) > fabs(sza);
+    const double ph = v.c * s.c + v.s * s.s * cphi;
+    const double Gam = PI * c.rr * (t1 - Oq);
+    const double Gc = Gv * 0.5 * (1.0 + ph);
+    const double F = M::div(Gc, Gam);
+    const double Mq = 1.0 - M::div(1.0 - Kgq, c.lambda * Gam);
+    const double PiMi = (1 - M::cos(x.theta_Mi * (1 - M::over_pi(s.ang - v.ang * cphi)))) / 2.0;
+    const double PvMv = x.Mv - (1.0 - M::cos_of_difference(v, s, cphi, ph)) / 2.0;
+    const double Po = (q == 1) ? PvMv : (view_steeper ? PiMi : PvMv);
+    const double f = M::div(F * (1.0 - M::div(Gv * (PvMv + PiMi - Po), Gc)), 1.0 - Mq);
+    if (q) {
+        r.fFpi = f * F;
+    } else {
+        r.fF0 = f * F;
+        r.cov = cov;  r.hb = hb;  r.t1 = t1;
+    }
+}
+
+// stage 2, a lane per row on another wave: what is left of the sun scalars, beta, the hot spot's sqrt(ls lv)
+template <class M>
+__device__ void row_rest_with(const gort_canopy &c, RowTerms &r)
+{
+#pragma clang fp contract(off)
+    const Primed s = r.s;
+    r.sun.fd = c.use_user_fd ? c.fd_user : M::div(r.cos_sz, r.cos_sz + 0.09);
+    r.sun.mu = s.c;
+    r.sun.t0 = M::exp(-(c.k * c.elai * s.sec));
+    r.sun.tp0 = r.sun.pn0 + r.sun.eps;
+    if (c.use_user_beta) {
+        r.beta = c.beta;
+    } else if (s.ang < 0.000000001) {
+        r.beta = 0.0;
+    } else {
+        const double Dd = c.r * M::cot_half(s);
+        const double dh = M::div(c.h2 - c.h1, Dd);
+        const double lg = c.lambda * r.Gv;
+        r.beta = M::div(lg, lg + dh) * M::div(1.0 - M::exp(-lg - dh), 1.0 - M::exp(-lg));
+    }
+    r.h1 = (r.ls * r.lv) > 0.0 ? M::sqrt(r.ls * r.lv) : 0.0;
+}
+
+// All threads of the workgroup call this (two barriers inside); rows[i], scr[i] in LDS for i < n_rows; args(i, c, vza, sza)
+// names row i's canopy and its two normalised zeniths.  blockDim.x >= roundup64(2 n_rows) + n_rows.
+template <class RowArgs>
+__device__ __forceinline__ void row_terms_split(int n_rows, RowTerms *rows, RowScratch *scr, bool reflectances_only, RowArgs args)
+{
+    const int tid = threadIdx.x;
+    if (tid < 2 * n_rows) {
+        const int i = tid >> 1, is_sun = tid & 1;
+        const gort_canopy *c;
+        double vza, sza;
+        args(i, c, vza, sza);
+        const double za = is_sun ? sza : vza;
+        double sn, cs;
+        sincos(za, &sn, &cs);                                  // the zeniths' own sine and cosine: the library's (row_terms)
+        const double other = __shfl_xor(cs, 1, 64);            // the row's other zenith sits on the neighbouring lane
+        const bool horizon = takes_reference_route(*c, is_sun ? other : cs, is_sun ? cs : other, reflectances_only);
+        if (!is_sun) rows[i].horizon = horizon ? 1 : 0;
+        if (__builtin_expect(horizon, 0)) row_unit_with<LibMath>(*c, is_sun != 0, za, sn, cs, rows[i], scr[i]);
+        else row_unit_with<FastMath>(*c, is_sun != 0, za, sn, cs, rows[i], scr[i]);
+    }
+    __syncthreads();
+    const int rest0 = (2 * n_rows + 63) & ~63;                 // the first lane of the wave behind the plane lanes
+    if (tid < 2 * n_rows) {
+        const int i = tid >> 1;
+        const gort_canopy *c;
+        double vza, sza;
+        args(i, c, vza, sza);
+        if (__builtin_expect(rows[i].horizon, 0)) row_plane_with<LibMath>(*c, tid & 1, vza, sza, rows[i], scr[i]);
+        else row_plane_with<FastMath>(*c, tid & 1, vza, sza, rows[i], scr[i]);
+    } else if (tid >= rest0 && tid < rest0 + n_rows) {
+        const int i = tid - rest0;
+        const gort_canopy *c;
+        double vza, sza;
+        args(i, c, vza, sza);
+        if (__builtin_expect(rows[i].horizon, 0)) row_rest_with<LibMath>(*c, rows[i]);
+        else row_rest_with<FastMath>(*c, rows[i]);
+    }
+    __syncthreads();
+}
+
 // The azimuth-dependent rest: overlap and Kg at the actual azimuth, the interpolated Kc, the other
 // proportions (gortt.c:424-449) and the hot spot.
 template <class M>

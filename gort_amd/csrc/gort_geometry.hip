@@ -112,6 +112,7 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           double *__restrict__ rsurf, int mirror)
 {
     __shared__ RowTerms s_row[GEOM_ROWS];
+    __shared__ RowScratch s_scr[GEOM_ROWS];
     __shared__ double s_sun_terms[GEOM_ROWS][GEOM_FUSED_MAX_BANDS][5];      // fused form: C0, B, Z, G, T per (row, band)
     __shared__ int s_member[GEOM_ROWS];
     __shared__ double s_vza_deg[GEOM_ROWS], s_sza_deg[GEOM_ROWS];
@@ -140,20 +141,32 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         rel0 = 0;
         rel1 = rows_here * per_row;
     }
-    if ((int)threadIdx.x < rows_here) {
-        const long grow = row_begin + first + threadIdx.x;
-        const long member = grow / rows_per_member;
+    // row i of this block: its member and the two zeniths as the grid's lines type them
+    auto row_of = [&](int i, long &member, double &vza_deg, double &sza_deg) {
+        const long grow = row_begin + first + i;
+        member = grow / rows_per_member;
         const long row = grow - member * rows_per_member;
         const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
-        const double vza_deg = g.vza0 + ivza * g.dvza, sza_deg = g.sza0 + isza * g.dsza;
-        double vza, sza, saa, raa;
-        normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
-        row_terms(canopies[ONE_MEMBER ? member0 : member], vza, sza, s_row[threadIdx.x], true);       // a LUT holds reflectances only
-        s_member[threadIdx.x] = (int)member;
-        s_vza_deg[threadIdx.x] = vza_deg;
-        s_sza_deg[threadIdx.x] = sza_deg;
+        vza_deg = g.vza0 + ivza * g.dvza;
+        sza_deg = g.sza0 + isza * g.dsza;
+    };
+    if ((int)threadIdx.x >= 64 && (int)threadIdx.x - 64 < rows_here) {     // on the second wave: the first one is busy below
+        const int i = (int)threadIdx.x - 64;
+        long member;
+        double vza_deg, sza_deg;
+        row_of(i, member, vza_deg, sza_deg);
+        s_member[i] = (int)member;
+        s_vza_deg[i] = vza_deg;
+        s_sza_deg[i] = sza_deg;
     }
-    __syncthreads();
+    // the rows' azimuth-independent terms, split over lanes (gort_geometry.h); a LUT holds reflectances only
+    row_terms_split(rows_here, s_row, s_scr, true, [&](int i, const gort_canopy *&c, double &vza, double &sza) {
+        long member;
+        double vza_deg, sza_deg, saa, raa;
+        row_of(i, member, vza_deg, sza_deg);
+        normalise_angles(vza_deg, g.phi0, sza_deg, 0.0, vza, sza, saa, raa);
+        c = &canopies[ONE_MEMBER ? member0 : member];
+    });
     GORT_STAMP(1);                                           // row terms
     // ONE_MEMBER: what the node loop reads of the canopy and (fused form) the first band's constants, once, ahead of the loop
     // fused form: the five (sun zenith, band) terms of the sample depend on the row and the band only - once per (row, band)

@@ -129,6 +129,10 @@ bool stream_is_large(int nw, long nA, bool want_scomp);
 int launch_expand_stream(const gort_canopy *canopy_dev, const double *L_dev, const double *band_table_dev, int nw,
                          const double *coef_dev, long nA, double *rsurf_dev, double *scomp_dev, int *xcd_slots_dev, void *stream,
                          bool grid_form);
+// the nodes of a few-band LUT (9 ... 127 bands) of n_members members, member-major classic records coef_dev[m][lines][16]
+// -> lut_dev[m][lines][nw] with the LUT family's five-term sample, one thread per sample; canopies_dev / L_dev at the first member
+int launch_expand_grid_members(const gort_canopy *canopies_dev, const double *L_dev, int nw, const double *coef_dev,
+                               long lines_per_member, int n_members, double *lut_dev, void *stream);
 // ---- streams of 17 ... ~250 bands without component spectra (gort_stream_lines.hip): geometry and samples in one kernel,
 // lanes = lines, rows leave LDS as whole 128-B lines whatever the band count; band_table_dev as above
 bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp);

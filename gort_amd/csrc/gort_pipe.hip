@@ -42,6 +42,7 @@ struct Slot {
     uint32_t *h_index = nullptr, *h_rows = nullptr;
     hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_out = nullptr;
     long n = 0, energy_rows = 0;
+    long energy_cap = 0;         // rows h_energy / d_energy hold (indexed mode: grown when a chunk has more distinct rows)
     int rc = GORT_OK;            // error raised while the chunk was submitted; reported by gort_pipe_wait
     std::string err;             // its message
 };
@@ -116,7 +117,16 @@ static int pipe_alloc(gort_pipe *p)
             if ((rc = both(&s.h_K, &s.d_K, D * 4 * n))) return rc;
         }
         if ((p->flags & GORT_PIPE_SCOMP) && (rc = both(&s.h_scomp, &s.d_scomp, D * 4 * n * nw))) return rc;
-        if ((p->flags & GORT_PIPE_ENERGY) && (rc = both(&s.h_energy, &s.d_energy, D * 3 * n * nw))) return rc;
+        if (p->flags & GORT_PIPE_ENERGY) {
+            // indexed: room for the distinct rows of a typical chunk (16 MiB; a million lines of a 1-degree sun grid have 91) - a
+            // chunk with more makes its slot grow (gort_pipe_submit knows the count before anything is queued for the rows)
+            s.energy_cap = (long)n;
+            if (p->flags & GORT_PIPE_ENERGY_INDEXED) {
+                const long typical = (long)(((size_t)16 << 20) / (D * 3 * (nw ? nw : 1)));
+                if (typical < s.energy_cap) s.energy_cap = typical < 1 ? 1 : typical;
+            }
+            if ((rc = both(&s.h_energy, &s.d_energy, D * 3 * (size_t)s.energy_cap * nw))) return rc;
+        }
         if (p->flags & GORT_PIPE_ENERGY_INDEXED) {
             PIPE_HIP(hipMalloc(&s.d_table, energy_table_workspace(p->max_lines)));
             PIPE_HIP(hipHostMalloc((void **)&s.h_index, sizeof(uint32_t) * n, hipHostMallocDefault));
@@ -208,14 +218,28 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
         if (indexed) {
             // the chunk's sun directions are counted behind its copy in, on the copy-in stream - not behind the kernels of the
             // chunks in front - and the host waits for the count: it sizes the evaluation and the copy out
-            const uint32_t *count_dev = energy_table_count(s.d_table, n);
-            if ((rc = gort_engine_energy_table(p->e, s.d_ang, n, s.d_table, nullptr, p->s_in))) return rc;
-            PIPE_HIP(hipMemcpyAsync(s.h_rows, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, p->s_in));
+            // (the count is STORED into pinned host memory by the table's last kernel: a 4-byte device -> host copy would queue
+            // behind the previous chunk's 50 MB of results on the copy engine, a millisecond per chunk)
+            if ((rc = gort_engine_energy_table(p->e, s.d_ang, n, s.d_table, s.h_rows, p->s_in))) return rc;
         }
         PIPE_HIP(hipEventRecord(s.ev_in, p->s_in));
         if (indexed) {
             PIPE_HIP(hipEventSynchronize(s.ev_in));
-            s.energy_rows = (long)*s.h_rows;
+            s.energy_rows = (long)*static_cast<volatile uint32_t *>(s.h_rows);
+            if (s.energy_rows > s.energy_cap) {
+                // more distinct rows than the slot has room for: nothing of this slot is in flight (the chunk that used it last has
+                // been released), so its buffers can be exchanged for bigger ones here
+                long cap = 2 * s.energy_cap > s.energy_rows ? 2 * s.energy_cap : s.energy_rows;
+                if (cap > p->max_lines) cap = p->max_lines;
+                PIPE_HIP(hipHostFree(s.h_energy));
+                s.h_energy = nullptr;
+                PIPE_HIP(hipFree(s.d_energy));
+                s.d_energy = nullptr;
+                s.energy_cap = 0;
+                PIPE_HIP(hipHostMalloc((void **)&s.h_energy, D * 3 * (size_t)cap * nw, hipHostMallocDefault));
+                PIPE_HIP(hipMalloc((void **)&s.d_energy, D * 3 * (size_t)cap * nw));
+                s.energy_cap = cap;
+            }
         }
         PIPE_HIP(hipStreamWaitEvent(ks, s.ev_in, 0));
         if (nw > 0 && s.d_rsurf) rc = gort_rsurf_stream_dev(p->e, s.d_ang, n, s.d_rsurf, s.d_scomp, s.d_K);

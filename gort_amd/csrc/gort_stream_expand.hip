@@ -264,6 +264,18 @@ int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const 
     return check_launch("expand_stream_kernel");
 }
 
+int launch_expand_grid_members(const gort_canopy *canopies_dev, const double *L_dev, int nw, const double *coef_dev,
+                               long lines_per_member, int n_members, double *lut_dev, void *stream)
+{
+    const long n = lines_per_member * nw;
+    if (n <= 0 || n_members <= 0) return GORT_OK;
+    if (n_members > 65535) return fail(GORT_EINVAL, "grid expansion: %d members in one launch (max 65535)", n_members);
+    if ((n + 255) / 256 >= (1L << 31)) return fail(GORT_EINVAL, "grid expansion: %ld samples per member in one launch", n);
+    hipLaunchKernelGGL(expand_stream_kernel<false>, dim3((unsigned)((n + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
+                       (hipStream_t)stream, canopies_dev, L_dev, nw, coef_dev, n, lut_dev, (double *)nullptr, 1);
+    return check_launch("expand_stream_kernel<grid>");
+}
+
 // ---- the aligned flat form: large, wide streams without component spectra (their records are in layout 1) ----
 // (>= 128 bands and >= 4M samples.  Streams of 17 ... 255 bands take gort_stream_lines.hip before they get here - the
 // hand-over is GORT_LINES_MAX_BANDS - and up to 16 bands the stream is fused with the geometry unless GORT_STREAM_FUSE=0.

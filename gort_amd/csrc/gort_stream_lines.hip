@@ -144,7 +144,16 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         ring_at[i] = (((r + 1) * pitch) >> 1) + q;                 // in 16-byte units: pitch is even
         gp[i] = origin + F + 2 * q;
     }
+    // Lanes exchange data through LDS here (a lane's ring is read by the eight store lanes of its row; heads go into the
+    // neighbour's ring): one wave, so no s_barrier - but the compiler must not move a lane's ring writes behind another
+    // lane's reads of them.  Release fence + wave barrier + acquire fence emit no instruction; they only forbid that.
+    auto wave_exchange = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto emit_full = [&](int j) {
+        wave_exchange();
         dbl2 v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -215,6 +224,7 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
             for (int i = 0; i < BLOCK_BANDS - 1; ++i)
                 if (i < s) prev_ring[(pos + i) & (RING - 1)] = head[i];
         }
+        wave_exchange();                                   // the heads are in their neighbours' rings
         // the seam behind row r = 8 i + sub, from the numbers of its store slot: complete where the next row is the wave's too
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

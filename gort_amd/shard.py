@@ -86,7 +86,9 @@ def rccl_comm_for_group(group=None):
     from . import api
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     box = [api.rccl_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0, group=group)
+    # `src` is a GLOBAL rank: the group's first member, which need not be global rank 0
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
     return api.RcclComm(world, box[0], rank)
 
 

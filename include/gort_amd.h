@@ -249,7 +249,9 @@ int  gort_engine_set_members_leaf(gort_engine *e, const gort_canopy *members, co
                                   int n_members, int compute_gaps, const double *wl_nm, int nw);
 /* Capacity for n_members x nw bands: device buffers, pinned staging and spectral tables are allocated now, so that the
  * member setters cost their copies and kernels only (an ensemble filter re-submits its members every cycle; the first
- * call of a process otherwise pays ~240 MB of allocation).  New surface; optional. */
+ * call of a process otherwise pays ~240 MB of allocation).  New surface; optional.  Call it BEFORE the setters: a call that
+ * has to grow a buffer discards the canopies / spectra the engine held, and the entry points then fail with "no canopy set"
+ * / "no spectra set" until they are set again. */
 int  gort_engine_reserve_members(gort_engine *e, int n_members, int nw);
 int  gort_engine_get_member(gort_engine *e, int member, gort_canopy *canopy, double *rsoil, double *rleaf,
                             double *tleaf);
@@ -283,7 +285,8 @@ typedef struct gort_grid {
 int  gort_rsurf_grid_dev(gort_engine *e, const gort_grid *g, long row_begin, long row_end,
                          double *lut_dev);
 /* Same grid for ensemble members [member_begin, member_end): lut_dev[member][nsza][nvza][nphi][nw],
- * one launch sequence for all of them (needs nw >= 128). */
+ * one launch sequence for all of them, whatever the band count (a MODIS-style ensemble of 7 bands - the use the
+ * reference's README.md:8-9 names - as well as the full spectrum). */
 int  gort_rsurf_members_grid_dev(gort_engine *e, const gort_grid *g, int member_begin, int member_end,
                                  double *lut_dev);
 /* The same nA angle lines for ensemble members [member_begin, member_end): rsurf[member][nA][nw] - the

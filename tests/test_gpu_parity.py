@@ -1103,6 +1103,38 @@ def test_bench_two_ranks_rehearsal():
     assert set(d["slack_sweep"]) == {"0", "16", "48"} and d["slack_sweep"]["0"]["value"] > 0 and "errors" not in d
 
 
+def test_bench_four_ranks_rehearsal_uneven_slabs():
+    """bench.py at world 4 as the driver's 8-GPU run goes through it: four ranks on this one GPU over
+    gloo, 23 sun zeniths = 2093 rows in slabs of 524 / 524 / 524 / 521 inside a gatherable buffer of 2096 rows, placement
+    slack capped at 8 GiB (four ranks share the card) with its sweep, per-rank records, both parity checks around the
+    in-place all-gather, and config 5 with 64 members = 16 per rank."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run(["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                          "--master-addr", "127.0.0.1", "--master-port", "29551", os.path.join(root, "bench.py"),
+                          "--gpus", "4", "--steps", "3", "--warmup", "1", "--nsza", "23", "--rehearse", "--lut-slack-gib", "8",
+                          "--sustain-s", "0.2", "--c5-members", "64", "--no-cpu-baseline"], capture_output=True, timeout=1200)
+    assert run.returncode == 0, run.stderr.decode()[-3000:]
+    lines = [l for l in run.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and "errors" not in d
+    rows = 23 * 91
+    pr = d["per_rank"]
+    assert [r["rows"] for r in pr] == [[0, 524], [524, 1048], [1048, 1572], [1572, rows]]
+    assert "2096 rows" in d["config"]["sharding"]
+    for r in pr:
+        assert r["kernel_ms"] > 0 and r["hbm"]["placement_slack_gb"] <= 8.6
+    assert d["parity"]["max_rel_err"] <= 1e-9 and d["parity"]["nan_pattern_equal"]
+    pf = d["parity_after_allgather"]
+    assert pf["nan_pattern_equal"] and pf["max_rel_err"] <= 1e-9 and pf["samples_checked"] == 24 * 2101
+    assert d["allgather"]["bytes_received_per_gpu"] == (2096 - 524) * 361 * 2101 * 8
+    assert set(d["slack_sweep"]) == {"0", "16", "8"}
+    c5 = d["config5"]
+    assert c5["members"] == 64 and [r["members"] for r in c5["per_rank"]] == [[0, 16], [16, 32], [32, 48], [48, 64]]
+    for k in ("own_member", "foreign_member"):
+        assert c5["parity"][k]["nan_pattern_equal"] and c5["parity"][k]["max_rel_err"] <= 1e-9
+
+
 def test_bench_prints_its_line_when_the_allgather_throws():
     """The one multi-GPU run the driver gets must not end without a JSON line: a collective behind the timed region that
     raises (here: injected into the LUT all-gather) is recorded, later collectives are skipped, rank 0 prints the line
@@ -1326,6 +1358,49 @@ def test_ensemble_members_one_launch(golden):
     e.close(); single.close()
 
 
+@pytest.mark.parametrize("nw", [1, 7, 8, 9, 16, 100, 127])
+def test_member_grids_of_any_band_count(golden, nw):
+    """gort_rsurf_members_grid_dev below 128 bands (the MODIS-style ensemble the reference's README.md:8-9 names): up to 8
+    bands the fused node kernel with every row's own member, 9 ... 127 bands records + one thread per sample with the member
+    in blockIdx.z.  32 members in one call == 32 single-canopy runs, bit for bit; the first 8 against the reference's own
+    runs of those members (tests/golden/c5_members.npz) at the bands picked; a member sub-range; a mirrored full circle."""
+    import torch
+    g, canopies, leaf = _members(golden)
+    n = len(canopies)
+    pick = np.unique(np.linspace(0, g["wl"].size - 1, nw).round().astype(int)) if nw > 1 else np.array([400])
+    assert pick.size == nw
+    wl = g["wl"][pick]
+    sp = np.stack([np.stack(api.spectra(wl, l)) for l in leaf])
+    members = [api.gap_probabilities(c) for c in canopies]
+    e = api.Engine()
+    e.set_members(members, sp)
+    single = api.Engine()
+    for grid in (_grid((30.0, 1.0, 1), (0.0, 45.0, 3), (0.0, 90.0, 4)), _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 10.0, 37))):
+        rows, nodes = grid.nsza * grid.nvza, grid.nsza * grid.nvza * grid.nphi
+        lut = torch.full((n * nodes * nw + 16,), -7.0, dtype=torch.float64, device="cuda")
+        e.rsurf_members_grid_dev(grid, 0, n, lut)
+        e.synchronize()
+        assert float(lut[n * nodes * nw:].max()) == -7.0
+        got = lut[:n * nodes * nw].view(n, nodes, nw)
+        assert not bool((got == -7.0).any())
+        one = torch.empty((nodes, nw), dtype=torch.float64, device="cuda")
+        for i in range(n):
+            single.set_canopy(members[i]); single.set_spectra(*sp[i])
+            single.rsurf_grid_dev(grid, 0, rows, one); single.synchronize()
+            a, b = got[i].cpu().numpy(), one.cpu().numpy()
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.int64), b[~np.isnan(b)].view(np.int64)), (nw, i)
+        part = torch.empty((3, nodes, nw), dtype=torch.float64, device="cuda")
+        e.rsurf_members_grid_dev(grid, 5, 8, part); e.synchronize()
+        assert torch.equal(part.view(torch.int64), got[5:8].contiguous().view(torch.int64))
+        if grid.nsza == 1:
+            host = got.cpu().numpy().reshape(n, 3, 4, nw)
+            for i in range(8):
+                for a, (vz, ph) in enumerate(g["angles"][:, :2]):
+                    if vz in (0.0, 45.0, 90.0) and ph in (0.0, 90.0, 180.0):
+                        assert err(host[i, int(vz // 45), int(ph // 90)], g["m%d/rsurf" % i][a][pick]) <= REGRESSION, (nw, i, vz, ph)
+    e.close(); single.close()
+
+
 def test_ensemble_energy_table(golden):
     """Per-member albedo/fAPAR for a member range in one launch == the single-canopy energy path == the oracle."""
     import torch
@@ -1351,6 +1426,29 @@ def test_ensemble_energy_table(golden):
     e.close(); single.close()
 
 
+def test_reserve_members_after_configuration_leaves_the_engine_not_ready():
+    """gort_engine_reserve_members that has to grow a buffer discards what the buffer held: the engine then refuses to
+    evaluate ("no canopy set") instead of streaming garbage, and works again once it is configured again."""
+    wl = np.linspace(400.0, 2500.0, 33)
+    c = gpu_canopy(lai=4.0)
+    e = api.Engine()
+    e.set_canopy(c)
+    e.set_spectra(*api.spectra(wl))
+    ang = np.array([[10.0, 0.0, 30.0, 20.0], [-55.0, 40.0, 62.0, 300.0]])
+    want = e.rsurf_stream(ang)[0]
+    e.reserve_members(1, 33)                                    # nothing grows: still configured
+    assert np.array_equal(e.rsurf_stream(ang)[0].view(np.int64), want.view(np.int64))
+    e.reserve_members(500, 2101)                                # grows every buffer
+    with pytest.raises(api.GortError, match="no canopy set|no spectra set"):
+        e.rsurf_stream(ang)
+    with pytest.raises(api.GortError, match="no canopy set|no spectra set"):
+        e.energy_stream(ang)
+    e.set_canopy(c)
+    e.set_spectra(*api.spectra(wl))
+    assert np.array_equal(e.rsurf_stream(ang)[0].view(np.int64), want.view(np.int64))
+    e.close()
+
+
 def test_ensemble_argument_errors():
     e = api.Engine()
     c = gpu_canopy(lai=4.0)
@@ -1358,9 +1456,6 @@ def test_ensemble_argument_errors():
         e.set_members_leaf([c], [api.leaf_soil()], [399.0, 500.0])
     assert ex.value.code == api.ERANGE
     e.set_members_leaf([c, c], [api.leaf_soil(), api.leaf_soil()], np.linspace(400, 2500, 64))
-    import torch
-    with pytest.raises(api.GortError):       # LUT path needs >= 128 bands for ensembles
-        e.rsurf_members_grid_dev(api.hemisphere_grid(2, 2, 2), 0, 2, torch.empty(2 * 8 * 64, dtype=torch.float64, device="cuda"))
     with pytest.raises(api.GortError):       # single-canopy spectra call on a 2-member engine
         e.set_spectra(np.ones(4), np.ones(4) * .1, np.ones(4) * .1)
     e.close()

@@ -69,7 +69,7 @@ def test_one_member_of_an_ensemble_takes_the_node_partition_with_its_own_canopy(
     import torch
     g = _grid((0.0, 15.0, 5), (0.0, 10.0, 8), (0.0, 2.0, 181))
     rows = g.nsza * g.nvza
-    wl = np.linspace(400.0, 2500.0, 130)                      # member grids need >= 128 bands (records + LUT kernel)
+    wl = np.linspace(400.0, 2500.0, 130)                      # records + LUT kernel
     members = [api.gap_probabilities(api.make_canopy(lai=x)) for x in (1.5, 3.0, 4.5)]
     spectra = np.stack([np.stack(api.spectra(wl)) * f for f in (1.0, 0.9, 0.8)])
     e = api.Engine()

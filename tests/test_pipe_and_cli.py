@@ -162,7 +162,6 @@ def test_cli_energy_rows_formatted_once_equal_rows_formatted_per_line():
         assert out == out2, args
         rc3, out3, _ = _gortt(["-LAI", "4.0"] + args, text, dict(small, GORTT_THREADS="3"))
         assert rc3 == 0 and out3 == out
-    lines = out.split(b"\n") if False else None
     # every line its own sun direction, one big chunk
     ang2 = np.round(_lines(rng, 1500), 4)
     text2 = ("%d 5 450 550 650 850 1600\n" % 1500).encode() + "".join("%.4f %.4f %.4f %.4f\n" % tuple(r) for r in ang2).encode()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One stream shape, device-resident: tools/bench_lines.py LINES BANDS [REPS].  For profiles of the kernel a band count
-takes (rocprofv3 --kernel-trace --stats / --pmc ... -- python3 tools/bench_lines.py 1000000 100 5)."""
+takes: rocprofv3 --kernel-trace --stats / --pmc ... -- "$PY" tools/bench_lines.py 1000000 100 5 with
+PY=$(python3 -c 'import sys; print(sys.executable)') - the interpreter BINARY itself after `--`: a `python3` shim, env or bash
+there would be an exec hop behind a profiler that has already initialised the GPU."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
