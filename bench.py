@@ -204,7 +204,7 @@ def measure_traffic(args, timeout_s=150):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
-             "--sustain-s", "0", "--no-config5", "--no-configs", "--lut-draws", "1", "--no-traffic", "--nsza", str(args.nsza), "--nw", str(args.nw)]
+             "--sustain-s", "0", "--no-config5", "--no-configs", "--lut-draws", "1", "--placement-evidence", "0", "--no-traffic", "--nsza", str(args.nsza), "--nw", str(args.nw)]
     kb = {}
     for counter in ("WRITE_SIZE", "FETCH_SIZE"):
         d = tempfile.mkdtemp(prefix="gort_pmc_", dir="/tmp")
@@ -444,9 +444,13 @@ def main():
     ap.add_argument("--nsza", type=int, default=91, help="sun-zenith nodes (91 = the metric grid)")
     ap.add_argument("--nw", type=int, default=2101, help="bands (2101 = the metric grid; other values are tuning experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lut-draws", type=int, default=5,
+    ap.add_argument("--lut-draws", type=int, default=None,
                     help="max_draws of gort_lut_alloc, the C ABI's allocator for LUT buffers: > 1 = the placement of this rank's "
-                         "window is measured (1 = plain allocation); the first-draw timing is always measured and reported beside it")
+                         "window is measured (1 = plain allocation).  Default: 1 at N = 1 (the headline is measured on a plain "
+                         "allocation, DESIGN.md 5.1), 5 at N > 1 (a rank's slab is placed by a scan through slack)")
+    ap.add_argument("--placement-evidence", type=int, default=3,
+                    help="N = 1: after the timed steps, this many plain allocations alive together (the headline's buffer among them) "
+                         "are each probed with gort_lut_alloc's store-pattern probe and written by 2 steps of the kernel: `per_draw`")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")
     ap.add_argument("--sustain-s", type=float, default=3.0,
                     help="after the timed region, keep stepping for this many seconds and report the mean step ('sustained'); 0 = off")
@@ -479,6 +483,8 @@ def main():
     import torch
     from gort_amd import api
 
+    if args.lut_draws is None:
+        args.lut_draws = 1 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 5
     if args.configs_only:
         torch.cuda.set_device(0)
         api.set_device(0)
@@ -591,14 +597,36 @@ def main():
     # ---- (1) a plain first allocation, timed exactly like the record: what hipMalloc's first answer is worth ----
     first = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1)
     fd_dt, fd_kernel = timed_steps(first.at(window[0]), args.warmup, args.steps)
-    # ---- (1b) N = 1: does the allocator's probe rank placements the way the kernel does?  Up to --lut-draws plain
-    #           allocations alive together (the first one among them), each probed with gort_lut_alloc's own store-pattern
-    #           probe and then written by 2 steps of the real kernel; the record is `per_draw` ----
+    first.free()
+    # ---- (2) the product allocator of the C ABI (gort_lut_alloc: best of <= --lut-draws placements by a store-pattern
+    #          probe of the window this rank writes); the number of record is measured on its buffer ----
+    #          At world > 1 the window is placed by a scan through slack that stays allocated (DESIGN.md 5.1 step 11): the
+    #          same steps are also timed with the slack capped at 0 and 16 GiB, so that the record says what the slack buys.
+    slack_sweep = None
+    if world > 1 and args.lut_draws > 1:
+        slack_sweep = {}
+        for cap in sorted({0, 16} - {args.lut_slack_gib}):
+            eng.set_lut_slack_gib(cap)
+            b2 = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
+            s_dt, s_k = timed_steps(b2.at(window[0]), args.warmup, args.steps)
+            slack_sweep[str(cap)] = {"dt": s_dt, "kernel_ms": s_k, "slack_gb": b2.placement["slack_bytes"] / 1e9}
+            b2.free()
+    eng.set_lut_slack_gib(args.lut_slack_gib)
+    buf = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
+    lut_ptr = buf.at(window[0])
+    free_b, total_b = torch.cuda.mem_get_info()
+    hbm = {"lut_buffer_gb": buf_rows * row_elems * 8 / 1e9, "placement_slack_gb": buf.placement["slack_bytes"] / 1e9,
+           "device_used_gb_with_lut": (total_b - free_b) / 1e9, "device_total_gb": total_b / 1e9}
+    dt, kernel_ms = timed_steps(lut_ptr, args.warmup, args.steps)
+    # ---- (3) N = 1: does the allocator's probe rank placements the way the kernel does?  Plain
+    #          allocations alive together - the headline's buffer is draw 0 - each probed with gort_lut_alloc's own
+    #          store-pattern probe and then written by 1 + 2 steps of the real kernel (after the timed steps: the probe
+    #          destroys the contents, the parity checks below recompute what they compare) ----
     per_draw, peak_used_gb = None, None
-    if world == 1 and args.lut_draws > 1 and r1 > r0:
-        held, per_draw = [first], []
+    if world == 1 and args.placement_evidence > 0 and r1 > r0:
+        held, per_draw = [buf], []
         win_bytes = window[1] * 8
-        for i in range(min(args.lut_draws, 4)):
+        for i in range(min(args.placement_evidence, 4)):
             if i > 0:
                 free_b, total_b = torch.cuda.mem_get_info()
                 if free_b < buf_rows * row_elems * 8 + (64 << 30):          # >= 64 GB stay free beside the draws
@@ -612,28 +640,7 @@ def main():
             per_draw.append({"probe_gbs": probe, "kernel_ms": k2})
         for b in held[1:]:
             b.free()
-    first.free()
-    # ---- (2) the product allocator of the C ABI (gort_lut_alloc: best of <= --lut-draws placements by a store-pattern
-    #          probe of the window this rank writes); the number of record is measured on its buffer ----
-    #          At world > 1 the window is placed by a scan through slack that stays allocated (DESIGN.md 5.1 step 11): the
-    #          same steps are also timed with the slack capped at 0 and 16 GiB, so that the record says what the slack buys.
-    slack_sweep = None
-    if world > 1 and args.lut_draws > 1:
-        slack_sweep = {}
-        for cap in sorted({0, 16} - {args.lut_slack_gib}):
-            os.environ["GORT_LUT_SLACK_GIB"] = str(cap)
-            b2 = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
-            s_dt, s_k = timed_steps(b2.at(window[0]), args.warmup, args.steps)
-            slack_sweep[str(cap)] = {"dt": s_dt, "kernel_ms": s_k, "slack_gb": b2.placement["slack_bytes"] / 1e9}
-            b2.free()
-    os.environ["GORT_LUT_SLACK_GIB"] = str(args.lut_slack_gib)
-    buf = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
-    os.environ.pop("GORT_LUT_SLACK_GIB", None)
-    lut_ptr = buf.at(window[0])
-    free_b, total_b = torch.cuda.mem_get_info()
-    hbm = {"lut_buffer_gb": buf_rows * row_elems * 8 / 1e9, "placement_slack_gb": buf.placement["slack_bytes"] / 1e9,
-           "device_used_gb_with_lut": (total_b - free_b) / 1e9, "device_total_gb": total_b / 1e9}
-    dt, kernel_ms = timed_steps(lut_ptr, args.warmup, args.steps)
+        timed_steps(lut_ptr, 1, 0)                 # the headline's buffer holds the LUT again (parity reads it)
 
     # ---- sustained rate: the same step back to back for >= --sustain-s seconds (clocks and power settled) ----
     dt, kernel_ms_max, fd_dt, fd_kernel_max = reduce_max([dt, kernel_ms, fd_dt, fd_kernel])
@@ -775,12 +782,15 @@ def main():
                        "sharding": "rows of (sun zenith, view zenith) in %d contiguous slabs (ceil partition); every rank "
                                    "computes into its window of ONE gatherable LUT buffer (%d rows, %.1f GB per GPU)"
                                    % (world, buf_rows, buf_rows * row_elems * 8 / 1e9),
-                       "allocation": "gort_lut_alloc, max_draws %d (the C ABI's allocator: placement of the rank's window measured; "
-                                     "first_draw = plain allocation, same steps)" % args.lut_draws},
+                       "allocation": ("gort_lut_alloc, max_draws %d: " % args.lut_draws) +
+                                     ("a plain allocation (the placement selection is not used for the headline at N = 1; `per_draw` "
+                                      "shows what it would have chosen from)" if args.lut_draws == 1 else
+                                      "the placement of the rank's window is measured; first_draw = plain allocation, same steps")},
             "per_draw": per_draw,
             "per_draw_what": None if per_draw is None else
-                             "plain allocations alive together (peak %.0f GB of the device in use), draw 0 = first_draw's buffer: "
-                             "gort_lut_alloc's store-pattern probe of each, then 2 steps of the real kernel on it (HIP events)" % peak_used_gb,
+                             "plain allocations alive together (peak %.0f GB of the device in use), draw 0 = the headline's buffer: "
+                             "gort_lut_alloc's store-pattern probe of each, then 1 + 2 steps of the real kernel on it (HIP events around "
+                             "the 2; a buffer's first steps run ~4 %% slower than its twentieth)" % peak_used_gb,
             "first_draw": {"value": total_samples * args.steps / fd_dt, "ms_per_step": fd_dt / args.steps * 1e3,
                            "kernel_ms_slowest_rank": fd_kernel_max,
                            "what": "the same warm-up + steps on a plain first allocation (gort_lut_alloc with max_draws 1), max over ranks"},

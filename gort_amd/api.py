@@ -90,7 +90,7 @@ DECLARED_SYMBOLS = [
 TUNING_SYMBOLS = [
     "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_time_streams", "gort_engine_stream_form",
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
-    "gort_engine_probe_store_pattern", "gort_selftest_index_math",
+    "gort_engine_probe_store_pattern", "gort_selftest_index_math", "gort_engine_set_lut_slack_gib",
 ]
 
 _lib = None
@@ -148,6 +148,7 @@ def lib():
         L.gort_engine_set_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.gort_engine_store_pattern_gbs.argtypes = [C.c_void_p]
         L.gort_engine_store_pattern_gbs.restype = D
+        L.gort_engine_set_lut_slack_gib.argtypes = [C.c_void_p, C.c_int]
         L.gort_engine_set_canopy.argtypes = [C.c_void_p, C.POINTER(Canopy)]
         L.gort_engine_set_spectra.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.gort_rsurf_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -631,6 +632,10 @@ class Engine:
         _check(lib().gort_lut_alloc(self.h, C.c_size_t(8 * int(doubles)), C.c_size_t(8 * int(off)), C.c_size_t(8 * int(cnt)),
                                     int(max_draws), C.byref(out), C.byref(info)))
         return LutBuffer(out.value, 8 * int(doubles), info, window)
+
+    def set_lut_slack_gib(self, gib):
+        """Cap (GiB) of the slack lut_alloc keeps beside a placed buffer of this engine (default: GORT_LUT_SLACK_GIB or 48)."""
+        _check(lib().gort_engine_set_lut_slack_gib(self.h, int(gib)))
 
     def probe_store_pattern(self, ptr, nbytes):
         """GB/s of the LUT kernel's bare store pattern over device memory the caller owns (contents destroyed)."""

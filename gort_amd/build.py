@@ -1,7 +1,8 @@
 """Build libgort_amd.so (HIP kernels + C ABI, gfx950) and the `gortt` drop-in executable.
 
     python -m gort_amd.build [--force]
-    python -m gort_amd.build --stamps        (a measuring build, gort_amd/libgort_amd_stamps.so: csrc/gort_stamps.h)
+    python -m gort_amd.build --ab            (the measuring build with the A/B switches, gort_amd/libgort_amd_ab.so)
+    python -m gort_amd.build --stamps        (the same with phase stamps in the kernels, gort_amd/libgort_amd_stamps.so)
 
 hipcc cross-compiles for gfx950 without a GPU.  Everything is built in-tree:
 gort_amd/libgort_amd.so and gort_amd/bin/gortt travel to the GPU box with the
@@ -58,22 +59,38 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-def build_stamps():
-    """gort_amd/libgort_amd_stamps.so: the same library with -DGORT_STAMPS (csrc/gort_stamps.h; tools/stamps.py) - a
-    measuring build beside the product library, never loaded unless GORT_AMD_LIB names it."""
-    obj = os.path.join(SRC, "build_stamps")
+def build_variant(name, defines, force=True):
+    """gort_amd/libgort_amd_<name>.so: the same sources with extra -D flags - a measuring build beside the product library,
+    never loaded unless GORT_AMD_LIB names it (or the `ab` tests do).
+        ab      -DGORT_AB: the A/B environment switches and the alternative kernel instantiations they select (csrc/gort_internal.h);
+                the tests marked `ab` run on it and hold every variant to the bits of the default
+        stamps  -DGORT_STAMPS -DGORT_AB: phase stamps in the kernels as well (csrc/gort_stamps.h; tools/stamps.py)"""
+    obj = os.path.join(SRC, "build_" + name)
     os.makedirs(obj, exist_ok=True)
     cc = hipcc()
-    common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-DGORT_STAMPS", "-I" + os.path.join(ROOT, "include"),
-              "-I" + SRC, "--offload-arch=" + ARCH]
+    import glob
+    headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(SRC, "*.h"))) + [os.path.abspath(__file__)]
+    common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + ["-D" + d for d in defines] + \
+             ["-I" + os.path.join(ROOT, "include"), "-I" + SRC, "--offload-arch=" + ARCH]
     objs = []
     for src, extra in UNITS:
+        s = os.path.join(SRC, src)
         o = os.path.join(obj, os.path.splitext(src)[0] + ".o")
-        _run([cc] + common + extra + ["-c", os.path.join(SRC, src), "-o", o])
+        if force or _newer(o, [s] + headers):
+            _run([cc] + common + extra + ["-c", s, "-o", o])
         objs.append(o)
-    lib = os.path.join(PKG, "libgort_amd_stamps.so")
-    _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs + ["-ldl"])
+    lib = os.path.join(PKG, "libgort_amd_%s.so" % name)
+    if force or _newer(lib, objs):
+        _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs + ["-ldl"])
     return lib
+
+
+def build_stamps():
+    return build_variant("stamps", ["GORT_STAMPS", "GORT_AB"])
+
+
+def build_ab(force=False):
+    return build_variant("ab", ["GORT_AB"], force=force)
 
 
 def build(force=False, verbose_resources=False):
@@ -107,5 +124,7 @@ def build(force=False, verbose_resources=False):
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
         build_stamps()
+    elif "--ab" in sys.argv:
+        build_ab(force="--force" in sys.argv)
     else:
         build(force="--force" in sys.argv, verbose_resources="--resources" in sys.argv)

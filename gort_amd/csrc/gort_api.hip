@@ -108,6 +108,7 @@ struct gort_engine {
     bool have_canopy = false, have_spectra = false, have_nodes = false, have_tables = false;
     int nw = 0;
     int device = 0;                      // the HIP device the engine was created on: its LUT buffers live there
+    int lut_slack_gib = 48;              // cap of the slack gort_lut_alloc keeps beside a placed buffer (GORT_LUT_SLACK_GIB at creation)
 };
 
 extern "C" int gort_device_count(void)
@@ -313,10 +314,16 @@ extern "C" int gort_engine_create(gort_engine **out)
         return fail(GORT_ENODEVICE, "gort_engine_create: cannot create streams/events");
     }
     if (hipGetDevice(&e->device) != hipSuccess) { (void)hipGetLastError(); e->device = 0; }
-    if (const char *v = getenv("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
-    if (const char *v = getenv("GORT_ENERGY_DEDUP")) e->energy_dedup = atoi(v) != 0;
-    if (const char *v = getenv("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
-    if (const char *v = getenv("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
+    if (const char *v = getenv("GORT_LUT_SLACK_GIB")) {
+        const long cap = atol(v);
+        e->lut_slack_gib = cap < 0 ? 0 : (cap > 63 ? 63 : (int)cap);
+    }
+    // A/B switches, read once per engine in the measuring build only (gort_internal.h); a host sets the duty weights through
+    // gort_engine_set_xcd_weights (include/gort_amd_tuning.h)
+    if (const char *v = ab_env("GORT_GRID_PIPELINE")) e->pipeline = atoi(v) != 0;
+    if (const char *v = ab_env("GORT_ENERGY_DEDUP")) e->energy_dedup = atoi(v) != 0;
+    if (const char *v = ab_env("GORT_XCD_CALIBRATE")) e->xcd_calibrated = e->xcd_weights_fixed = atoi(v) == 0;   // 0: equal weights
+    if (const char *v = ab_env("GORT_XCD_WEIGHTS")) {                                         // "32,25,32,25,..."
         int w[8];
         if (sscanf(v, "%d,%d,%d,%d,%d,%d,%d,%d", w, w + 1, w + 2, w + 3, w + 4, w + 5, w + 6, w + 7) == 8) {
             // the range gort_engine_set_xcd_weights accepts: what gort_engine_xcd_weights reports is what is used
@@ -386,6 +393,13 @@ extern "C" int gort_engine_xcd_weights(const gort_engine *e, int weights[8])
 }
 
 extern "C" int gort_selftest_index_math(void) { return selftest_index_math(); }
+
+extern "C" int gort_engine_set_lut_slack_gib(gort_engine *e, int gib)
+{
+    if (!e || gib < 0 || gib > 63) return fail(GORT_EINVAL, "gort_engine_set_lut_slack_gib: bad argument");
+    e->lut_slack_gib = gib;
+    return GORT_OK;
+}
 
 extern "C" double gort_engine_store_pattern_gbs(const gort_engine *e) { return e ? e->xcd_pattern_gbs : 0.0; }
 
@@ -905,7 +919,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     if (few_bands) {
         // up to 8 bands (config 3 has one): no records at all, the geometry kernel writes the samples itself - every row with its
         // own member's canopy and band constants (rows are global: member * rows_per_member + ...)
-        static const bool fuse = !(getenv("GORT_GRID_FUSE") && atoi(getenv("GORT_GRID_FUSE")) == 0);
+        static const bool fuse = !(ab_env("GORT_GRID_FUSE") && atoi(ab_env("GORT_GRID_FUSE")) == 0);
         if (nw <= 8 && fuse) return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream);
         // 9 ... 127 bands: full angle records, then one thread per sample (the LUT family's five-term sample).  Several members:
         // whole members only (what gort_rsurf_members_grid_dev asks for), member = blockIdx.z of the expansion
@@ -1069,13 +1083,10 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         for (int attempt = 0; attempt < 3 && rc == GORT_OK; ++attempt) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-            // GORT_LUT_SLACK_GIB: the cap of the slack that stays allocated with the buffer (default 48; 0 = no scan, a
-            // plain allocation).  Ranks that share a GPU, or a caching allocator beside this one, want it small.
-            size_t slack_gib = 48;
-            if (const char *v = getenv("GORT_LUT_SLACK_GIB")) {
-                const long cap = atol(v);
-                slack_gib = cap < 0 ? 0 : (cap > 63 ? 63 : (size_t)cap);
-            }
+            // the cap of the slack that stays allocated with the buffer (GORT_LUT_SLACK_GIB when the engine was created,
+            // gort_engine_set_lut_slack_gib; default 48; 0 = no scan, a plain allocation).  Ranks that share a GPU, or a
+            // caching allocator beside this one, want it small.
+            size_t slack_gib = (size_t)e->lut_slack_gib;
             while (slack_gib > 0 && bytes + slack_gib * GIB + 8 * GIB > free_b) slack_gib /= 2;
             slack_bytes = 0;
             for (;; slack_gib /= 2) {
@@ -1120,11 +1131,11 @@ extern "C" int gort_lut_alloc(gort_engine *e, size_t bytes, size_t win_offset, s
         }
     } else {
         // the window is (most of) the buffer: separate allocations, alive together (a freed candidate's memory would
-        // come straight back) as far as the device has room for them beside 8 GiB for everybody else
+        // come straight back) as far as the device has room for them beside 64 GiB for everybody else
         const int draws = select ? (max_draws < 5 ? max_draws : 5) : 1;
         for (; n < draws; ++n) {
             size_t free_b = 0, total_b = 0;
-            if (n > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)8 << 30))) {
+            if (n > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)64 << 30))) {
                 (void)hipGetLastError();
                 break;
             }

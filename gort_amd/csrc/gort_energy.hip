@@ -709,7 +709,7 @@ static int launch_energy_list(const gort_canopy *canopies_dev, int n_members, co
                               long nA, const double *nodes_dev, double *out_dev, long rows_cap, const EnergyTable &t,
                               long n_rows_known, hipStream_t s)
 {
-    const char *sr = getenv("GORT_ENERGY_SHARE_ROWS");       // read per call: the test switches it inside one process
+    const char *sr = ab_env("GORT_ENERGY_SHARE_ROWS");       // measuring build, read per call: the test switches it inside one process
     const bool share_rows = !(sr && atoi(sr) == 0);
     long most = n_rows_known >= 0 ? n_rows_known : nA;
     if (rows_cap >= 0 && most > rows_cap) most = rows_cap;
@@ -718,16 +718,19 @@ static int launch_energy_list(const gort_canopy *canopies_dev, int n_members, co
     RowsOut ro;
     ro.rows_cap = rows_cap;
     ro.member_stride = (rows_cap >= 0 ? rows_cap : nA) * (long)nw * 3;
-    const char *pl = getenv("GORT_ENERGY_BATCH");            // 0: one line after the other (tests compare the two)
-    if (share_rows && !(pl && atoi(pl) == 0))
-        hipLaunchKernelGGL(energy_list_batched_kernel, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev,
-                           nw, angles_dev, nA, nodes_dev, out_dev, (const unsigned *)t.uniq, ro);
-    else if (share_rows)
+#ifdef GORT_AB
+    const char *pl = ab_env("GORT_ENERGY_BATCH");            // 0: one line after the other (tests compare the two)
+    if (share_rows && pl && atoi(pl) == 0)
         hipLaunchKernelGGL(energy_list_kernel<true>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
                            angles_dev, nA, nodes_dev, out_dev, (const unsigned *)t.uniq, ro);
-    else
+    else if (!share_rows)
         hipLaunchKernelGGL(energy_list_kernel<false>, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev, nw,
                            angles_dev, nA, nodes_dev, out_dev, (const unsigned *)t.uniq, ro);
+    else
+#endif
+        hipLaunchKernelGGL(energy_list_batched_kernel, dim3(wgs, (unsigned)n_members), dim3(ENERGY_THREADS), 0, s, canopies_dev, L_dev,
+                           nw, angles_dev, nA, nodes_dev, out_dev, (const unsigned *)t.uniq, ro);
+    (void)share_rows;
     return check_launch("energy_list_kernel");
 }
 
@@ -753,7 +756,7 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     if (n_members > 65535) return fail(GORT_EINVAL, "energy: %d members in one launch (max 65535)", n_members);
     hipStream_t s = (hipStream_t)stream;
     if (!ws_dev || nA < ENERGY_DEDUP_MIN_LINES) {
-        const char *sr = getenv("GORT_ENERGY_SHARE_ROWS");   // read per call: the test switches it inside one process
+        const char *sr = ab_env("GORT_ENERGY_SHARE_ROWS");   // measuring build, read per call: the test switches it inside one process
         const bool share_rows = !(sr && atoi(sr) == 0);
         if (nA >= (1L << 31)) return fail(GORT_EINVAL, "energy: %ld lines in one launch", nA);
         // band ranges: as many as give every range one pass, as far as every workgroup still has a CU of its own (two
@@ -770,12 +773,15 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
         if (splits < 1) splits = 1;
         if (splits > 64) splits = 64;
         const dim3 grid((unsigned)nA, (unsigned)n_members, (unsigned)splits);
-        if (share_rows)
-            hipLaunchKernelGGL(energy_kernel<true>, grid, dim3(ENERGY_THREADS), 0, s,
-                               canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
-        else
+#ifdef GORT_AB
+        if (!share_rows)
             hipLaunchKernelGGL(energy_kernel<false>, grid, dim3(ENERGY_THREADS), 0, s,
                                canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
+        else
+#endif
+            hipLaunchKernelGGL(energy_kernel<true>, grid, dim3(ENERGY_THREADS), 0, s,
+                               canopies_dev, L_dev, nw, angles_dev, nA, nodes_dev, energy_dev);
+        (void)share_rows;
         return check_launch("energy_kernel");
     }
     int rc = launch_energy_table(angles_dev, nA, ws_dev, nullptr, stream);
@@ -789,7 +795,7 @@ int launch_energy(const gort_canopy *canopies_dev, int n_members, const double *
     const int row = 3 * nw;
     // rows of at least a KiB, and counters that fit the table's memory (done with by now): the row-by-row form is launched
     // too, and the number of owner lines decides on the device which of the two works (broadcast_goes_by_rows)
-    const char *bf = getenv("GORT_ENERGY_BROADCAST");        // "chunks" / "rows": one form for everything (tests compare the two)
+    const char *bf = ab_env("GORT_ENERGY_BROADCAST");        // measuring build: "chunks" / "rows" = one form for everything
     const bool rows_possible = row >= CHUNK && (size_t)n_members * sizeof(unsigned) <= cap * sizeof(unsigned long long) &&
                                !(bf && bf[0] == 'c');
     const bool rows_always = rows_possible && bf && bf[0] == 'r';

@@ -14,7 +14,7 @@
 namespace gort {
 namespace {
 
-// Tuning knobs of the flat kernels (environment, read once; the table of all knobs is in DESIGN.md 10):
+// Tuning knobs of the flat kernels (A/B switches: the measuring build only, gort_internal.h; read once):
 //   GORT_EXPAND_DEPTH    1 | 2 | 4                coefficient records in flight per lane (LUT kernel)
 //   GORT_EXPAND_NT       1 | 0                    non-temporal stores
 //   GORT_EXPAND_WAVES    target wave stride of expand_flat_kernel in chunks = waves per panel (rounded to a
@@ -46,14 +46,14 @@ struct ExpandTuning {
     int stream_steps = 0;           // GORT_STREAM_STEPS: steps per wave = panel height of the per-line stream kernel; 0 = from the stream's size
     ExpandTuning()
     {
-        if (const char *v = getenv("GORT_EXPAND_NT")) nt = atoi(v) != 0;
-        if (const char *v = getenv("GORT_EXPAND_DEPTH")) depth = atoi(v);
-        if (const char *v = getenv("GORT_EXPAND_WAVES")) waves = atol(v);
-        if (const char *v = getenv("GORT_STREAM_WAVES")) stream_waves = atol(v);
-        if (const char *v = getenv("GORT_STREAM_STEPS")) stream_steps = atoi(v);
+        if (const char *v = ab_env("GORT_EXPAND_NT")) nt = atoi(v) != 0;
+        if (const char *v = ab_env("GORT_EXPAND_DEPTH")) depth = atoi(v);
+        if (const char *v = ab_env("GORT_EXPAND_WAVES")) waves = atol(v);
+        if (const char *v = ab_env("GORT_STREAM_WAVES")) stream_waves = atol(v);
+        if (const char *v = ab_env("GORT_STREAM_STEPS")) stream_steps = atoi(v);
         if (stream_steps < 0) stream_steps = 0;
-        if (const char *v = getenv("GORT_EXPAND_XCD")) xcd_mode = atoi(v);
-        if (const char *v = getenv("GORT_EXPAND_STEPS")) steps = atoi(v);
+        if (const char *v = ab_env("GORT_EXPAND_XCD")) xcd_mode = atoi(v);
+        if (const char *v = ab_env("GORT_EXPAND_STEPS")) steps = atoi(v);
         if (xcd_mode < -1 || xcd_mode > 2) xcd_mode = -1;
         if (depth != 1 && depth != 2 && depth != 4) depth = 2;
         if (steps > 0) steps = (steps + depth - 1) / depth * depth;        // whole groups of DEPTH

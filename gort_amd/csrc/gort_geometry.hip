@@ -281,7 +281,7 @@ int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const d
 // few bands, no component spectra: one fused launch (GORT_STREAM_FUSE=0 keeps the two-kernel path, for tests)
 bool stream_fuses(int nw, bool want_scomp)
 {
-    const char *v = getenv("GORT_STREAM_FUSE");             // read per call: the tests switch it inside one process
+    const char *v = ab_env("GORT_STREAM_FUSE");             // measuring build, read per call: the tests switch it inside one process
     return !(v && atoi(v) == 0) && !want_scomp && nw > 0 && nw <= 16;
 }
 
@@ -300,7 +300,7 @@ int launch_geometry_stream_fused(const gort_canopy *canopy_dev, int n_members, c
 // Only for grids of non-negative zeniths, where the sun azimuth of every node is the 0 of the grid's lines.
 static bool grid_mirrors(const gort_grid &g)
 {
-    static const bool on = !(getenv("GORT_GRID_MIRROR") && atoi(getenv("GORT_GRID_MIRROR")) == 0);
+    static const bool on = !(ab_env("GORT_GRID_MIRROR") && atoi(ab_env("GORT_GRID_MIRROR")) == 0);
     return on && g.nphi >= 3 && g.phi0 == 0.0 && g.dphi > 0.0 && g.dphi * (g.nphi - 1) == 360.0 && g.sza0 >= 0.0 && g.dsza >= 0.0 &&
            g.vza0 >= 0.0 && g.dvza >= 0.0;
 }
@@ -340,7 +340,7 @@ static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_gr
     const dim3 block(GEOM_ROW_THREADS);
     hipStream_t s = (hipStream_t)stream;
     const long rows_per_member = (long)g.nsza * g.nvza;
-    const char *br = getenv("GORT_GRID_BY_ROWS");                      // tests: the general form for everything (read per call)
+    const char *br = ab_env("GORT_GRID_BY_ROWS");                      // measuring build: the general form for everything (read per call)
     const bool by_rows = br && atoi(br) != 0;
     if (!by_rows && row_begin / rows_per_member == (row_begin + rows - 1) / rows_per_member) {
         // one member: partitioned by nodes.  One round of the machine's slots (four waves per SIMD, two per workgroup) where the

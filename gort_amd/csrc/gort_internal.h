@@ -5,9 +5,22 @@
 #include "gort_amd.h"
 #include "gort_amd_tuning.h"
 
+#include <cstdlib>
+
 namespace gort {
 
 int fail(int code, const char *fmt, ...);
+
+// ---- A/B switches ----
+// Environment variables that select another kernel form, panel shape or mapping with THE SAME RESULT exist in the MEASURING
+// build only (python -m gort_amd.build --ab -> libgort_amd_ab.so, -DGORT_AB; so does the stamps build): the tests marked
+// `ab` run there and hold every variant to the bits of the default.  The product library reads none of them - ab_env() is
+// a null pointer at compile time and the alternative template instantiations are not compiled in.
+#ifdef GORT_AB
+inline const char *ab_env(const char *name) { return getenv(name); }
+#else
+inline const char *ab_env(const char *) { return nullptr; }
+#endif
 
 // ---- wavelength-only table L[k][nw] (SoA, k-major so that lanes read consecutive bands) ----
 enum LambdaSlot {

@@ -274,11 +274,15 @@ int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_
                        angles_per_sza, angle0, n_total, shift, stride, da, steps, make_fast_div((unsigned)stride),   \
                        make_fast_div((unsigned)nw), make_fast_div((unsigned)angles_per_sza), lut_dev,            \
                        xcd_mode, duty, useful, xcd_slots_dev)
+#ifdef GORT_AB
     if (tune.nt) {
         if (tune.depth == 1) GORT_FLAT(1, true); else if (tune.depth == 2) GORT_FLAT(2, true); else GORT_FLAT(4, true);
     } else {
         if (tune.depth == 1) GORT_FLAT(1, false); else if (tune.depth == 2) GORT_FLAT(2, false); else GORT_FLAT(4, false);
     }
+#else
+    GORT_FLAT(2, true);                 // the product's one form: two records in flight per lane, non-temporal stores
+#endif
 #undef GORT_FLAT
     return check_launch("expand_flat_kernel");
 }

@@ -368,12 +368,14 @@ static int launch_expand_stream_flat(const double *band_table_dev, int nw, const
     const long nblocks = plan_xcd_duty(xcd_mode, useful, nullptr, duty);
     if (nblocks >= (1L << 31)) return fail(GORT_EINVAL, "stream expansion: %ld workgroups in one launch", nblocks);
     const dim3 grid((unsigned)nblocks);
-    if (tune.nt)
-        hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, bands, nw, coef_dev, n_total, shift, stride,
+#ifdef GORT_AB
+    if (!tune.nt)
+        hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, bands, nw, coef_dev, n_total, shift, stride,
                            da, steps, make_fast_div((unsigned)stride), make_fast_div((unsigned)nw), rsurf_dev, xcd_mode, duty,
                            useful, xcd_slots_dev);
     else
-        hipLaunchKernelGGL(expand_flat_stream_kernel<false>, grid, dim3(256), 0, s, bands, nw, coef_dev, n_total, shift, stride,
+#endif
+        hipLaunchKernelGGL(expand_flat_stream_kernel<true>, grid, dim3(256), 0, s, bands, nw, coef_dev, n_total, shift, stride,
                            da, steps, make_fast_div((unsigned)stride), make_fast_div((unsigned)nw), rsurf_dev, xcd_mode, duty,
                            useful, xcd_slots_dev);
     return check_launch("expand_flat_stream_kernel");

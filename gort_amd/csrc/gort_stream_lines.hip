@@ -55,13 +55,21 @@ __device__ __forceinline__ void band_wait(BandRegs &r)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi) : : "memory");
 }
-__device__ __forceinline__ StreamBand band_of(const BandRegs &r)
+// cT: ONE of a band's twelve constants does not come off the scalar registers.  stream_sample() forms c2 t0 - cT, two band
+// constants in one instruction, and an instruction reads one scalar register pair: the compiler copied cT into a vector
+// register first, two v_mov_b32 per band - as dear as two FMAs in issue slots.  The wave keeps the cT of all bands in LDS
+// (nw doubles behind the rings) and reads them back as broadcasts - the LDS port, not the vector ALU - each requested beside
+// its band's scalar loads, a band ahead, and covered by the same wait.
+__device__ __forceinline__ StreamBand band_of(const BandRegs &r, double cT)
 {
     StreamBand b;
-    b.g2 = r.lo[0];  b.c1 = r.lo[1];  b.c2 = r.lo[2];  b.Rff = r.lo[3];  b.cT = r.lo[4];  b.tff = r.lo[5];  b.pff = r.lo[6];
+    b.g2 = r.lo[0];  b.c1 = r.lo[1];  b.c2 = r.lo[2];  b.Rff = r.lo[3];  b.cT = cT;  b.tff = r.lo[5];  b.pff = r.lo[6];
     b.rs = r.lo[7];  b.mgk = r.hi[0];  b.Zf = r.hi[1];  b.Tf = r.hi[2];  b.B = r.hi[3];
     return b;
 }
+typedef __attribute__((address_space(3))) double lds_double;
+// an LDS byte address as a pointer (the host pass of the compiler sees 64-bit pointers here: through uintptr_t)
+__device__ __forceinline__ lds_double *lds_at(unsigned byte_address) { return (lds_double *)(uintptr_t)byte_address; }
 
 // the cache line at position X (relative to the wave's 256-B aligned origin, a multiple of 16) of ring row `row`:
 // lane q of eight moves 16 bytes; positions outside [lo, hi) are not the wave's to write
@@ -82,13 +90,16 @@ __device__ __forceinline__ void emit_cache_line(const double *__restrict__ ring,
 }
 
 // ring rows: 0 = the cache line in front of the wave's first row (its head only), 1 + l = line l of the wave
-template <bool NT>
+// P32: the ring pitch is 32 doubles, every lane's ring a 256-byte aligned 256 bytes of LDS: the slot of the next band is
+// (slot + 8) & 255 OR-ed into the ring's address - an add and a v_and_or_b32 per band where the general form (pitch 34 for band
+// counts that are multiples of four) needs an add, an and and a shift-add
+template <bool NT, bool P32>
 __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__restrict__ canopy,
                                                           const double *__restrict__ angles, long nA,
                                                           const StreamBand *__restrict__ bands, int nw, int pitch,
                                                           double *__restrict__ out, double *__restrict__ K)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_ring[];
+    extern __shared__ __attribute__((aligned(256))) double s_ring[];
     const int lane = threadIdx.x;
     GORT_STAMPS_BEGIN();
     GORT_STAMP(0);
@@ -172,6 +183,9 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         }
     };
 
+    // the cT of every band, behind the rings (16-byte aligned: 65 pitch doubles are even); read back after the fence below
+    double *const s_cT = s_ring + 65 * pitch;
+    for (int i = lane; i < nw + 2; i += 64) s_cT[i] = bands[i < nw ? i : nw - 1].cT;
     // ---- band block 0: its 16 samples stay in registers as well (the row's head is among them)
     double head[BLOCK_BANDS];
 #pragma unroll
@@ -187,27 +201,45 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         BandRegs A, B;
         int t = BLOCK_BANDS;
         double vprev = head[BLOCK_BANDS - 1];                  // written again where it already is: harmless
+        wave_exchange();                                       // s_cT is complete
+        // the LDS address of band t's cT, kept in a vector register (it is uniform: left alone the compiler keeps it in a scalar
+        // one and copies it over for every read)
+        unsigned ct_at = (unsigned)(uintptr_t)(lds_double *)(s_cT + t);
+        asm volatile("" : "+v"(ct_at));
+        double ctA = *lds_at(ct_at), ctB = 0.0;    // cT of band t; B's follows with B's request
         band_request(A, bands + t);                            // nw >= 17
+        // where the sample of band t - 1 goes: byte `slot` of my ring (P32), or its index (general form)
+        lds_double *const ring_lds = (lds_double *)my_ring;
+        unsigned slot = P32 ? (unsigned)((pos + t - 1) & (RING - 1)) * 8u : 0u;
+        auto put = [&](int band, unsigned byte, double v) {
+            if (P32) *lds_at((unsigned)(uintptr_t)ring_lds | (byte & 255u)) = v;
+            else ring_lds[(pos + band) & (RING - 1)] = v;
+        };
         while (t < nw) {
             const int block_end = t + BLOCK_BANDS < nw ? t + BLOCK_BANDS : nw;
             while (t + 1 < block_end) {
                 band_wait(A);
+                ctB = *lds_at(ct_at + 8u);       // band t + 1
                 band_request(B, bands + t + 1);
-                my_ring[(pos + t - 1) & (RING - 1)] = vprev;
-                vprev = stream_sample(l, band_of(A));
+                put(t - 1, slot, vprev);
+                vprev = stream_sample(l, band_of(A, ctA));
                 band_wait(B);
+                ctA = *lds_at(ct_at + 16u);      // band t + 2 (s_cT has two doubles of padding)
                 band_request(A, bands + (t + 2 < nw ? t + 2 : nw - 1));
-                my_ring[(pos + t) & (RING - 1)] = vprev;
-                vprev = stream_sample(l, band_of(B));
+                put(t, slot + 8u, vprev);
+                vprev = stream_sample(l, band_of(B, ctB));
+                ct_at += 16u;
+                slot += 16u;
                 t += 2;
             }
             if (t < block_end) {                               // an odd band at the end of the last block
                 band_wait(A);
-                my_ring[(pos + t - 1) & (RING - 1)] = vprev;
-                vprev = stream_sample(l, band_of(A));
+                put(t - 1, slot, vprev);
+                vprev = stream_sample(l, band_of(A, ctA));
+                slot += 8u;
                 t += 1;
             }
-            my_ring[(pos + t - 1) & (RING - 1)] = vprev;
+            put(t - 1, slot, vprev);
             emit_full((t - 1) / BLOCK_BANDS - 1);
         }
         band_wait(A);                                          // the last request may still be on its way
@@ -259,8 +291,8 @@ constexpr int LINES_MIN_BANDS = 17;
 constexpr int LINES_MAX_BANDS = 255;
 bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp)
 {
-    const char *v = getenv("GORT_LINES_MAX_BANDS");           // read per call: tests and tools/shape_scan.py move the hand-over
-    const int max_bands = v ? atoi(v) : LINES_MAX_BANDS;       // to the flat-panel kernel inside one process
+    const char *v = ab_env("GORT_LINES_MAX_BANDS");           // measuring build, read per call: tests and tools/shape_scan.py move
+    const int max_bands = v ? atoi(v) : LINES_MAX_BANDS;       // the hand-over to the flat-panel kernel inside one process
     return !want_scomp && nw >= LINES_MIN_BANDS && nw <= max_bands && nA * (long)nw >= (1L << 18);
 }
 
@@ -276,15 +308,18 @@ int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_
     // ring pitch: even (16-B aligned rows); lanes' ring positions differ by nw, so a multiple of four bands wants
     // rows two doubles apart in the banks (two-way conflicts at worst), any other count none
     const int pitch = (nw % 4 == 0) ? RING + 2 : RING;
-    const size_t lds = sizeof(double) * 65 * (size_t)pitch;
+    const size_t lds = sizeof(double) * (65 * (size_t)pitch + (size_t)nw + 2);       // the rings, then the bands' cT (+ 2 of padding)
     const StreamBand *tb = reinterpret_cast<const StreamBand *>(band_table_dev);
-    static const bool nt = !(getenv("GORT_EXPAND_NT") && atoi(getenv("GORT_EXPAND_NT")) == 0);
-    if (nt)
-        hipLaunchKernelGGL(stream_lines_kernel<true>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
-                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
+#define GORT_LINES_LAUNCH(NT, P32) hipLaunchKernelGGL((stream_lines_kernel<NT, P32>), dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev, angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev)
+#ifdef GORT_AB
+    static const bool nt = !(ab_env("GORT_EXPAND_NT") && atoi(ab_env("GORT_EXPAND_NT")) == 0);
+    if (!nt && pitch == RING) GORT_LINES_LAUNCH(false, true);
+    else if (!nt) GORT_LINES_LAUNCH(false, false);
     else
-        hipLaunchKernelGGL(stream_lines_kernel<false>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
-                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
+#endif
+    if (pitch == RING) GORT_LINES_LAUNCH(true, true);
+    else GORT_LINES_LAUNCH(true, false);
+#undef GORT_LINES_LAUNCH
     return check_launch("stream_lines_kernel");
 }
 

@@ -4,7 +4,7 @@
  * NOT part of the drop-in boundary (include/gort_amd.h): nothing here changes a result, and no caller of the
  * reference's path needs any of it.  bench.py reads the kernel timers; tests use the form overrides to compare
  * kernels that must write the same bits; the XCD functions expose what the LUT kernel measured about the part.
- * The environment knobs that belong to the same category are listed in DESIGN.md (section "Knobs").
+ * The environment switches of the same category exist in the measuring build only (DESIGN.md, section "Knobs").
  */
 #ifndef GORT_AMD_TUNING_H
 #define GORT_AMD_TUNING_H
@@ -29,8 +29,8 @@ double gort_engine_last_stream_ms(gort_engine *e);
 /* ---- which kernel family expanded the last gort_rsurf_stream[_dev] call ----
  * 0 = a narrow-stream kernel (per sample / band-major / fused with the geometry for up to 16 bands), 1 = the aligned
  * flat-panel kernel (expand_flat_stream_kernel: >= 128 bands, >= 4M samples, records in between), 2 = the fused line kernel
- * (stream_lines_kernel: 17 ... 255 bands, >= 256K samples, geometry and samples in one launch; GORT_LINES_MAX_BANDS moves
- * the hand-over to 1).  All of them write the same bits; tests use this to know which one they have compared. */
+ * (stream_lines_kernel: 17 ... 255 bands, >= 256K samples, geometry and samples in one launch).  All of them write the same
+ * bits; tests use this to know which one they have compared. */
 int  gort_engine_stream_form(gort_engine *e);
 
 /* ---- XCDs ---- */
@@ -41,8 +41,7 @@ int  gort_engine_xcd_mapping(gort_engine *e);
  * the slower ones get a smaller share of the LUT slab.  Measured with one pass of the bare store pattern over a
  * buffer whose contents are about to be overwritten anyway: a fresh gort_lut_alloc buffer, or the output slab of a
  * grid call of >= 1 GiB right before the call writes it (only bytes the call itself will write); once per engine
- * and again when the slab's size class (power of two) changes.  GORT_XCD_CALIBRATE=0 or
- * GORT_XCD_WEIGHTS="w0,...,w7" override.  Returns 1 once calibrated or set, else 0. */
+ * and again when the slab's size class (power of two) changes.  Returns 1 once calibrated or set, else 0. */
 int  gort_engine_xcd_weights(const gort_engine *e, int weights[8]);
 /* set the weights (each 8..32) instead of calibrating; NULL = forget them and calibrate on the next big slab */
 int  gort_engine_set_xcd_weights(gort_engine *e, const int weights[8]);
@@ -52,6 +51,9 @@ double gort_engine_store_pattern_gbs(const gort_engine *e);
  * [dev, dev + bytes) (best of two passes after a first one that touches the pages; the contents are destroyed);
  * 0 for regions below ~0.8 GB (the pattern needs 64 panels), < 0 = a GORT_E* code */
 double gort_engine_probe_store_pattern(gort_engine *e, void *dev, size_t bytes);
+/* the cap (GiB, 0..63) of the slack gort_lut_alloc keeps beside a placed buffer of this engine (include/gort_amd.h): the
+ * engine starts with GORT_LUT_SLACK_GIB from the environment (default 48, read once when it is created) */
+int  gort_engine_set_lut_slack_gib(gort_engine *e, int gib);
 /* host-only self-test of the flat kernels' index arithmetic (multiply-shift divisions, XCD duty mapping as a
  * bijection); 0 = ok.  Needs no GPU. */
 int  gort_selftest_index_math(void);

@@ -1,0 +1,100 @@
+"""The A/B tests: kernel forms that must write the same bits, selected through environment switches that exist in the
+MEASURING build of the library only (gort_amd/libgort_amd_ab.so, -DGORT_AB: python -m gort_amd.build --ab; the product
+library reads none of them - VERDICT r4 item 7).  The tests marked `ab` all over tests/ run here, in ONE process of their
+own on that build; and what that build writes with every switch at its default is what the product library writes."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gort_amd import api
+
+AB_LIB = os.path.join(ROOT, "gort_amd", "libgort_amd_ab.so")
+AB_SWITCHES = [b"GORT_EXPAND_DEPTH", b"GORT_EXPAND_NT", b"GORT_EXPAND_XCD", b"GORT_EXPAND_STEPS", b"GORT_EXPAND_WAVES", b"GORT_STREAM_WAVES",
+               b"GORT_STREAM_STEPS", b"GORT_STREAM_FUSE", b"GORT_GRID_FUSE", b"GORT_GRID_MIRROR", b"GORT_GRID_BY_ROWS", b"GORT_GRID_PIPELINE",
+               b"GORT_LINES_MAX_BANDS", b"GORT_ENERGY_DEDUP", b"GORT_ENERGY_SHARE_ROWS", b"GORT_ENERGY_BATCH", b"GORT_ENERGY_BROADCAST",
+               b"GORT_XCD_CALIBRATE", b"GORT_XCD_WEIGHTS"]
+
+
+def test_the_product_library_has_no_ab_switches():
+    """No A/B switch's name is in libgort_amd.so, all of them are in the measuring build; what the product reads from the
+    environment: GORT_GAP_CACHE and GORT_LUT_SLACK_GIB (and GORT_AMD_LIB in the Python binding)."""
+    product = open(api.LIB_PATH if not os.environ.get("GORT_AMD_LIB") else os.path.join(ROOT, "gort_amd", "libgort_amd.so"), "rb").read()
+    assert not [s for s in AB_SWITCHES if s in product]
+    assert b"GORT_GAP_CACHE" in product and b"GORT_LUT_SLACK_GIB" in product
+    # the strings of the library that are nothing but a GORT_* name = what it can hand to getenv()
+    assert set(re.findall(rb"\x00(GORT_[A-Z_]{4,})(?=\x00)", product)) == {b"GORT_GAP_CACHE", b"GORT_LUT_SLACK_GIB"}
+    if os.path.exists(AB_LIB):
+        ab = open(AB_LIB, "rb").read()
+        assert not [s for s in AB_SWITCHES if s not in ab]
+        assert os.path.getsize(AB_LIB) > os.path.getsize(os.path.join(ROOT, "gort_amd", "libgort_amd.so"))
+
+
+def _default_forms():
+    """A few calls with every switch at its default: a 100-band stream (line kernel), a 7-band stream (fused), a wide
+    stream (flat panels), a 1-band and a 300-band grid, an albedo table and an `-energy` stream with shared rows."""
+    import torch
+    rng = np.random.default_rng(77)
+    eng = api.Engine()
+    eng.set_canopy(api.gap_probabilities(api.make_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3)))
+    out = {}
+    n = 6000
+    ang = np.stack([rng.uniform(-89, 89, n), rng.uniform(0, 360, n), rng.integers(0, 90, n).astype(float), rng.choice([0.0, 200.0], n)], 1)
+    a = torch.as_tensor(ang, device="cuda")
+    for nw in (100, 7, 2101):
+        eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
+        o = torch.empty((n, nw), dtype=torch.float64, device="cuda")
+        eng.rsurf_stream_dev(a, o); eng.synchronize()
+        out["stream_%d" % nw] = o.cpu().numpy()
+        out["form_%d" % nw] = np.array([{"narrow": 0, "flat": 1, "lines": 2}[eng.stream_form()]])
+    g = api.hemisphere_grid(5, 91, 361)
+    for nw in (1, 300):
+        eng.set_spectra(*api.spectra(np.linspace(450.0, 2300.0, nw)))
+        lut = torch.empty((5 * 91 * 361, nw), dtype=torch.float64, device="cuda")
+        eng.rsurf_grid_dev(g, 3, 5 * 91 - 2, lut[: (5 * 91 - 5) * 361]); eng.synchronize()
+        out["grid_%d" % nw] = lut[: (5 * 91 - 5) * 361].cpu().numpy()
+    eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, 211)))
+    out["energy_table"] = eng.energy_stream(np.array([[0.0, 0.0, float(s), 0.0] for s in range(0, 91, 6)]))
+    out["energy_stream"] = eng.energy_stream(ang[:700])
+    eng.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.ab
+def test_ab_build_dumps_its_default_forms():
+    """(runs in the A/B process) what the measuring build writes with every switch at its default, for the product's
+    process to compare with its own"""
+    path = os.environ.get("GORT_AB_DUMP")
+    if not path:
+        pytest.skip("no GORT_AB_DUMP")
+    assert os.path.samefile(api.LIB_PATH, AB_LIB)
+    np.savez(path, **_default_forms())
+
+
+@pytest.mark.gpu
+def test_ab_forms_on_the_measuring_build(tmp_path):
+    """Every test marked `ab` in one child process on libgort_amd_ab.so; then the default forms of that build against the
+    product library, bit for bit."""
+    assert os.path.exists(AB_LIB), "gort_amd/libgort_amd_ab.so missing: python -m gort_amd.build --ab"
+    assert not os.environ.get("GORT_AMD_LIB"), "this test compares the product library with the measuring build"
+    dump = str(tmp_path / "ab_defaults.npz")
+    env = dict(os.environ, GORT_AB_SUITE="1", GORT_AMD_LIB=AB_LIB, GORT_AB_DUMP=dump)
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-x", "-m", "gpu and ab", "-p", "no:cacheprovider"],
+                         capture_output=True, timeout=2400, env=env, cwd=ROOT)
+    tail = run.stdout.decode()[-3000:]
+    assert run.returncode == 0, tail + run.stderr.decode()[-2000:]
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 40 and " failed" not in tail and " skipped" not in tail, tail
+    theirs = dict(np.load(dump))
+    mine = _default_forms()
+    assert set(theirs) == set(mine)
+    for k in sorted(mine):
+        a, b = np.ascontiguousarray(mine[k]), np.ascontiguousarray(theirs[k])
+        assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)), k
+        assert np.array_equal(a.view(np.int64)[~np.isnan(a)], b.view(np.int64)[~np.isnan(b)]), k
+    assert [int(mine["form_%d" % nw][0]) for nw in (100, 7, 2101)] == [2, 0, 1]

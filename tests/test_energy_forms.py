@@ -53,6 +53,7 @@ def _same_bits_nan_for_nan(a, b):
     return np.array_equal(na, nb) and np.array_equal(_bits(a)[~na], _bits(b)[~nb])
 
 
+@pytest.mark.ab
 def test_row_terms_once_per_zenith_node_same_bits():
     """BASELINE config 4's 91 sun zeniths (the per-line kernel) and a 3000-line stream in which every line has its own sun
     direction (the list kernel behind the sun-direction table), a sun on the horizon and a NaN line among them."""
@@ -90,6 +91,7 @@ def test_row_terms_once_per_zenith_node_same_bits():
     assert np.abs(res["1"][0][:90].sum(axis=2) - 1.0).max() < 1e-12        # albedo + favegt + fasoil = 1
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("nw,n", [(61, 3001), (2101, 702), (5, 129), (513, 1503)])
 def test_batched_list_kernel_same_bits(nw, n):
     """energy_list_batched_kernel (four lines per workgroup pass: their row terms side by side on four waves, a band's
@@ -117,6 +119,7 @@ def test_batched_list_kernel_same_bits(nw, n):
     assert _same_bits_nan_for_nan(res["1"], res["0"])
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("nw,n", [(43, 4001), (128, 1501), (2101, 333), (7, 5001), (128, 100003), (47, 300007)])
 def test_broadcast_of_shared_rows_same_bits(nw, n):
     """Rows of 3 nw doubles copied from the line that owns their sun direction, by either broadcast (chunk by chunk of the
@@ -150,6 +153,7 @@ def test_broadcast_of_shared_rows_same_bits(nw, n):
             assert np.array_equal(_bits(res[form][k]), _bits(res["every line"][k])), (nw, form, k)
 
 
+@pytest.mark.ab
 def test_member_batched_broadcast_same_bits():
     """gort_energy_members_dev: the lines' rows are shared per member (blockIdx.y); with an odd nA x row every second
     member's slab starts on an 8-byte boundary of its own."""

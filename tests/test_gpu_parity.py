@@ -344,6 +344,7 @@ def test_grid_equals_stream_and_oracle(eng, nw):
     assert err(got, ref) <= REGRESSION
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("nw", [1, 3, 8])
 def test_few_band_grid_fused_equals_two_kernel_path(nw):
     """Grids of up to 8 bands (BASELINE config 3 has one) form their samples inside the geometry kernel; the
@@ -372,6 +373,7 @@ print(hashlib.sha256(lut[: (13 * 91 - 12) * 361].cpu().numpy().tobytes()).hexdig
     assert digests[0] == digests[1] and len(digests[0]) == 64
 
 
+@pytest.mark.ab
 def test_full_circle_grid_mirrors_its_azimuth_nodes(golden):
     """Grids whose azimuth nodes run once round the circle from 0 (BASELINE configs 3 and the metric grid) evaluate the
     nodes 0..180 and write each result to its mirror image too (rsurf depends on the relative azimuth through cos, sin^2
@@ -452,6 +454,7 @@ def test_energy_depends_on_sun_only(eng):
     assert np.array_equal(a[0], a[1]) and np.array_equal(a[0], a[2])
 
 
+@pytest.mark.ab
 def test_energy_stream_shares_rows_of_equal_sun_directions(golden):
     """`-energy` on a stream (gortt.c:321-325 calls gortt_energy per line; the hemispherical integral of
     gortt_albedo.c:62-138 keeps only the line's sun zenith and sun azimuth): 100 000 lines with 91 sun zeniths - some
@@ -808,6 +811,7 @@ def _wide_stream_lines(n, seed):
     return np.round(ang, 6)
 
 
+@pytest.mark.ab
 def test_wide_stream_kernels_against_the_reference():
     """The WIDE stream kernels pinned to the real reference itself (not only to the restatement): 60 000 lines x 180
     bands (as many bands as the reference's 999-character header takes; 1.08e7 samples), through the flat-panel kernel
@@ -985,6 +989,7 @@ print(hashlib.sha256(lut.view(-1)[5:5 + 63 * 361 * 2101].cpu().numpy().tobytes()
 """
 
 
+@pytest.mark.ab
 def test_lut_kernel_variants_bitwise_identical():
     """Every tuning variant of the LUT expansion (kernel form, XCD mapping mode, prefetch depth, wave count,
     store flavour) writes the same bytes: the knobs change speed only."""
@@ -1531,6 +1536,7 @@ def test_finite_difference_jacobian_is_the_forward_model():
     assert (J[STATE.index("Cab"), :, 0] < 0).all()
 
 
+@pytest.mark.ab
 def test_grid_pipeline_equals_single_stream():
     """LUT calls whose records fit the double buffer are pipelined over two streams (geometry of call i+1 under
     the expansion of call i); larger ones and engines with GORT_GRID_PIPELINE=0 use one stream.  A sequence that

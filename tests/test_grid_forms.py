@@ -34,6 +34,7 @@ GRIDS = {
 }
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("name", sorted(GRIDS))
 @pytest.mark.parametrize("nw", [1, 3, 40])
 def test_node_partition_equals_row_partition(name, nw):

@@ -152,6 +152,7 @@ def test_grid_lines_through_the_stream_equal_the_lut(setup):
     assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13
 
 
+@pytest.mark.ab
 @pytest.mark.parametrize("nw", [1, 4, 16, 17])
 def test_few_band_streams_fused_launch_equals_two_kernels(setup, nw):
     """Streams of up to 16 bands (C1, C2, an ensemble filter's observation operator) take ONE launch: geometry and samples
@@ -183,6 +184,7 @@ def test_few_band_streams_fused_launch_equals_two_kernels(setup, nw):
     assert relerr(res["1"][0][:64], ref, floor=1e-12) <= 1e-9
 
 
+@pytest.mark.ab
 def test_member_batched_few_band_stream_fuses_the_same_way():
     from gort_amd.ensemble import DEFAULT, Ensemble
     rng = np.random.default_rng(77)
@@ -199,6 +201,7 @@ def test_member_batched_few_band_stream_fuses_the_same_way():
     assert fused.shape == (9, 40, 4) and np.array_equal(fused.view(np.int64), two.view(np.int64))
 
 
+@pytest.mark.ab
 def test_flat_kernel_panel_shapes_write_the_same_bits():
     """The panel shape of the flat stream kernel (waves x steps: chosen from the stream's size, or GORT_STREAM_WAVES /
     GORT_STREAM_STEPS) changes the ORDER in which chunks are written, never a bit: one sha256 over 20 outputs (five band

@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """`-energy` on a stream (gortt.c:321-325): N random lines with 91 distinct sun zeniths x 2101 bands, device-resident,
-with the rows of equal sun directions shared (the default) and with every line evaluated (GORT_ENERGY_DEDUP=0).
+with the rows of equal sun directions shared (the default) and with every line evaluated (GORT_ENERGY_DEDUP=0, a switch
+of the measuring build gort_amd/libgort_amd_ab.so, which this tool loads).
 Prints ms per call and the output rate (24 B per (line, band): albedo, vegetation and soil absorption)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+# GORT_ENERGY_DEDUP is an A/B switch: it exists in the measuring build only (python -m gort_amd.build --ab)
+os.environ.setdefault("GORT_AMD_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gort_amd", "libgort_amd_ab.so"))
 import torch
 from gort_amd import api
 
