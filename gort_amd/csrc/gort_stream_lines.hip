@@ -55,21 +55,13 @@ __device__ __forceinline__ void band_wait(BandRegs &r)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.lo), "+s"(r.hi) : : "memory");
 }
-// cT: ONE of a band's twelve constants does not come off the scalar registers.  stream_sample() forms c2 t0 - cT, two band
-// constants in one instruction, and an instruction reads one scalar register pair: the compiler copied cT into a vector
-// register first, two v_mov_b32 per band - as dear as two FMAs in issue slots.  The wave keeps the cT of all bands in LDS
-// (nw doubles behind the rings) and reads them back as broadcasts - the LDS port, not the vector ALU - each requested beside
-// its band's scalar loads, a band ahead, and covered by the same wait.
-__device__ __forceinline__ StreamBand band_of(const BandRegs &r, double cT)
+__device__ __forceinline__ StreamBand band_of(const BandRegs &r)
 {
     StreamBand b;
-    b.g2 = r.lo[0];  b.c1 = r.lo[1];  b.c2 = r.lo[2];  b.Rff = r.lo[3];  b.cT = cT;  b.tff = r.lo[5];  b.pff = r.lo[6];
+    b.g2 = r.lo[0];  b.c1 = r.lo[1];  b.c2 = r.lo[2];  b.Rff = r.lo[3];  b.cT = r.lo[4];  b.tff = r.lo[5];  b.pff = r.lo[6];
     b.rs = r.lo[7];  b.mgk = r.hi[0];  b.Zf = r.hi[1];  b.Tf = r.hi[2];  b.B = r.hi[3];
     return b;
 }
-typedef __attribute__((address_space(3))) double lds_double;
-// an LDS byte address as a pointer (the host pass of the compiler sees 64-bit pointers here: through uintptr_t)
-__device__ __forceinline__ lds_double *lds_at(unsigned byte_address) { return (lds_double *)(uintptr_t)byte_address; }
 
 // the cache line at position X (relative to the wave's 256-B aligned origin, a multiple of 16) of ring row `row`:
 // lane q of eight moves 16 bytes; positions outside [lo, hi) are not the wave's to write
@@ -90,16 +82,13 @@ __device__ __forceinline__ void emit_cache_line(const double *__restrict__ ring,
 }
 
 // ring rows: 0 = the cache line in front of the wave's first row (its head only), 1 + l = line l of the wave
-// P32: the ring pitch is 32 doubles, every lane's ring a 256-byte aligned 256 bytes of LDS: the slot of the next band is
-// (slot + 8) & 255 OR-ed into the ring's address - an add and a v_and_or_b32 per band where the general form (pitch 34 for band
-// counts that are multiples of four) needs an add, an and and a shift-add
-template <bool NT, bool P32>
+template <bool NT>
 __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__restrict__ canopy,
                                                           const double *__restrict__ angles, long nA,
                                                           const StreamBand *__restrict__ bands, int nw, int pitch,
                                                           double *__restrict__ out, double *__restrict__ K)
 {
-    extern __shared__ __attribute__((aligned(256))) double s_ring[];
+    extern __shared__ __attribute__((aligned(16))) double s_ring[];
     const int lane = threadIdx.x;
     GORT_STAMPS_BEGIN();
     GORT_STAMP(0);
@@ -140,21 +129,7 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
     const int m = (nw + BLOCK_BANDS - 1) / BLOCK_BANDS;
 
     // full cache line j of every row (rows whose line j is not complete inside the row skip it): eight reads, then the
-    // stores.  What does not depend on j is formed once per wave - per store slot the row's count of full lines, where
-    // its first one lies in its ring (the ring holds two lines: line j sits in half (first + j) & 1) and in the output.
-    int n_full[8], ring_at[8], first_half[8], tail_len[8];
-    double *gp[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int r = 8 * i + sub;
-        const int pr = g0 + r * nw;
-        const int F = (pr + 15) & ~15;
-        n_full[i] = r < lines_here ? (pr + nw - F) >> 4 : 0;
-        tail_len[i] = r < lines_here ? (pr + nw - F) & 15 : 0;     // what the row leaves in the cache line behind its last full one
-        first_half[i] = (F >> 4) & 1;
-        ring_at[i] = (((r + 1) * pitch) >> 1) + q;                 // in 16-byte units: pitch is even
-        gp[i] = origin + F + 2 * q;
-    }
+    // stores.  What does not depend on j is formed once per wave.
     // Lanes exchange data through LDS here (a lane's ring is read by the eight store lanes of its row; heads go into the
     // neighbour's ring): one wave, so no s_barrier - but the compiler must not move a lane's ring writes behind another
     // lane's reads of them.  Release fence + wave barrier + acquire fence emit no instruction; they only forbid that.
@@ -163,29 +138,59 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // Per store slot: where its 16 bytes of cache line j lie in the ring - the ring holds two lines, line j sits in half
+    // (first + j) & 1: rd_even[i] for even j, rd_even[i] + rd_step[i] (+-8 sixteen-byte units) for odd j, one multiply-add per
+    // read - and at[i] = the byte offset of its 16 bytes of line 0 from `origin`: 32 bits beside a wave-uniform base that moves
+    // 128 bytes per line (the store's scalar-base form: no 64-bit vector address arithmetic).
+    int n_full[8], tail_len[8], rd_even[8], rd_step[8];
+    unsigned at[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 8 * i + sub;
+        const int pr = g0 + r * nw;
+        const int F = (pr + 15) & ~15;
+        n_full[i] = r < lines_here ? (pr + nw - F) >> 4 : 0;
+        tail_len[i] = r < lines_here ? (pr + nw - F) & 15 : 0;     // what the row leaves in the cache line behind its last full one
+        const int first_half = (F >> 4) & 1;
+        const int ring_at = (((r + 1) * pitch) >> 1) + q;          // in 16-byte units: pitch is even
+        rd_even[i] = ring_at + (first_half << 3);
+        rd_step[i] = first_half ? -8 : 8;
+        at[i] = (unsigned)(F + 2 * q) * 8u;
+    }
+    // every row of a full wave has at least this many full lines (pr + nw - F >= nw - 15): lines below it leave unpredicated
+    const int n_full_everywhere = lines_here == 64 ? (nw - 15) >> 4 : 0;
+    char *const origin_bytes = reinterpret_cast<char *>(origin);
     auto emit_full = [&](int j) {
         wave_exchange();
         dbl2 v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            v[i] = reinterpret_cast<const dbl2 *>(s_ring)[ring_at[i] + (((first_half[i] + j) & 1) << 3)];
+        for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const dbl2 *>(s_ring)[rd_even[i] + rd_step[i] * (j & 1)];
         // the reads are waited for HERE, outside the branches of the stores: else the compiler's wait-count pass carries
         // them as pending round the loop and drains everything - the band request included - at the top of the next block
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));
+        char *const line = origin_bytes + 128L * j;               // wave-uniform
+        if (j < n_full_everywhere) {
+            // the eight stores in their scalar-base form, spelled out: the compiler forms one 64-bit vector address per store
+            // (it shares the address arithmetic with the predicated path below).  The wait state behind each store is the one
+            // the hardware wants between a store of more than 8 bytes and a write to its data registers.
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(at[i]), "v"(v[i]), "s"(line) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" : : "v"(at[i]), "v"(v[i]), "s"(line) : "memory");
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (j < n_full[i]) {
-                dbl2 *o = reinterpret_cast<dbl2 *>(gp[i] + 16 * j);
+                dbl2 *o = reinterpret_cast<dbl2 *>(line + at[i]);
                 if (NT) __builtin_nontemporal_store(v[i], o);
                 else *o = v[i];
             }
         }
     };
 
-    // the cT of every band, behind the rings (16-byte aligned: 65 pitch doubles are even); read back after the fence below
-    double *const s_cT = s_ring + 65 * pitch;
-    for (int i = lane; i < nw + 2; i += 64) s_cT[i] = bands[i < nw ? i : nw - 1].cT;
     // ---- band block 0: its 16 samples stay in registers as well (the row's head is among them)
     double head[BLOCK_BANDS];
 #pragma unroll
@@ -201,45 +206,27 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         BandRegs A, B;
         int t = BLOCK_BANDS;
         double vprev = head[BLOCK_BANDS - 1];                  // written again where it already is: harmless
-        wave_exchange();                                       // s_cT is complete
-        // the LDS address of band t's cT, kept in a vector register (it is uniform: left alone the compiler keeps it in a scalar
-        // one and copies it over for every read)
-        unsigned ct_at = (unsigned)(uintptr_t)(lds_double *)(s_cT + t);
-        asm volatile("" : "+v"(ct_at));
-        double ctA = *lds_at(ct_at), ctB = 0.0;    // cT of band t; B's follows with B's request
         band_request(A, bands + t);                            // nw >= 17
-        // where the sample of band t - 1 goes: byte `slot` of my ring (P32), or its index (general form)
-        lds_double *const ring_lds = (lds_double *)my_ring;
-        unsigned slot = P32 ? (unsigned)((pos + t - 1) & (RING - 1)) * 8u : 0u;
-        auto put = [&](int band, unsigned byte, double v) {
-            if (P32) *lds_at((unsigned)(uintptr_t)ring_lds | (byte & 255u)) = v;
-            else ring_lds[(pos + band) & (RING - 1)] = v;
-        };
         while (t < nw) {
             const int block_end = t + BLOCK_BANDS < nw ? t + BLOCK_BANDS : nw;
             while (t + 1 < block_end) {
                 band_wait(A);
-                ctB = *lds_at(ct_at + 8u);       // band t + 1
                 band_request(B, bands + t + 1);
-                put(t - 1, slot, vprev);
-                vprev = stream_sample(l, band_of(A, ctA));
+                my_ring[(pos + t - 1) & (RING - 1)] = vprev;
+                vprev = stream_sample(l, band_of(A));
                 band_wait(B);
-                ctA = *lds_at(ct_at + 16u);      // band t + 2 (s_cT has two doubles of padding)
                 band_request(A, bands + (t + 2 < nw ? t + 2 : nw - 1));
-                put(t, slot + 8u, vprev);
-                vprev = stream_sample(l, band_of(B, ctB));
-                ct_at += 16u;
-                slot += 16u;
+                my_ring[(pos + t) & (RING - 1)] = vprev;
+                vprev = stream_sample(l, band_of(B));
                 t += 2;
             }
             if (t < block_end) {                               // an odd band at the end of the last block
                 band_wait(A);
-                put(t - 1, slot, vprev);
-                vprev = stream_sample(l, band_of(A, ctA));
-                slot += 8u;
+                my_ring[(pos + t - 1) & (RING - 1)] = vprev;
+                vprev = stream_sample(l, band_of(A));
                 t += 1;
             }
-            put(t - 1, slot, vprev);
+            my_ring[(pos + t - 1) & (RING - 1)] = vprev;
             emit_full((t - 1) / BLOCK_BANDS - 1);
         }
         band_wait(A);                                          // the last request may still be on its way
@@ -262,8 +249,8 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         for (int i = 0; i < 8; ++i) {
             if (tail_len[i] > 0) {
                 const int r = 8 * i + sub;
-                const dbl2 v = reinterpret_cast<const dbl2 *>(s_ring)[ring_at[i] + (((first_half[i] + n_full[i]) & 1) << 3)];
-                double *o = gp[i] + 16 * n_full[i];
+                const dbl2 v = reinterpret_cast<const dbl2 *>(s_ring)[rd_even[i] + rd_step[i] * (n_full[i] & 1)];
+                double *o = reinterpret_cast<double *>(origin_bytes + 128L * n_full[i] + at[i]);
                 if (r + 1 < lines_here) {
                     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<dbl2 *>(o));
                     else *reinterpret_cast<dbl2 *>(o) = v;
@@ -308,18 +295,17 @@ int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_
     // ring pitch: even (16-B aligned rows); lanes' ring positions differ by nw, so a multiple of four bands wants
     // rows two doubles apart in the banks (two-way conflicts at worst), any other count none
     const int pitch = (nw % 4 == 0) ? RING + 2 : RING;
-    const size_t lds = sizeof(double) * (65 * (size_t)pitch + (size_t)nw + 2);       // the rings, then the bands' cT (+ 2 of padding)
+    const size_t lds = sizeof(double) * 65 * (size_t)pitch;
     const StreamBand *tb = reinterpret_cast<const StreamBand *>(band_table_dev);
-#define GORT_LINES_LAUNCH(NT, P32) hipLaunchKernelGGL((stream_lines_kernel<NT, P32>), dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev, angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev)
 #ifdef GORT_AB
     static const bool nt = !(ab_env("GORT_EXPAND_NT") && atoi(ab_env("GORT_EXPAND_NT")) == 0);
-    if (!nt && pitch == RING) GORT_LINES_LAUNCH(false, true);
-    else if (!nt) GORT_LINES_LAUNCH(false, false);
+    if (!nt)
+        hipLaunchKernelGGL(stream_lines_kernel<false>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
+                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
     else
 #endif
-    if (pitch == RING) GORT_LINES_LAUNCH(true, true);
-    else GORT_LINES_LAUNCH(true, false);
-#undef GORT_LINES_LAUNCH
+        hipLaunchKernelGGL(stream_lines_kernel<true>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
+                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
     return check_launch("stream_lines_kernel");
 }
 
