@@ -22,10 +22,27 @@ namespace {
 constexpr int ENERGY_THREADS = 512;
 constexpr long ENERGY_DEDUP_MIN_LINES = 128;      // below: one workgroup per line, no table (BASELINE config 4 has 91 lines, all distinct)
 
-__device__ inline double wave_sum(double v)
+// The sum of v over the wave's 64 lanes, IN LANE 63 (the other lanes hold partial sums).  Data-parallel moves - shifts inside
+// the rows of sixteen lanes (an inclusive scan: 1, 2, 4, 8), then the two row broadcasts of the GCN reduction idiom - instead
+// of six __shfl_down steps: those are ds_bpermute round trips through the LDS pipe, ~30 dependent ones per line for the five
+// sums of the quadrature (1.9 us of a line's 9, by the stamps), where a DPP move costs an issue slot.  One association for
+// every form of the albedo kernels (they all call this): the forms still write the same bits.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_moved(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);      // lanes without a source: 0
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_moved<0x111, 0xf>(v);          // row_shr:1
+    v += dpp_moved<0x112, 0xf>(v);          // row_shr:2
+    v += dpp_moved<0x114, 0xf>(v);          // row_shr:4
+    v += dpp_moved<0x118, 0xf>(v);          // row_shr:8   -> lane 15 of every row: the row's sum
+    v += dpp_moved<0x142, 0xa>(v);          // row_bcast:15 into rows 1 and 3
+    v += dpp_moved<0x143, 0xc>(v);          // row_bcast:31 into rows 2 and 3 -> lane 63: the wave's sum
     return v;
 }
 
@@ -179,7 +196,6 @@ __global__ __launch_bounds__(TABLE_THREADS) void energy_index_kernel(long nA, co
 constexpr int ENERGY_ZENITH_NODES = 16;
 struct EnergyShared {
     double part[5][ENERGY_THREADS / 64];
-    double abar[5];
     double sun[6];
     RowTerms row[ENERGY_ZENITH_NODES];
     RowScratch scr[ENERGY_ZENITH_NODES];
@@ -235,23 +251,27 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         part[k] = wave_sum(part[k]);
-        if (lane == 0) sh.part[k][wave] = part[k];
+        if (lane == 63) sh.part[k][wave] = part[k];
     }
     if (tid == 0) {
         sh.sun[0] = g.sun.fd;  sh.sun[1] = g.sun.mu;  sh.sun[2] = g.sun.t0;
         sh.sun[3] = g.sun.tp0; sh.sun[4] = g.sun.eps; sh.sun[5] = g.sun.pn0;
     }
     __syncthreads();
-    if (tid < 5) {
+    // every thread adds the eight waves' partial sums itself, in wave order (what five threads did for all between two
+    // barriers: the same additions in the same order, one barrier less)
+    double abar[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
         double t = 0.0;
-        for (int q = 0; q < ENERGY_THREADS / 64; ++q) t += sh.part[tid][q];
-        sh.abar[tid] = t;
+#pragma unroll
+        for (int q = 0; q < ENERGY_THREADS / 64; ++q) t += sh.part[k][q];
+        abar[k] = t;
     }
-    __syncthreads();
     GORT_STAMP(3);                                           // the five sums
     SunScalars s;
     s.fd = sh.sun[0];  s.mu = sh.sun[1];  s.t0 = sh.sun[2];  s.tp0 = sh.sun[3];  s.eps = sh.sun[4];  s.pn0 = sh.sun[5];
-    const double aC = sh.abar[0], aB = sh.abar[1], aZ = sh.abar[2], aG = sh.abar[3], aT = sh.abar[4];
+    const double aC = abar[0], aB = abar[1], aZ = abar[2], aG = abar[3], aT = abar[4];
     for (int i = band_begin + tid; i < band_end; i += ENERGY_THREADS) {
         BandTerms t;
         if (PREFETCH) {
@@ -398,7 +418,7 @@ __global__ __launch_bounds__(ENERGY_THREADS, 4) void energy_list_batched_kernel(
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 part[k] = wave_sum(part[k]);
-                if (lane == 0) sh.part[b][k][wave] = part[k];
+                if (lane == 63) sh.part[b][k][wave] = part[k];
             }
             if (tid == 0) {
                 sh.sun[b][0] = g.sun.fd;  sh.sun[b][1] = g.sun.mu;  sh.sun[b][2] = g.sun.t0;

@@ -296,13 +296,12 @@ __device__ __forceinline__ void row_terms_split(int n_rows, RowTerms *rows, RowS
 
 // The azimuth-dependent rest: overlap and Kg at the actual azimuth, the interpolated Kc, the other
 // proportions (gortt.c:424-449) and the hot spot.
+// (sin_r, cos_r) = M::sincos(raa): handed in, because a grid kernel has them in a table per azimuth node
 template <class M>
-__device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, double raa, GeomOut &o)
+__device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, double raa, double sin_r, double cos_r, GeomOut &o)
 {
 #pragma clang fp contract(off)
     const Primed &v = r.v, &s = r.s;
-    double sin_r, cos_r;
-    M::sincos(raa, sin_r, cos_r);
     const double O_r = overlap<M, false>(r.hb, s, v, cos_r, sin_r);
     const double Kg = M::exp(-(r.cov * (r.t1 - O_r)));
     const double ph_r = v.c * s.c + v.s * s.s * cos_r;
@@ -340,10 +339,25 @@ __device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, doubl
     o.sun = r.sun;
 }
 
+template <class M>
+__device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, double raa, GeomOut &o)
+{
+    double sin_r, cos_r;
+    M::sincos(raa, sin_r, cos_r);
+    finish_angle_with<M>(c, r, raa, sin_r, cos_r, o);
+}
+
 __device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa, GeomOut &o)
 {
     if (__builtin_expect(r.horizon, 0)) finish_angle_with<LibMath>(c, r, raa, o);
     else finish_angle_with<FastMath>(c, r, raa, o);
+}
+
+// the same with the azimuth's FastMath sine and cosine from the caller's table (a row on the reference's route forms its own)
+__device__ void finish_angle(const gort_canopy &c, const RowTerms &r, double raa, double sin_fast, double cos_fast, GeomOut &o)
+{
+    if (__builtin_expect(r.horizon, 0)) finish_angle_with<LibMath>(c, r, raa, o);
+    else finish_angle_with<FastMath>(c, r, raa, sin_fast, cos_fast, o);
 }
 
 // areal proportions + hot spot for one normalised geometry

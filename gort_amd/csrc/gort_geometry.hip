@@ -87,6 +87,11 @@ constexpr int GEOM_FUSED_MAX_BANDS = 8;      // the fused form serves grids of u
 #endif
 constexpr int GEOM_SPAN_THREADS = GORT_GEOM_SPAN_THREADS;      // threads of a workgroup of the node-partitioned form
 constexpr int GEOM_SPAN_ROWS = GEOM_SPAN_THREADS / 32 + 4;          // rows such a workgroup may touch (8 / 12 / 20 at 128 / 256 / 512 threads)
+// Azimuth table (round 5).  In a grid of non-negative zeniths a node's relative azimuth - and with it M::sincos(raa), ~75 of
+// a node's ~560 instructions - depends on its azimuth index only (gortt.c:240-279: saa = 0, vaa = phi): the waves that wait
+// for the row terms anyway fill a table of (raa, sin, cos) per azimuth node in LDS, and the node loop reads it.  The same
+// functions on the same numbers: the same bits.
+constexpr int GEOM_AZ_TABLE = 384;           // azimuth nodes per row the table holds (the mirrored hemisphere has 181, the full circle 361)
 
 // mode 0: full stream records (GORT_COEF_STRIDE doubles per node); 1: compact 64-B records for the LUT kernel;
 // 2: FUSED for grids of a few bands (BASELINE config 3 is one band): the node's samples are formed right here from
@@ -109,9 +114,10 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
                                                                           double *__restrict__ coef, int compact,
                                                                           const double *__restrict__ Lall, int nw,
-                                                                          double *__restrict__ rsurf, int mirror)
+                                                                          double *__restrict__ rsurf, int mirror, int az_table)
 {
     __shared__ RowTerms s_row[GEOM_ROWS];
+    __shared__ double s_az[3][GEOM_AZ_TABLE];
     __shared__ RowScratch s_scr[GEOM_ROWS];
     __shared__ double s_sun_terms[GEOM_ROWS][GEOM_FUSED_MAX_BANDS][5];      // fused form: C0, B, Z, G, T per (row, band)
     __shared__ int s_member[GEOM_ROWS];
@@ -150,6 +156,16 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         vza_deg = g.vza0 + ivza * g.dvza;
         sza_deg = g.sza0 + isza * g.dsza;
     };
+    constexpr int THREADS = ONE_MEMBER ? GEOM_SPAN_THREADS : GEOM_ROW_THREADS;
+    if (az_table && (int)threadIdx.x >= 64)                                 // the waves that would wait for the row terms
+        for (int l = (int)threadIdx.x - 64; l < per_row; l += THREADS - 64) {
+            double vza, sza, saa, raa, sn, cs;
+            normalise_angles(0.0, g.phi0 + l * g.dphi, 0.0, 0.0, vza, sza, saa, raa);
+            FastMath::sincos(raa, sn, cs);
+            s_az[0][l] = raa;
+            s_az[1][l] = sn;
+            s_az[2][l] = cs;
+        }
     if ((int)threadIdx.x >= 64 && (int)threadIdx.x - 64 < rows_here) {     // on the second wave: the first one is busy below
         const int i = (int)threadIdx.x - 64;
         long member;
@@ -182,7 +198,16 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         }
         __syncthreads();
     }
-    constexpr int THREADS = ONE_MEMBER ? GEOM_SPAN_THREADS : GEOM_ROW_THREADS;
+    // a node's azimuth-dependent rest: from the table where there is one
+    auto finish_node = [&](const gort_canopy &c, int r, int l, GeomOut &o) {
+        if (az_table) {
+            finish_angle(c, s_row[r], s_az[0][l], s_az[1][l], s_az[2][l], o);
+        } else {
+            double vza, sza, saa, raa;
+            normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
+            finish_angle(c, s_row[r], raa, o);
+        }
+    };
     if (compact == 1) {
         // LUT path: the five expansion coefficients of a node, one 64-B record - and its image's.  A lane holding its record
         // would store it as four 16-B pieces 64 B apart: every store instruction a quarter of 32 cache lines.  The wave
@@ -197,10 +222,8 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
             if (n < rel1) {
                 const int r = n / per_row, l = n - r * per_row;
                 const gort_canopy &c = canopies[ONE_MEMBER ? member0 : (long)s_member[r]];
-                double vza, sza, saa, raa;
-                normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
                 GeomOut o;
-                finish_angle(c, s_row[r], raa, o);
+                finish_node(c, r, l, o);
                 i = (first + r) * g.nphi + l;
                 const int l2 = g.nphi - 1 - l;
                 i2 = (mirror && l2 != l) ? (first + r) * g.nphi + l2 : -1;
@@ -237,10 +260,8 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         const int r = n / per_row, l = n - r * per_row;
         const long member = ONE_MEMBER ? member0 : (long)s_member[r];
         const gort_canopy &c = canopies[member];
-        double vza, sza, saa, raa;
-        normalise_angles(s_vza_deg[r], g.phi0 + l * g.dphi, s_sza_deg[r], 0.0, vza, sza, saa, raa);
         GeomOut o;
-        finish_angle(c, s_row[r], raa, o);
+        finish_node(c, r, l, o);
         const long i = (first + r) * g.nphi + l;
         const int l2 = g.nphi - 1 - l;
         const long i2 = (mirror && l2 != l) ? (first + r) * g.nphi + l2 : -1;       // the image, if the node has one
@@ -337,6 +358,11 @@ static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_gr
                                     int compact, const double *L_dev, int nw, double *rsurf_dev, void *stream)
 {
     const int mirror = grid_mirrors(g) ? 1 : 0;
+    // the azimuth table: grids of non-negative zeniths (no line's azimuths are turned by pi, gortt.c:244-251) whose rows fit it
+    const char *az = ab_env("GORT_GRID_AZ_TABLE");                  // measuring build, read per call: 0 = every node forms its own
+    const bool az_on = !(az && atoi(az) == 0);
+    const int az_table = az_on && g.sza0 >= 0.0 && g.dsza >= 0.0 && g.vza0 >= 0.0 && g.dvza >= 0.0 &&
+                         (mirror ? (g.nphi + 1) / 2 : g.nphi) <= GEOM_AZ_TABLE ? 1 : 0;
     const dim3 block(GEOM_ROW_THREADS);
     hipStream_t s = (hipStream_t)stream;
     const long rows_per_member = (long)g.nsza * g.nvza;
@@ -352,12 +378,12 @@ static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_gr
         if (G > slots) G = slots;
         if ((total + G - 1) / G > span_max) G = (total + span_max - 1) / span_max;
         hipLaunchKernelGGL((geometry_grid_kernel<GEOM_SPAN_ROWS, true>), dim3((unsigned)G), dim3(GEOM_SPAN_THREADS), 0, s, canopy_dev, g, row_begin, rows,
-                           coef_dev, compact, L_dev, nw, rsurf_dev, mirror);
+                           coef_dev, compact, L_dev, nw, rsurf_dev, mirror, az_table);
         return check_launch("geometry_grid_kernel");
     }
     const int per = geom_rows_per_workgroup(rows);
     const dim3 grid((unsigned)((rows + per - 1) / per));
-#define GORT_GRID_LAUNCH(ROWS) hipLaunchKernelGGL((geometry_grid_kernel<ROWS, false>), grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror)
+#define GORT_GRID_LAUNCH(ROWS) hipLaunchKernelGGL((geometry_grid_kernel<ROWS, false>), grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror, az_table)
     if (per == 4) GORT_GRID_LAUNCH(4);
     else if (per == 6) GORT_GRID_LAUNCH(6);
     else GORT_GRID_LAUNCH(8);

@@ -2,7 +2,9 @@
 
 * single-member launches are partitioned by NODES into the machine's workgroup slots (round 4), a workgroup evaluating the
   row terms of whatever rows its span touches;
-* everything else - and everything under GORT_GRID_BY_ROWS=1 - by ROWS (4 / 6 / 8 per workgroup).
+* everything else - and everything under GORT_GRID_BY_ROWS=1 - by ROWS (4 / 6 / 8 per workgroup);
+* with the azimuth table (round 5: raa, sin, cos per azimuth node in LDS, filled by the waves that wait for the row terms)
+  and with every node forming its own (GORT_GRID_AZ_TABLE=0).
 
 Grids of odd shapes, slabs that begin inside a grid (a rank's window), mirrored and unmirrored azimuths, one band (the
 fused form, BASELINE config 3), a few bands, and enough bands for the record + expansion path.
@@ -30,7 +32,8 @@ GRIDS = {
     "one_row": ((30.0, 1.0, 1), (40.0, 1.0, 1), (0.0, 1.0, 361)),
     "three_nodes": ((10.0, 20.0, 4), (0.0, 30.0, 3), (0.0, 180.0, 3)),               # rows of two evaluated nodes
     "unmirrored": ((5.0, 11.0, 7), (2.0, 9.0, 9), (3.0, 7.0, 50)),                   # phi0 != 0: every node evaluated
-    "long_rows": ((20.0, 30.0, 2), (10.0, 35.0, 3), (0.0, 0.25, 1441)),              # a span shorter than a row
+    "long_rows": ((20.0, 30.0, 2), (10.0, 35.0, 3), (0.0, 0.25, 1441)),              # a span shorter than a row; too long for the azimuth table
+    "negative_zeniths": ((-20.0, 20.0, 3), (-30.0, 30.0, 3), (0.0, 45.0, 9)),        # azimuths turned by pi row by row: no azimuth table
 }
 
 
@@ -48,8 +51,9 @@ def test_node_partition_equals_row_partition(name, nw):
     windows = [(0, rows)] + ([(rows // 3, rows - 1)] if rows > 3 else [])
     for r0, r1 in windows:
         out = {}
-        for by_rows in ("0", "1"):
+        for by_rows, az in (("0", "1"), ("1", "1"), ("0", "0"), ("1", "0")):
             os.environ["GORT_GRID_BY_ROWS"] = by_rows
+            os.environ["GORT_GRID_AZ_TABLE"] = az
             try:
                 buf = torch.full(((r1 - r0) * g.nphi * nw + 16,), -7.0, dtype=torch.float64, device="cuda")
                 lut = buf[8:8 + (r1 - r0) * g.nphi * nw]
@@ -57,10 +61,13 @@ def test_node_partition_equals_row_partition(name, nw):
                 e.synchronize()
             finally:
                 os.environ.pop("GORT_GRID_BY_ROWS")
+                os.environ.pop("GORT_GRID_AZ_TABLE")
             assert float(buf[:8].min()) == -7.0 and float(buf[-8:].max()) == -7.0
-            out[by_rows] = lut.cpu().numpy()
-        assert not (out["0"] == -7.0).any()
-        assert np.array_equal(out["0"].view(np.int64), out["1"].view(np.int64)), (name, nw, r0, r1)
+            out[by_rows + az] = lut.cpu().numpy()
+        assert not (out["01"] == -7.0).any()
+        for other in ("11", "00", "10"):
+            a, b = out["01"], out[other]
+            assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a.view(np.int64)[~np.isnan(a)], b.view(np.int64)[~np.isnan(b)]), (name, nw, r0, r1, other)
     e.close()
 
 
