@@ -446,11 +446,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lut-draws", type=int, default=None,
                     help="max_draws of gort_lut_alloc, the C ABI's allocator for LUT buffers: > 1 = the placement of this rank's "
-                         "window is measured (1 = plain allocation).  Default: 1 at N = 1 (the headline is measured on a plain "
-                         "allocation, DESIGN.md 5.1), 5 at N > 1 (a rank's slab is placed by a scan through slack)")
+                         "window is measured (1 = plain allocation).  Default: 3 at N = 1 (best of three 50 GB allocations by the "
+                         "store-pattern probe, >= 64 GB of the device left free; `per_draw` is the evidence that the probe ranks "
+                         "placements as the kernel does, DESIGN.md 5.1), 5 at N > 1 (a rank's slab is placed by a scan through slack)")
     ap.add_argument("--placement-evidence", type=int, default=3,
-                    help="N = 1: after the timed steps, this many plain allocations alive together (the headline's buffer among them) "
-                         "are each probed with gort_lut_alloc's store-pattern probe and written by 2 steps of the kernel: `per_draw`")
+                    help="N = 1: before the headline's buffer is allocated, this many plain allocations alive together (the first "
+                         "draw's buffer among them) are each probed with gort_lut_alloc's store-pattern probe and written by 1 + 3 "
+                         "steps of the kernel: `per_draw`")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")
     ap.add_argument("--sustain-s", type=float, default=3.0,
                     help="after the timed region, keep stepping for this many seconds and report the mean step ('sustained'); 0 = off")
@@ -484,7 +486,7 @@ def main():
     from gort_amd import api
 
     if args.lut_draws is None:
-        args.lut_draws = 1 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 5
+        args.lut_draws = 3 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 5
     if args.configs_only:
         torch.cuda.set_device(0)
         api.set_device(0)
@@ -597,6 +599,28 @@ def main():
     # ---- (1) a plain first allocation, timed exactly like the record: what hipMalloc's first answer is worth ----
     first = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1)
     fd_dt, fd_kernel = timed_steps(first.at(window[0]), args.warmup, args.steps)
+    # ---- (1b) N = 1: does the allocator's probe rank placements the way the kernel does?  Plain
+    #           allocations alive together - the first draw's buffer is draw 0 - each probed with gort_lut_alloc's own
+    #           store-pattern probe and then written by 1 + 3 steps of the real kernel.  All of them are freed before the
+    #           headline's buffer is allocated (by gort_lut_alloc, which holds at most --lut-draws candidates itself) ----
+    per_draw, peak_used_gb = None, None
+    if world == 1 and args.placement_evidence > 0 and r1 > r0:
+        held, per_draw = [first], []
+        win_bytes = window[1] * 8
+        for i in range(min(args.placement_evidence, 4)):
+            if i > 0:
+                free_b, total_b = torch.cuda.mem_get_info()
+                if free_b < buf_rows * row_elems * 8 + (64 << 30):          # >= 64 GB stay free beside the draws
+                    break
+                held.append(eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1))
+            b = held[i]
+            probe = eng.probe_store_pattern(b.at(window[0]), win_bytes)
+            _, k3 = timed_steps(b.at(window[0]), 1, 3)
+            free_b, total_b = torch.cuda.mem_get_info()
+            peak_used_gb = max(peak_used_gb or 0.0, (total_b - free_b) / 1e9)
+            per_draw.append({"probe_gbs": probe, "kernel_ms": k3})
+        for b in held[1:]:
+            b.free()
     first.free()
     # ---- (2) the product allocator of the C ABI (gort_lut_alloc: best of <= --lut-draws placements by a store-pattern
     #          probe of the window this rank writes); the number of record is measured on its buffer ----
@@ -618,29 +642,6 @@ def main():
     hbm = {"lut_buffer_gb": buf_rows * row_elems * 8 / 1e9, "placement_slack_gb": buf.placement["slack_bytes"] / 1e9,
            "device_used_gb_with_lut": (total_b - free_b) / 1e9, "device_total_gb": total_b / 1e9}
     dt, kernel_ms = timed_steps(lut_ptr, args.warmup, args.steps)
-    # ---- (3) N = 1: does the allocator's probe rank placements the way the kernel does?  Plain
-    #          allocations alive together - the headline's buffer is draw 0 - each probed with gort_lut_alloc's own
-    #          store-pattern probe and then written by 1 + 2 steps of the real kernel (after the timed steps: the probe
-    #          destroys the contents, the parity checks below recompute what they compare) ----
-    per_draw, peak_used_gb = None, None
-    if world == 1 and args.placement_evidence > 0 and r1 > r0:
-        held, per_draw = [buf], []
-        win_bytes = window[1] * 8
-        for i in range(min(args.placement_evidence, 4)):
-            if i > 0:
-                free_b, total_b = torch.cuda.mem_get_info()
-                if free_b < buf_rows * row_elems * 8 + (64 << 30):          # >= 64 GB stay free beside the draws
-                    break
-                held.append(eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1))
-            b = held[i]
-            probe = eng.probe_store_pattern(b.at(window[0]), win_bytes)
-            _, k2 = timed_steps(b.at(window[0]), 1, 2)
-            free_b, total_b = torch.cuda.mem_get_info()
-            peak_used_gb = max(peak_used_gb or 0.0, (total_b - free_b) / 1e9)
-            per_draw.append({"probe_gbs": probe, "kernel_ms": k2})
-        for b in held[1:]:
-            b.free()
-        timed_steps(lut_ptr, 1, 0)                 # the headline's buffer holds the LUT again (parity reads it)
 
     # ---- sustained rate: the same step back to back for >= --sustain-s seconds (clocks and power settled) ----
     dt, kernel_ms_max, fd_dt, fd_kernel_max = reduce_max([dt, kernel_ms, fd_dt, fd_kernel])
@@ -783,14 +784,15 @@ def main():
                                    "computes into its window of ONE gatherable LUT buffer (%d rows, %.1f GB per GPU)"
                                    % (world, buf_rows, buf_rows * row_elems * 8 / 1e9),
                        "allocation": ("gort_lut_alloc, max_draws %d: " % args.lut_draws) +
-                                     ("a plain allocation (the placement selection is not used for the headline at N = 1; `per_draw` "
-                                      "shows what it would have chosen from)" if args.lut_draws == 1 else
-                                      "the placement of the rank's window is measured; first_draw = plain allocation, same steps")},
+                                     ("a plain allocation" if args.lut_draws == 1 else
+                                      "the placement of the rank's window is measured (the C ABI's allocator); first_draw = a plain "
+                                      "allocation, same steps; per_draw = probe and kernel time on plain allocations side by side")},
             "per_draw": per_draw,
             "per_draw_what": None if per_draw is None else
-                             "plain allocations alive together (peak %.0f GB of the device in use), draw 0 = the headline's buffer: "
-                             "gort_lut_alloc's store-pattern probe of each, then 1 + 2 steps of the real kernel on it (HIP events around "
-                             "the 2; a buffer's first steps run ~4 %% slower than its twentieth)" % peak_used_gb,
+                             "plain allocations alive together (peak %.0f GB of the device in use), draw 0 = first_draw's buffer: "
+                             "gort_lut_alloc's store-pattern probe of each, then 1 + 3 steps of the real kernel on it (HIP events around "
+                             "the 3; a buffer's first steps run a few %% slower than its twentieth).  The headline's buffer is "
+                             "allocated afterwards by gort_lut_alloc(max_draws %d), which ranks its own candidates by that probe" % (peak_used_gb, args.lut_draws),
             "first_draw": {"value": total_samples * args.steps / fd_dt, "ms_per_step": fd_dt / args.steps * 1e3,
                            "kernel_ms_slowest_rank": fd_kernel_max,
                            "what": "the same warm-up + steps on a plain first allocation (gort_lut_alloc with max_draws 1), max over ranks"},

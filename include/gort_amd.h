@@ -164,8 +164,9 @@ int   gort_memcpy_d2h(void *dst, const void *src_dev, size_t bytes);
  *   - else: up to min(max_draws, 5) separate allocations, alive together as far as the device keeps 64 GiB free beside
  *     them, the rest freed (on some boxes every second 50 GB allocation runs the LUT kernel 11 % slower than the others,
  *     for its whole life; the probe tells them apart: profiles/r04/placement_select.log).  Whether that is worth holding
- *     several buffers for a moment is the caller's call: bench.py measures its headline on max_draws = 1 and reports the
- *     probe and the kernel's time on three draws beside it (`per_draw`).
+ *     several buffers for a moment is the caller's call: bench.py asks for three and reports, beside its headline, the
+ *     probe and the kernel's time on three plain allocations (`per_draw`) and the same steps on a plain first allocation
+ *     (`first_draw`): DESIGN.md 5.1.
  * It stops early at 0.985 x the best rate this engine has measured for the size class.  Windows below 1 GiB and
  * max_draws = 1 are plain allocations.  Contents are undefined.  Release with gort_lut_free.
  * New surface (the reference keeps ONE row of nw doubles, malloc in main(): gortt.c:188). */
