@@ -234,6 +234,7 @@ def test_indexed_rows_equal_the_dense_output_bitwise(nw, n):
     if n_rows > 2:
         rows2 = torch.full((n_rows - 1, nw, 3), -7.0, dtype=torch.float64, device="cuda")
         guard = torch.full((4 * nw,), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()                 # torch fills on its stream, the engine writes on its own
         e.energy_stream_indexed_dev(a, rows2[:n_rows - 2], index, count)
         e.synchronize()
         assert int(count[0]) == n_rows and float(rows2[n_rows - 2].max()) == -7.0 and float(guard.max()) == -7.0
