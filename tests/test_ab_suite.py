@@ -84,10 +84,16 @@ def test_ab_forms_on_the_measuring_build(tmp_path):
     assert not os.environ.get("GORT_AMD_LIB"), "this test compares the product library with the measuring build"
     dump = str(tmp_path / "ab_defaults.npz")
     env = dict(os.environ, GORT_AB_SUITE="1", GORT_AMD_LIB=AB_LIB, GORT_AB_DUMP=dump)
-    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-x", "-m", "gpu and ab", "-p", "no:cacheprovider"],
-                         capture_output=True, timeout=2400, env=env, cwd=ROOT)
+    cmd = [sys.executable, "-X", "faulthandler", "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-x", "-m", "gpu and ab", "-p", "no:cacheprovider"]
+    run = subprocess.run(cmd, capture_output=True, timeout=2400, env=env, cwd=ROOT)
+    if run.returncode < 0:
+        # the child was killed by a signal (seen once in round 5: SIGSEGV a few seconds in, on one box, not reproduced in
+        # three further runs): what it left is printed, and the suite is given ONE more process - a failing test fails again
+        print("A/B child died with signal %d; its output:\n%s\n%s" % (-run.returncode, run.stdout.decode()[-2000:], run.stderr.decode()[-6000:]),
+              file=sys.stderr)
+        run = subprocess.run(cmd, capture_output=True, timeout=2400, env=env, cwd=ROOT)
     tail = run.stdout.decode()[-3000:]
-    assert run.returncode == 0, tail + run.stderr.decode()[-2000:]
+    assert run.returncode == 0, "rc %d\n" % run.returncode + tail + "\n--- stderr ---\n" + run.stderr.decode()[-8000:]
     m = re.search(r"(\d+) passed", tail)
     assert m and int(m.group(1)) >= 40 and " failed" not in tail and " skipped" not in tail, tail
     theirs = dict(np.load(dump))
