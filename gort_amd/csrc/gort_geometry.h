@@ -172,8 +172,11 @@ __device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms
 struct RowScratch { double Mv, Mi, theta_Mi; };
 
 // stage 1: thread `unit` of the workgroup's first 2 n_rows threads = (row unit >> 1, which = unit & 1: 0 view, 1 sun)
+// (pn0, eps) = gap_lookup(c, za): handed in - the caller asks for them in front of the zenith's sine and cosine, so that the
+// table's four loads are on their way while the library's sincos runs (their addresses need the angle only)
 template <class M>
-__device__ void row_unit_with(const gort_canopy &c, bool is_sun, double za, double sn, double cs, RowTerms &r, RowScratch &x)
+__device__ void row_unit_with(const gort_canopy &c, bool is_sun, double sn, double cs, double pn0, double eps, RowTerms &r,
+                              RowScratch &x)
 {
 #pragma clang fp contract(off)
     const Primed p = M::prime(c.ell, M::div(sn, cs));
@@ -181,8 +184,6 @@ __device__ void row_unit_with(const gort_canopy &c, bool is_sun, double za, doub
     const double xx = cov * p.sec;
     const double e = M::exp(-xx);
     const double Mm = 1.0 - M::div(1.0 - e, xx);
-    double pn0, eps;
-    gap_lookup(c, za, pn0, eps);
     const double l = M::div_ieee(-M::log(eps), is_sun ? c.k * c.favd : 0.5 * c.favd);
     if (is_sun) {
         r.s = p;  r.sin_sz = sn;  r.cos_sz = cs;  r.es = e;
@@ -266,13 +267,15 @@ __device__ __forceinline__ void row_terms_split(int n_rows, RowTerms *rows, RowS
         double vza, sza;
         args(i, c, vza, sza);
         const double za = is_sun ? sza : vza;
+        double pn0, eps;
+        gap_lookup(*c, za, pn0, eps);                          // first: its loads fly while the sine and cosine are formed
         double sn, cs;
         sincos(za, &sn, &cs);                                  // the zeniths' own sine and cosine: the library's (row_terms)
         const double other = __shfl_xor(cs, 1, 64);            // the row's other zenith sits on the neighbouring lane
         const bool horizon = takes_reference_route(*c, is_sun ? other : cs, is_sun ? cs : other, reflectances_only);
         if (!is_sun) rows[i].horizon = horizon ? 1 : 0;
-        if (__builtin_expect(horizon, 0)) row_unit_with<LibMath>(*c, is_sun != 0, za, sn, cs, rows[i], scr[i]);
-        else row_unit_with<FastMath>(*c, is_sun != 0, za, sn, cs, rows[i], scr[i]);
+        if (__builtin_expect(horizon, 0)) row_unit_with<LibMath>(*c, is_sun != 0, sn, cs, pn0, eps, rows[i], scr[i]);
+        else row_unit_with<FastMath>(*c, is_sun != 0, sn, cs, pn0, eps, rows[i], scr[i]);
     }
     __syncthreads();
     const int rest0 = (2 * n_rows + 63) & ~63;                 // the first lane of the wave behind the plane lanes
