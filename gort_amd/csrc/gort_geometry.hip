@@ -283,9 +283,35 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
     GORT_STAMPS_END(geometry, (long)blockIdx.x * 4 + (threadIdx.x >> 6), (threadIdx.x & 63) == 0);
 }
 
+// the nodes of LUT rows as the angle lines a user would stream for them, "vza phi sza 0" (SURVEY 8d, C3): rows
+// [row_first, row_first + n_rows) of ONE member's grid, node-major.  What grids of 9 ... 127 bands are evaluated from (gort_api.hip)
+__global__ __launch_bounds__(256) void grid_lines_kernel(gort_grid g, long row_first, long n_lines, double *__restrict__ angles)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_lines) return;
+    const long r = idx / g.nphi;
+    const int l = (int)(idx - r * g.nphi);
+    const long row = row_first + r;
+    const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
+    double *a = angles + 4 * idx;
+    a[0] = g.vza0 + ivza * g.dvza;
+    a[1] = g.phi0 + l * g.dphi;
+    a[2] = g.sza0 + isza * g.dsza;
+    a[3] = 0.0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------- launchers
+
+int launch_grid_lines(const gort_grid &g, long row_first, long n_rows, double *angles_dev, void *stream)
+{
+    const long n = n_rows * g.nphi;
+    if (n <= 0) return GORT_OK;
+    if ((n + 255) / 256 >= (1L << 31)) return fail(GORT_EINVAL, "grid lines: %ld nodes in one launch", n);
+    hipLaunchKernelGGL(grid_lines_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, row_first, n, angles_dev);
+    return check_launch("grid_lines_kernel");
+}
 
 // n_members > 1: blockIdx.z = member, canopy_dev[m], records coef_dev[m][nA][16], proportions K_dev[m][nA][4]
 int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const double *angles_dev, long nA,

@@ -69,6 +69,7 @@ inline size_t stream_band_table_offset(int nw, int n_members)            // in d
 {
     return ((size_t)L_NSLOT * n_members * (size_t)nw + 1) & ~(size_t)1;
 }
+constexpr int STREAM_BAND_TABLE_DOUBLES = 12;      // per band: sizeof(StreamBand) / sizeof(double) (gort_device.h asserts it)
 inline size_t lambda_table_doubles(int nw, int n_members) { return stream_band_table_offset(nw, n_members) + (size_t)12 * nw; }
 inline const double *stream_band_table(const double *L_dev, int nw, int n_members)
 {
@@ -149,8 +150,13 @@ int launch_expand_grid_members(const gort_canopy *canopies_dev, const double *L_
 // ---- streams of 17 ... ~250 bands without component spectra (gort_stream_lines.hip): geometry and samples in one kernel,
 // lanes = lines, rows leave LDS as whole 128-B lines whatever the band count; band_table_dev as above
 bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp);
-int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_dev, int nw, const double *angles_dev, long nA,
-                        double *rsurf_dev, double *K_dev, void *stream);
+// n_members > 1: the same lines for canopy_dev[m] with band_table_dev[m][nw][12], rows rsurf_dev[m][nA][nw] (K_dev null)
+int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const double *band_table_dev, int nw, const double *angles_dev,
+                        long nA, double *rsurf_dev, double *K_dev, void *stream);
+// StreamBand tables of n_members members from their band tables L_dev[m][L_NSLOT][nw]: bands_dev[m][nw][12]
+int launch_member_stream_bands(const double *L_dev, int n_members, int nw, double *bands_dev, void *stream);
+// the nodes of n_rows LUT rows of one member's grid, from row row_first, as angle lines "vza phi sza 0": angles_dev[n_rows * nphi][4]
+int launch_grid_lines(const gort_grid &g, long row_first, long n_rows, double *angles_dev, void *stream);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);

@@ -1366,8 +1366,9 @@ def test_ensemble_members_one_launch(golden):
 @pytest.mark.parametrize("nw", [1, 7, 8, 9, 16, 100, 127])
 def test_member_grids_of_any_band_count(golden, nw):
     """gort_rsurf_members_grid_dev below 128 bands (the MODIS-style ensemble the reference's README.md:8-9 names): up to 8
-    bands the fused node kernel with every row's own member, 9 ... 127 bands records + one thread per sample with the member
-    in blockIdx.z.  32 members in one call == 32 single-canopy runs, bit for bit; the first 8 against the reference's own
+    bands the fused node kernel with every row's own member; 9 ... 127 bands the stream kernels on the nodes written out as
+    angle lines (the fused stream kernel to 16 bands, the line kernel with the member in blockIdx.y beyond; small grids: records
+    + one thread per sample with the member in blockIdx.z).  32 members in one call == 32 single-canopy runs, bit for bit; the first 8 against the reference's own
     runs of those members (tests/golden/c5_members.npz) at the bands picked; a member sub-range; a mirrored full circle."""
     import torch
     g, canopies, leaf = _members(golden)
@@ -1380,7 +1381,9 @@ def test_member_grids_of_any_band_count(golden, nw):
     e = api.Engine()
     e.set_members(members, sp)
     single = api.Engine()
-    for grid in (_grid((30.0, 1.0, 1), (0.0, 45.0, 3), (0.0, 90.0, 4)), _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 10.0, 37))):
+    # the third grid is big enough for the line kernel (17 ... 127 bands: the nodes go through the stream kernels as angle lines)
+    for grid in (_grid((30.0, 1.0, 1), (0.0, 45.0, 3), (0.0, 90.0, 4)), _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 10.0, 37)),
+                 _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 1.0, 361))):
         rows, nodes = grid.nsza * grid.nvza, grid.nsza * grid.nvza * grid.nphi
         lut = torch.full((n * nodes * nw + 16,), -7.0, dtype=torch.float64, device="cuda")
         e.rsurf_members_grid_dev(grid, 0, n, lut)

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Hemisphere LUT at band counts below the LUT kernel's 128: which path, how fast (single canopy)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+from gort_amd import api
+eng = api.Engine(); eng.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
+g = api.hemisphere_grid(); rows = g.nsza * g.nvza
+for nw in (1, 7, 8, 9, 16, 32, 64, 100, 127, 128, 200):
+    eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
+    lut = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        eng.rsurf_grid_dev(g, 0, rows, lut); eng.synchronize()
+    ts = []
+    for _ in range(7):
+        t0 = time.perf_counter(); eng.rsurf_grid_dev(g, 0, rows, lut); eng.synchronize(); ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    print("hemisphere x %4d bands: %9.1f us  %.3e samples/s  %6.0f GB/s" % (nw, t * 1e6, rows * g.nphi * nw / t, rows * g.nphi * nw * 8 / t / 1e9), flush=True)
+    del lut
