@@ -216,7 +216,7 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
     // everything this thread reads of the node table, in front of the prefetch (the load counter is in order: a wait for a node
     // behind the band constants would be a wait for the band constants); my_row = the row this thread serves in row_terms_split()
     const double node_vaa = nodes[3 * tid], w = nodes[3 * tid + 2];
-    const int my_row = tid < 2 * ENERGY_ZENITH_NODES ? tid >> 1 : (tid - 64) & (ENERGY_ZENITH_NODES - 1);
+    const int my_row = tid < 2 * ENERGY_ZENITH_NODES ? tid >> 1 : ((tid - 64) >> 1) & (ENERGY_ZENITH_NODES - 1);
     const double row_vza = nodes[3 * my_row + 1], node_vza = nodes[3 * tid + 1];
     BandTerms ahead;
     if (PREFETCH) ahead = load_band(L, nw, band_begin + tid < band_end ? band_begin + tid : band_begin);
@@ -233,10 +233,10 @@ __device__ __forceinline__ void energy_line(const gort_canopy &c, const double *
         // reflectances only leave this kernel (gort_geometry.h, row_terms: the 90-degree sun of BASELINE config 4 walked the
         // reference's route for 8.8 us where the other lines' row terms take 4.5, and a launch ends with its longest line)
         // split over lanes (gort_geometry.h, row_terms_split: the same numbers as row_terms())
-        row_terms_split(ENERGY_ZENITH_NODES, sh.row, sh.scr, true, [&](int, const gort_canopy *&ci, double &vz, double &sz) {
+        row_terms_split(ENERGY_ZENITH_NODES, sh.row, sh.scr, true, [&](int i, const gort_canopy *&ci, double &vz, double &sz) {
             ci = &c;
-            vz = row_vza;                                    // asked for row my_row only
-            sz = sza;
+            vz = i == my_row ? row_vza : node_vza;           // (asked for my_row, or - the first sixteen threads - for row tid:
+            sz = sza;                                        //  node tid's zenith is row tid's)
         });
         GORT_STAMP(1);                                       // row terms
         finish_angle(c, sh.row[tid & (ENERGY_ZENITH_NODES - 1)], raa, g);

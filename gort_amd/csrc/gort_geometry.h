@@ -163,56 +163,85 @@ __device__ void row_terms(const gort_canopy &c, double vza, double sza, RowTerms
 // the workgroup waits at the barrier: 2.5 us (hemisphere grid) to 4.5 us (albedo line) at the front of every workgroup with
 // the SIMDs a quarter busy.  But the chain is three chains that do not need each other ("Mi, theta_Mi on theta_s;
 // Mv, theta_Mv on theta_v"; gortt_brdf.c:118-238):
-//   stage 1, a lane per (row, zenith): the zenith's primed angle, its gap-table lookup, exp(-cov sec), M and the path length
-//            of Kuusk's hot spot - the view zenith's on one lane, the sun zenith's (with theta_Mi) on its neighbour;
-//   stage 2, a lane per (row, principal-plane azimuth 0 | pi): overlap, Kg and f F there - and meanwhile, on the lanes of
-//            ANOTHER wave (other issue slots), a lane per row: the sun's fd and t0, beta, and the hot spot's sqrt(ls lv).
-// The longest path is ~650 instructions.  Every number is formed by the expression row_terms_with() forms it by, from the
+//   stage 1, a lane per (row, zenith): the zenith's sine and cosine, its gap-table lookup and its primed angle - the view
+//            zenith's on one lane, the sun zenith's on its neighbour;
+//   stage 2, the same lanes: exp(-cov sec), M, the path length of Kuusk's hot spot, the sun's theta_Mi - while the lanes of
+//            ANOTHER wave (other issue slots), a lane per (row, principal-plane azimuth 0 | pi), form the overlap and Kg there,
+//            which need the primed angles only;
+//   stage 3, those lanes: f F on the principal plane - while a lane per row on the first wave forms the sun's fd and t0, beta,
+//            and the hot spot's sqrt(ls lv).
+// The longest path is ~450 instructions (~650 with two stages, round 5's first form).  Every number is formed by the expression row_terms_with() forms it by, from the
 // same operands (contraction off in both): the same bits (tests/test_grid_forms.py, tests/test_energy_forms.py).
-struct RowScratch { double Mv, Mi, theta_Mi; };
+struct RowScratch { double Mv, Mi, theta_Mi, O[2], Kg[2]; };
 
-// stage 1: thread `unit` of the workgroup's first 2 n_rows threads = (row unit >> 1, which = unit & 1: 0 view, 1 sun)
-// (pn0, eps) = gap_lookup(c, za): handed in - the caller asks for them in front of the zenith's sine and cosine, so that the
-// table's four loads are on their way while the library's sincos runs (their addresses need the angle only)
+// stage 1, thread `unit` of the workgroup's first 2 n_rows threads = (row unit >> 1, which = unit & 1: 0 view, 1 sun): the
+// zenith's primed angle (and what needs nothing else of it).  (pn0, eps) = gap_lookup(c, za): handed in - the caller asks for
+// them in front of the zenith's sine and cosine, so that the table's four loads are on their way while the library's sincos runs
 template <class M>
-__device__ void row_unit_with(const gort_canopy &c, bool is_sun, double sn, double cs, double pn0, double eps, RowTerms &r,
-                              RowScratch &x)
+__device__ void row_prime_with(const gort_canopy &c, bool is_sun, double sn, double cs, double pn0, double eps, RowTerms &r)
 {
 #pragma clang fp contract(off)
     const Primed p = M::prime(c.ell, M::div(sn, cs));
+    if (is_sun) {
+        r.s = p;  r.sin_sz = sn;  r.cos_sz = cs;
+        r.sun.pn0 = pn0;  r.sun.eps = eps;  r.eps_s = eps;
+    } else {
+        r.v = p;  r.sin_vz = sn;  r.cos_vz = cs;
+        r.Gv = PI * c.rr * p.sec;
+        r.eps_v = eps;
+    }
+}
+
+// stage 2 on the same threads: what else belongs to one zenith - exp(-cov sec), M, the hot spot's path length, the sun's theta_Mi
+template <class M>
+__device__ void row_unit_with(const gort_canopy &c, bool is_sun, RowTerms &r, RowScratch &x)
+{
+#pragma clang fp contract(off)
+    const Primed p = is_sun ? r.s : r.v;
+    const double eps = is_sun ? r.eps_s : r.eps_v;
     const double cov = c.lambda * PI * c.rr;
     const double xx = cov * p.sec;
     const double e = M::exp(-xx);
     const double Mm = 1.0 - M::div(1.0 - e, xx);
     const double l = M::div_ieee(-M::log(eps), is_sun ? c.k * c.favd : 0.5 * c.favd);
     if (is_sun) {
-        r.s = p;  r.sin_sz = sn;  r.cos_sz = cs;  r.es = e;
-        r.sun.pn0 = pn0;  r.sun.eps = eps;  r.eps_s = eps;
+        r.es = e;
         r.kf = c.k * c.favd;
         r.ls = l;
         x.Mi = Mm;
         x.theta_Mi = M::acos(1.0 - 2.0 * Mm);
     } else {
-        r.v = p;  r.sin_vz = sn;  r.cos_vz = cs;  r.ev = e;
-        r.Gv = PI * c.rr * p.sec;
-        r.eps_v = eps;
+        r.ev = e;
         r.lv = l;
         x.Mv = Mm;
     }
 }
 
-// stage 2, lane (row, q): f F on the principal plane at phi = 0 (q = 0) or pi (q = 1)
+// stage 2 on the threads of another wave, lane (row, q): the overlap on the principal plane at phi = 0 (q = 0) or pi (q = 1)
+// and Kg there - they need the two primed angles and nothing else
 template <class M>
-__device__ void row_plane_with(const gort_canopy &c, int q, double vza, double sza, RowTerms &r, const RowScratch &x)
+__device__ void row_overlap_with(const gort_canopy &c, int q, RowTerms &r, RowScratch &x)
 {
 #pragma clang fp contract(off)
     const Primed v = r.v, s = r.s;
     const double cov = c.lambda * PI * c.rr;
     const double hb = M::div(c.h, c.b);
     const double t1 = s.sec + v.sec;
-    const double cphi = q ? -1.0 : 1.0;
     const double Oq = q ? overlap<M, true>(hb, s, v, -1.0, 1.2246467991473532e-16) : overlap<M, true>(hb, s, v, 1.0, 0.0);
-    const double Kgq = M::exp(-(cov * (t1 - Oq)));
+    x.O[q] = Oq;
+    x.Kg[q] = M::exp(-(cov * (t1 - Oq)));
+    if (q == 0) { r.cov = cov;  r.hb = hb;  r.t1 = t1; }
+}
+
+// stage 3 on those threads: f F on the principal plane from everything above
+template <class M>
+__device__ void row_plane_with(const gort_canopy &c, int q, double vza, double sza, RowTerms &r, const RowScratch &x)
+{
+#pragma clang fp contract(off)
+    const Primed v = r.v, s = r.s;
+    const double t1 = s.sec + v.sec;
+    const double cphi = q ? -1.0 : 1.0;
+    const double Oq = x.O[q], Kgq = x.Kg[q];
     const double Gv = r.Gv;
     const bool view_steeper = fabs(vza) > fabs(sza);
     const double ph = v.c * s.c + v.s * s.s * cphi;
@@ -224,15 +253,11 @@ __device__ void row_plane_with(const gort_canopy &c, int q, double vza, double s
     const double PvMv = x.Mv - (1.0 - M::cos_of_difference(v, s, cphi, ph)) / 2.0;
     const double Po = (q == 1) ? PvMv : (view_steeper ? PiMi : PvMv);
     const double f = M::div(F * (1.0 - M::div(Gv * (PvMv + PiMi - Po), Gc)), 1.0 - Mq);
-    if (q) {
-        r.fFpi = f * F;
-    } else {
-        r.fF0 = f * F;
-        r.cov = cov;  r.hb = hb;  r.t1 = t1;
-    }
+    if (q) r.fFpi = f * F;
+    else r.fF0 = f * F;
 }
 
-// stage 2, a lane per row on another wave: what is left of the sun scalars, beta, the hot spot's sqrt(ls lv)
+// stage 3, a lane per row on the first wave again: what is left of the sun scalars, beta, the hot spot's sqrt(ls lv)
 template <class M>
 __device__ void row_rest_with(const gort_canopy &c, RowTerms &r)
 {
@@ -255,17 +280,23 @@ __device__ void row_rest_with(const gort_canopy &c, RowTerms &r)
     r.h1 = (r.ls * r.lv) > 0.0 ? M::sqrt(r.ls * r.lv) : 0.0;
 }
 
-// All threads of the workgroup call this (two barriers inside); rows[i], scr[i] in LDS for i < n_rows; args(i, c, vza, sza)
-// names row i's canopy and its two normalised zeniths.  blockDim.x >= roundup64(2 n_rows) + n_rows.
+// All threads of the workgroup call this (three barriers inside); rows[i], scr[i] in LDS for i < n_rows; args(i, c, vza, sza)
+// names row i's canopy and its two normalised zeniths.  With U = 2 n_rows and P = U rounded up to whole waves:
+//   stage 1  threads [0, U): primed angles;   stage 2  [0, U): the zeniths' other terms  |  [P, P + U): overlap and Kg;
+//   stage 3  [P, P + U): f F                  |  [0, n_rows): the rest.       blockDim.x >= P + U.
 template <class RowArgs>
 __device__ __forceinline__ void row_terms_split(int n_rows, RowTerms *rows, RowScratch *scr, bool reflectances_only, RowArgs args)
 {
     const int tid = threadIdx.x;
-    if (tid < 2 * n_rows) {
-        const int i = tid >> 1, is_sun = tid & 1;
-        const gort_canopy *c;
-        double vza, sza;
-        args(i, c, vza, sza);
+    const int U = 2 * n_rows, P = (U + 63) & ~63;
+    const gort_canopy *c = nullptr;
+    double vza = 0.0, sza = 0.0;
+    int i = -1;
+    if (tid < U) i = tid >> 1;
+    else if (tid >= P && tid < P + U) i = (tid - P) >> 1;
+    if (i >= 0) args(i, c, vza, sza);
+    if (tid < U) {
+        const int is_sun = tid & 1;
         const double za = is_sun ? sza : vza;
         double pn0, eps;
         gap_lookup(*c, za, pn0, eps);                          // first: its loads fly while the sine and cosine are formed
@@ -274,25 +305,27 @@ __device__ __forceinline__ void row_terms_split(int n_rows, RowTerms *rows, RowS
         const double other = __shfl_xor(cs, 1, 64);            // the row's other zenith sits on the neighbouring lane
         const bool horizon = takes_reference_route(*c, is_sun ? other : cs, is_sun ? cs : other, reflectances_only);
         if (!is_sun) rows[i].horizon = horizon ? 1 : 0;
-        if (__builtin_expect(horizon, 0)) row_unit_with<LibMath>(*c, is_sun != 0, sn, cs, pn0, eps, rows[i], scr[i]);
-        else row_unit_with<FastMath>(*c, is_sun != 0, sn, cs, pn0, eps, rows[i], scr[i]);
+        if (__builtin_expect(horizon, 0)) row_prime_with<LibMath>(*c, is_sun != 0, sn, cs, pn0, eps, rows[i]);
+        else row_prime_with<FastMath>(*c, is_sun != 0, sn, cs, pn0, eps, rows[i]);
     }
     __syncthreads();
-    const int rest0 = (2 * n_rows + 63) & ~63;                 // the first lane of the wave behind the plane lanes
-    if (tid < 2 * n_rows) {
-        const int i = tid >> 1;
-        const gort_canopy *c;
-        double vza, sza;
-        args(i, c, vza, sza);
-        if (__builtin_expect(rows[i].horizon, 0)) row_plane_with<LibMath>(*c, tid & 1, vza, sza, rows[i], scr[i]);
-        else row_plane_with<FastMath>(*c, tid & 1, vza, sza, rows[i], scr[i]);
-    } else if (tid >= rest0 && tid < rest0 + n_rows) {
-        const int i = tid - rest0;
-        const gort_canopy *c;
-        double vza, sza;
-        args(i, c, vza, sza);
-        if (__builtin_expect(rows[i].horizon, 0)) row_rest_with<LibMath>(*c, rows[i]);
-        else row_rest_with<FastMath>(*c, rows[i]);
+    if (tid < U) {
+        if (__builtin_expect(rows[i].horizon, 0)) row_unit_with<LibMath>(*c, (tid & 1) != 0, rows[i], scr[i]);
+        else row_unit_with<FastMath>(*c, (tid & 1) != 0, rows[i], scr[i]);
+    } else if (i >= 0) {
+        if (__builtin_expect(rows[i].horizon, 0)) row_overlap_with<LibMath>(*c, (tid - P) & 1, rows[i], scr[i]);
+        else row_overlap_with<FastMath>(*c, (tid - P) & 1, rows[i], scr[i]);
+    }
+    __syncthreads();
+    if (tid >= P && i >= 0) {
+        if (__builtin_expect(rows[i].horizon, 0)) row_plane_with<LibMath>(*c, (tid - P) & 1, vza, sza, rows[i], scr[i]);
+        else row_plane_with<FastMath>(*c, (tid - P) & 1, vza, sza, rows[i], scr[i]);
+    } else if (tid < n_rows) {
+        const gort_canopy *cr;
+        double vz, sz;
+        args(tid, cr, vz, sz);
+        if (__builtin_expect(rows[tid].horizon, 0)) row_rest_with<LibMath>(*cr, rows[tid]);
+        else row_rest_with<FastMath>(*cr, rows[tid]);
     }
     __syncthreads();
 }
