@@ -196,22 +196,29 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         }
     };
 
-    // ---- band block 0: its 16 samples stay in registers as well (the row's head is among them)
+    // ---- band block 0: its 16 samples stay in registers as well (the row's head is among them).  Its band constants are
+    // requested a band ahead like those of every other block (left to the compiler each of the sixteen scalar loads sat directly
+    // in front of its wait: ~100 exposed cycles per band of the block)
     double head[BLOCK_BANDS];
+    BandRegs A, B;
+    band_request(A, bands);
 #pragma unroll
-    for (int i = 0; i < BLOCK_BANDS; ++i) {
-        const StreamBand b = bands[i];                         // wave-uniform: scalar loads
-        const double v = stream_sample(l, b);
-        head[i] = v;
-        my_ring[(pos + i) & (RING - 1)] = v;
+    for (int i = 0; i < BLOCK_BANDS; i += 2) {
+        band_wait(A);
+        band_request(B, bands + i + 1);                        // nw >= 17
+        if (i > 0) my_ring[(pos + i - 1) & (RING - 1)] = head[i - 1];
+        head[i] = stream_sample(l, band_of(A));
+        band_wait(B);
+        band_request(A, bands + i + 2);
+        my_ring[(pos + i) & (RING - 1)] = head[i];
+        head[i + 1] = stream_sample(l, band_of(B));
     }
     // the other blocks: the sample of a band is written to the ring one band later (its ds_write would otherwise sit
     // directly in front of the next wait, which counts LDS operations too)
     {
-        BandRegs A, B;
         int t = BLOCK_BANDS;
-        double vprev = head[BLOCK_BANDS - 1];                  // written again where it already is: harmless
-        band_request(A, bands + t);                            // nw >= 17
+        double vprev = head[BLOCK_BANDS - 1];                  // (block 0 left it to this loop's first write)
+        // A holds the request for band 16 already
         while (t < nw) {
             const int block_end = t + BLOCK_BANDS < nw ? t + BLOCK_BANDS : nw;
             while (t + 1 < block_end) {
