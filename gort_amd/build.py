@@ -59,6 +59,16 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+def _run_all(cmds, jobs=None):
+    """Independent compile commands, a few at a time (hipcc is one process per unit; the container has 8 cores and no swap)."""
+    if not cmds:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = jobs or max(1, min(4, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(jobs) as pool:
+        list(pool.map(_run, cmds))
+
+
 def build_variant(name, defines, force=True):
     """gort_amd/libgort_amd_<name>.so: the same sources with extra -D flags - a measuring build beside the product library,
     never loaded unless GORT_AMD_LIB names it (or the `ab` tests do).
@@ -72,13 +82,14 @@ def build_variant(name, defines, force=True):
     headers = sorted(glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(SRC, "*.h"))) + [os.path.abspath(__file__)]
     common = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"] + ["-D" + d for d in defines] + \
              ["-I" + os.path.join(ROOT, "include"), "-I" + SRC, "--offload-arch=" + ARCH]
-    objs = []
+    objs, todo = [], []
     for src, extra in UNITS:
         s = os.path.join(SRC, src)
         o = os.path.join(obj, os.path.splitext(src)[0] + ".o")
         if force or _newer(o, [s] + headers):
-            _run([cc] + common + extra + ["-c", s, "-o", o])
+            todo.append([cc] + common + extra + ["-c", s, "-o", o])
         objs.append(o)
+    _run_all(todo)
     lib = os.path.join(PKG, "libgort_amd_%s.so" % name)
     if force or _newer(lib, objs):
         _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", lib] + objs + ["-ldl"])
@@ -104,14 +115,15 @@ def build(force=False, verbose_resources=False):
               "-I" + SRC, "--offload-arch=" + ARCH]
     if verbose_resources:
         common.append("-Rpass-analysis=kernel-resource-usage")
-    objs = []
+    objs, todo = [], []
     for src, extra in UNITS:
         s = os.path.join(SRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         deps = [s] + headers + (data if src == "gort_host.cpp" else [])
         if force or _newer(o, deps):
-            _run([cc] + common + extra + ["-c", s, "-o", o])
+            todo.append([cc] + common + extra + ["-c", s, "-o", o])
         objs.append(o)
+    _run_all(todo)
     if force or _newer(LIB, objs):
         _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"])
     main = os.path.join(SRC, "gortt_main.cpp")
