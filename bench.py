@@ -788,6 +788,13 @@ def main():
                                       "the placement of the rank's window is measured (the C ABI's allocator); first_draw = a plain "
                                       "allocation, same steps; per_draw = probe and kernel time on plain allocations side by side")},
             "per_draw": per_draw,
+            # does the probe order the draws as the kernel does?  (the slowest-probing draw is the slowest-running one; null
+            # where the draws lie within 1 % of each other by both measures: nothing to order)
+            "per_draw_probe_orders_kernel": None if not per_draw or len(per_draw) < 2 or
+                (max(x["probe_gbs"] for x in per_draw) < 1.01 * min(x["probe_gbs"] for x in per_draw) and
+                 max(x["kernel_ms"] for x in per_draw) < 1.01 * min(x["kernel_ms"] for x in per_draw)) else
+                bool(min(range(len(per_draw)), key=lambda i: per_draw[i]["probe_gbs"]) ==
+                     max(range(len(per_draw)), key=lambda i: per_draw[i]["kernel_ms"])),
             "per_draw_what": None if per_draw is None else
                              "plain allocations alive together (peak %.0f GB of the device in use), draw 0 = first_draw's buffer: "
                              "gort_lut_alloc's store-pattern probe of each, then 1 + 3 steps of the real kernel on it (HIP events around "
