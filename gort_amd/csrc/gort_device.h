@@ -102,6 +102,9 @@ __device__ inline void sincos_of(double x, double &s, double &c)
 // rare, the branch is wave-uniform almost always, and its code is round 3's (which the goldens pinned).
 struct FastMath {
     static __device__ __forceinline__ double div(double a, double b) { return gm::quot_finite(a, b); }     // b finite, not 0
+    // div(a, b) with recip(b) formed ahead (a denominator shared by many quotients): the same bits as div(a, b)
+    static __device__ __forceinline__ double recip(double b) { return gm::recip(b); }
+    static __device__ __forceinline__ double div_with(double a, double b, double rb) { return gm::quot_finite_with(a, b, rb); }
     static __device__ __forceinline__ double div_ieee(double a, double b) { return gm::quot(a, b); }       // b = 0, inf as IEEE
     static __device__ __forceinline__ double sqrt(double x) { return gm::sqrt_(x); }
     static __device__ __forceinline__ double acos_unit(double x) { return gm::acos_unit(x); }
@@ -148,6 +151,8 @@ __device__ GORT_LIB_CALL double cos_call(double x) { return ::cos(x); }
 }  // namespace lib
 struct LibMath {
     static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double recip(double) { return 0.0; }                       // (IEEE division has no use for it)
+    static __device__ __forceinline__ double div_with(double a, double b, double) { return a / b; }
     static __device__ __forceinline__ double div_ieee(double a, double b) { return a / b; }
     static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
     static __device__ __forceinline__ double acos_unit(double x) { return lib::acos_call(x); }

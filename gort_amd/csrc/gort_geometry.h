@@ -16,16 +16,31 @@ namespace {
 // EXACTLY; an FMA leaves 1e-16 t^2 of product rounding in d, sqrt turns it into 1e-8 t, and Kc at 89/89 deg
 // moves by 3e-8.  All geometry below keeps plain IEEE multiply/add for the same reason.
 // M: the arithmetic (gort_device.h: FastMath for all lines but those at the horizon, LibMath there).
-template <class M, bool PRINCIPAL>
-__device__ inline double overlap(double hb, const Primed &s, const Primed &v, double cphi, double sphi)
+// What every overlap of one (view zenith, sun zenith) pair shares - the three of the row's terms and those of all its azimuth
+// nodes: the products of the primed tangents as overlap() had them inline, t1 = s.sec + v.sec and M::recip(t1)
+struct OverlapPair { double tt_sum, tt_2, tt_prod, t1, rcp_t1; };
+template <class M>
+__device__ __forceinline__ OverlapPair overlap_pair(const Primed &s, const Primed &v)
 {
 #pragma clang fp contract(off)
-    const double d = s.t * s.t + v.t * v.t - 2.0 * s.t * v.t * cphi;
+    OverlapPair p;
+    p.tt_sum = s.t * s.t + v.t * v.t;
+    p.tt_2 = 2.0 * s.t * v.t;
+    p.tt_prod = s.t * v.t;
+    p.t1 = s.sec + v.sec;
+    p.rcp_t1 = M::recip(p.t1);
+    return p;
+}
+template <class M, bool PRINCIPAL>
+__device__ inline double overlap(double hb, const OverlapPair &p, double cphi, double sphi)
+{
+#pragma clang fp contract(off)
+    const double d = p.tt_sum - p.tt_2 * cphi;            // s.t s.t + v.t v.t - 2.0 s.t v.t cphi
     const double D = M::sqrt(ref_max(0.0, d));
-    const double x = s.t * v.t * sphi;
+    const double x = p.tt_prod * sphi;
     const double t2 = PRINCIPAL ? M::hypot_principal(D, x) : M::sqrt(D * D + x * x);
-    const double t1 = s.sec + v.sec;
-    double cos_t = M::div(hb * t2, t1);
+    const double t1 = p.t1;
+    double cos_t = M::div_with(hb * t2, t1, p.rcp_t1);
     cos_t = ref_max(-1.0, cos_t);
     cos_t = ref_min(1.0, cos_t);
     const double t = M::acos_unit(cos_t);                 // hb, t2, t1 >= 0
@@ -46,9 +61,36 @@ struct RowTerms {
     double cov, hb, t1, es, ev, Gv;
     double fF0, fFpi, beta;
     double eps_s, eps_v, ls, lv, h1, kf;
+    // what a row's azimuth nodes would each form again (round 5): reciprocals of the denominators they share - t1 (overlap),
+    // the crown radius (hot spot), 2 cos(sza') cos(vza') (A) - and the row-only factors of Kuusk's term.  Formed by the
+    // expressions finish_angle_with() had inline, used through M::div_with(): the same bits.
+    OverlapPair op;
+    double rcp_r, den_A, rcp_den_A, q2_a, q2_b, kf_h1, eps_sv, half_Gv, cc, ss, czz, szz, one_m_beta, one_m_ev;
     SunScalars sun;
     int horizon;                           // the line takes the reference's route (LibMath)
 };
+
+// the row-only operands of finish_angle_with() (RowTerms: "what a row's azimuth nodes would each form again"); needs ls, lv, kf,
+// h1, eps_s, eps_v, Gv and the primed angles
+template <class M>
+__device__ __forceinline__ void row_node_invariants(const gort_canopy &c, RowTerms &r)
+{
+#pragma clang fp contract(off)
+    r.rcp_r = M::recip(c.r);
+    r.den_A = 2.0 * r.s.c * r.v.c;
+    r.rcp_den_A = M::recip(r.den_A);
+    r.q2_a = r.ls * r.ls + r.lv * r.lv;
+    r.q2_b = 2. * r.ls * r.lv;
+    r.kf_h1 = r.kf * r.h1;
+    r.eps_sv = r.eps_s * r.eps_v;
+    r.half_Gv = r.Gv * 0.5;
+    r.cc = r.v.c * r.s.c;
+    r.ss = r.v.s * r.s.s;
+    r.czz = r.cos_sz * r.cos_vz;
+    r.szz = r.sin_sz * r.sin_vz;
+    r.one_m_beta = 1.0 - r.beta;
+    r.one_m_ev = 1.0 - r.ev;
+}
 
 // Restates the azimuth-independent parts of gortt_kg/gortt_kc/gortt_kc_fFbeta (gortt_brdf.c:7-238),
 // gortt_set_zenith_dependant_probabilities (gortt.c:872-915) and gortt_kuusk (gortt_brdf.c:638-702).
@@ -63,12 +105,13 @@ __device__ void row_terms_with(const gort_canopy &c, double vza, double sza, Row
     const Primed &v = r.v, &s = r.s;
     r.cov = c.lambda * PI * c.rr;                         // lambda pi r^2
     r.hb = M::div(c.h, c.b);
-    r.t1 = s.sec + v.sec;
+    r.op = overlap_pair<M>(s, v);
+    r.t1 = r.op.t1;
     const double cov = r.cov, t1 = r.t1;
 
     // principal-plane overlaps (Kc is interpolated between phi = 0 and pi, gortt_brdf.c:143-159)
-    const double O_0 = overlap<M, true>(r.hb, s, v, 1.0, 0.0);
-    const double O_pi = overlap<M, true>(r.hb, s, v, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
+    const double O_0 = overlap<M, true>(r.hb, r.op, 1.0, 0.0);
+    const double O_pi = overlap<M, true>(r.hb, r.op, -1.0, 1.2246467991473532e-16);   // sin(M_PI) in double
     const double Kg0 = M::exp(-(cov * (t1 - O_0)));
     const double Kgpi = M::exp(-(cov * (t1 - O_pi)));
 
@@ -123,6 +166,7 @@ __device__ void row_terms_with(const gort_canopy &c, double vza, double sza, Row
     r.ls = M::div_ieee(-M::log(r.eps_s), r.kf);                // favd = 0 (-LAI 0): inf or NaN as the reference's
     r.lv = M::div_ieee(-M::log(r.eps_v), 0.5 * c.favd);
     r.h1 = (r.ls * r.lv) > 0.0 ? M::sqrt(r.ls * r.lv) : 0.0;
+    row_node_invariants<M>(c, r);
 }
 
 // The sine and cosine of the two ZENITHS are the device library's in both arithmetics.  In the exact hot-spot
@@ -226,11 +270,12 @@ __device__ void row_overlap_with(const gort_canopy &c, int q, RowTerms &r, RowSc
     const Primed v = r.v, s = r.s;
     const double cov = c.lambda * PI * c.rr;
     const double hb = M::div(c.h, c.b);
-    const double t1 = s.sec + v.sec;
-    const double Oq = q ? overlap<M, true>(hb, s, v, -1.0, 1.2246467991473532e-16) : overlap<M, true>(hb, s, v, 1.0, 0.0);
+    const OverlapPair op = overlap_pair<M>(s, v);
+    const double t1 = op.t1;
+    const double Oq = q ? overlap<M, true>(hb, op, -1.0, 1.2246467991473532e-16) : overlap<M, true>(hb, op, 1.0, 0.0);
     x.O[q] = Oq;
     x.Kg[q] = M::exp(-(cov * (t1 - Oq)));
-    if (q == 0) { r.cov = cov;  r.hb = hb;  r.t1 = t1; }
+    if (q == 0) { r.cov = cov;  r.hb = hb;  r.t1 = t1;  r.op = op; }
 }
 
 // stage 3 on those threads: f F on the principal plane from everything above
@@ -278,6 +323,7 @@ __device__ void row_rest_with(const gort_canopy &c, RowTerms &r)
         r.beta = M::div(lg, lg + dh) * M::div(1.0 - M::exp(-lg - dh), 1.0 - M::exp(-lg));
     }
     r.h1 = (r.ls * r.lv) > 0.0 ? M::sqrt(r.ls * r.lv) : 0.0;
+    row_node_invariants<M>(c, r);
 }
 
 // All threads of the workgroup call this (three barriers inside); rows[i], scr[i] in LDS for i < n_rows; args(i, c, vza, sza)
@@ -337,22 +383,21 @@ template <class M>
 __device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, double raa, double sin_r, double cos_r, GeomOut &o)
 {
 #pragma clang fp contract(off)
-    const Primed &v = r.v, &s = r.s;
-    const double O_r = overlap<M, false>(r.hb, s, v, cos_r, sin_r);
+    const double O_r = overlap<M, false>(r.hb, r.op, cos_r, sin_r);
     const double Kg = M::exp(-(r.cov * (r.t1 - O_r)));
-    const double ph_r = v.c * s.c + v.s * s.s * cos_r;
-    const double F_r = M::div(r.Gv * 0.5 * (1.0 + ph_r), PI * c.rr * (r.t1 - O_r));
+    const double ph_r = r.cc + r.ss * cos_r;               // v.c s.c + v.s s.s cos_r
+    const double F_r = M::div(r.half_Gv * (1.0 + ph_r), PI * c.rr * (r.t1 - O_r));
 
     double frac = M::over_pi(raa);
     if (frac > 1.0) frac = 2.0 - frac;
     double f = (1. - frac) * r.fF0 + frac * r.fFpi;
-    f = r.beta * f + (1.0 - r.beta) * F_r;
+    f = r.beta * f + r.one_m_beta * F_r;
     const double Kc = f * (1.0 - Kg);
 
     const double Kz = r.ev - Kg;                             // gortt.c:439
     const double Kt = ref_max(0.0, 1.0 - Kc - Kz - Kg);      // gortt.c:443-444
     const double Kpg = r.es - Kg;                            // gortt.c:448
-    const double Kpz = 1.0 - r.ev - Kpg;                     // gortt.c:449
+    const double Kpz = r.one_m_ev - Kpg;                     // gortt.c:449: 1.0 - ev - K'g
 
     // Kuusk's hot spot (unprimed angles in cos xi).  In the exact hot-spot direction (vza = sza, raa = 0)
     // q2 is pure rounding noise of cos_xi around 1, and exp(kf*h1*h2) amplifies it (up to ~1e-4 relative at
@@ -361,17 +406,17 @@ __device__ void finish_angle_with(const gort_canopy &c, const RowTerms &r, doubl
     // whenever the device sin/cos agree with glibc's.
     double h2 = 1.0;
     {
-        const double cos_xi = r.cos_sz * r.cos_vz + r.sin_sz * r.sin_vz * cos_r;
-        const double q2 = r.ls * r.ls + r.lv * r.lv - 2. * r.ls * r.lv * cos_xi;
+        const double cos_xi = r.czz + r.szz * cos_r;           // cos_sz cos_vz + sin_sz sin_vz cos_r
+        const double q2 = r.q2_a - r.q2_b * cos_xi;            // ls ls + lv lv - 2 ls lv cos xi, the row's parts formed ahead
         if (q2 > 0.0) {
-            const double x = M::div(M::sqrt(q2), c.r);
+            const double x = M::div_with(M::sqrt(q2), c.r, r.rcp_r);
             h2 = M::div(1.0 - M::exp(-x), x);
         }
     }
-    const double kuusk = r.eps_s * r.eps_v * M::exp(r.kf * r.h1 * h2);
+    const double kuusk = r.eps_sv * M::exp(r.kf_h1 * h2);
 
     o.Kc = Kc;  o.Kg = Kg;  o.Kt = Kt;  o.Kz = Kz;  o.Kpg = Kpg;  o.Kpz = Kpz;
-    o.A = M::div(kuusk, 2.0 * s.c * v.c);
+    o.A = M::div_with(kuusk, r.den_A, r.rcp_den_A);
     o.sun = r.sun;
 }
 
