@@ -286,13 +286,19 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
 
 // Which streams take this kernel: no component spectra, 17 ... LINES_MAX_BANDS bands, and enough lines to fill the
 // machine (below that the narrow kernels, whose threads are samples, have more parallelism)
+// [r5] ... and beyond 255 bands where the flat-panel kernel's chunks do not fit the rows: a million lines x 257 / 300 / 400 / 500
+// bands 446 / 524 / 678 / 837 us here against 539 / 589 / 724 / 862 through records + flat panels; at multiples of 128 bands
+// (256: 430 against 447, 384: 625 against 655, 512: 782 against 949) the flat kernel's perfectly aligned chunks win, from ~600
+// bands it wins everywhere (2101: 3.04 against 3.43 ms) - profiles/r05/lines_vs_flat_wide.log
 constexpr int LINES_MIN_BANDS = 17;
-constexpr int LINES_MAX_BANDS = 255;
+constexpr int LINES_MAX_BANDS = 255;                 // every band count up to here
+constexpr int LINES_MAX_BANDS_OFF_GRID = 600;        // and up to here unless the band count is a multiple of 128
 bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp)
 {
-    const char *v = ab_env("GORT_LINES_MAX_BANDS");           // measuring build, read per call: tests and tools/shape_scan.py move
-    const int max_bands = v ? atoi(v) : LINES_MAX_BANDS;       // the hand-over to the flat-panel kernel inside one process
-    return !want_scomp && nw >= LINES_MIN_BANDS && nw <= max_bands && nA * (long)nw >= (1L << 18);
+    if (want_scomp || nw < LINES_MIN_BANDS || nA * (long)nw < (1L << 18)) return false;
+    if (const char *v = ab_env("GORT_LINES_MAX_BANDS"))       // measuring build, read per call: tests and tools/shape_scan.py move
+        return nw <= atoi(v);                                  // the hand-over to the flat-panel kernel inside one process
+    return nw <= LINES_MAX_BANDS || (nw <= LINES_MAX_BANDS_OFF_GRID && nw % 128 != 0);
 }
 
 int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const double *band_table_dev, int nw, const double *angles_dev,

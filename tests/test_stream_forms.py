@@ -38,14 +38,15 @@ def setup():
 
 def _run(eng, torch, ang, nw, pieces=False, out=None):
     """The stream in ONE call (wide kernel where it applies), or cut into pieces below the wide kernels' thresholds (4M
-    samples from 256 bands, 256K samples for 17 ... 255 bands)."""
+    samples for the flat-panel kernel, 256K samples for the line kernel's band counts)."""
     a = torch.as_tensor(np.ascontiguousarray(ang), device="cuda")
     n = ang.shape[0]
     if out is None:
         out = torch.full((n, nw), -7.0, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
     forms = set()
-    step = n if not pieces else max(1, ((1 << (22 if nw > 255 else 18)) - 1) // nw)
+    lines_kernel = nw <= 255 or (nw <= 600 and nw % 128 != 0)          # gort_stream_lines.hip: stream_takes_lines_kernel
+    step = n if not pieces else max(1, ((1 << (18 if lines_kernel else 22)) - 1) // nw)
     for i in range(0, n, step):
         eng.rsurf_stream_dev(a[i:i + step], out[i:i + step])
         forms.add(eng.stream_form())
@@ -85,12 +86,13 @@ def test_flat_kernel_equals_narrow_kernels_bitwise_and_oracle(setup):
     assert relerr(got, ref, floor=1e-12) <= REGRESSION
 
 
-@pytest.mark.parametrize("nw", [17, 18, 31, 32, 33, 47, 48, 64, 65, 100, 127, 128, 129, 143, 144, 190, 255, 256, 1000, 1999, 2048, 3000])
+@pytest.mark.parametrize("nw", [17, 18, 31, 32, 33, 47, 48, 64, 65, 100, 127, 128, 129, 143, 144, 190, 255, 256, 257, 300, 384, 512, 513, 600, 601, 1000, 1999, 2048, 3000])
 def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
     """Band counts with every gcd(nw, 128) (wave strides of 1..128 chunk columns), the last panel ragged, the output
     itself starting off a 1-KiB chunk boundary (front and back edge handling).  Up to 255 bands: the fused line kernel
     (lines in lanes, rows through LDS rings indexed by absolute position, whole 128-B lines whatever the band count; the
-    output offsets 1 and 5 leave partial lines at both ends of every wave's span), ragged last wave."""
+    output offsets 1 and 5 leave partial lines at both ends of every wave's span), ragged last wave; and on to 600 bands off
+    the 128-band grid, where it beats records + flat panels."""
     eng, c, torch = setup
     rng = np.random.default_rng(nw)
     wl = np.linspace(400.0, 2500.0, nw)
@@ -103,7 +105,8 @@ def test_flat_kernel_band_counts_and_output_alignments(setup, nw):
         buf = torch.full((n * nw + 160,), -7.0, dtype=torch.float64, device="cuda")
         out = buf[offset:offset + n * nw].view(n, nw)
         g, form = _run(eng, torch, ang, nw, out=out)
-        assert form == ("lines" if nw <= 255 else "flat")
+        # the line kernel up to 255 bands, and up to 600 where the band count is not a multiple of 128 (gort_stream_lines.hip)
+        assert form == ("lines" if nw <= 255 or (nw <= 600 and nw % 128) else "flat")
         assert _bits_equal(g, p), (nw, offset)
         assert float(buf[:offset].min() if offset else -7.0) == -7.0 and float(buf[offset + n * nw:].max()) == -7.0
 
@@ -113,7 +116,7 @@ def test_one_sun_zenith_and_horizon_and_nan_lines(setup):
     which give NaN rows whatever the kernel."""
     eng, c, torch = setup
     rng = np.random.default_rng(7)
-    wl = np.linspace(400.0, 2500.0, 300)
+    wl = np.linspace(400.0, 2500.0, 640)                     # the flat-panel kernel (300 bands would take the line kernel)
     rs, rl, tl = api.spectra(wl)
     eng.set_spectra(rs, rl, tl)
     n = 300000
