@@ -56,13 +56,15 @@ __device__ __forceinline__ double wave_sum(double v)
 // only, and a store-bound copy kernel broadcasts their rows.  Bitwise equal to the per-line evaluation by construction.
 struct SunKey { unsigned long long z, a; };
 
-__device__ inline SunKey sun_key(const double *__restrict__ angles, long line)
+// zenith_only: the key of the wide streams that share (sun zenith, band) terms (gort_stream_suns.hip) - a BRDF sample's sun
+// scalars depend on the normalised zenith alone
+__device__ inline SunKey sun_key(const double *__restrict__ angles, long line, int zenith_only = 0)
 {
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * line], angles[4 * line + 1], angles[4 * line + 2], angles[4 * line + 3], vza, sza, saa, raa);
     SunKey k;
     k.z = (unsigned long long)__double_as_longlong(sza);
-    k.a = (unsigned long long)__double_as_longlong(saa);
+    k.a = zenith_only ? 0ull : (unsigned long long)__double_as_longlong(saa);
     return k;
 }
 
@@ -78,11 +80,11 @@ __device__ inline unsigned long long sun_hash(SunKey k)
 // one thread per line: claim / find the slot of the line's key hash, lowest line index becomes the slot's owner
 __global__ __launch_bounds__(256) void energy_key_kernel(const double *__restrict__ angles, long nA,
                                                           unsigned long long *__restrict__ tab, unsigned *__restrict__ owner,
-                                                          unsigned mask, unsigned *__restrict__ slot_of)
+                                                          unsigned mask, unsigned *__restrict__ slot_of, int zenith_only)
 {
     const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (line >= nA) return;
-    const unsigned long long h = sun_hash(sun_key(angles, line));
+    const unsigned long long h = sun_hash(sun_key(angles, line, zenith_only));
     unsigned idx = (unsigned)h & mask;
     for (unsigned tries = 0; tries <= mask; ++tries) {       // the table has >= 2 nA slots: ends long before
         const unsigned long long old = atomicCAS(&tab[idx], 0ull, h);
@@ -96,11 +98,11 @@ __global__ __launch_bounds__(256) void energy_key_kernel(const double *__restric
 // the line whose row `line` shares: the owner of its slot if that one has the same key (two keys with one hash share a
 // slot; the one that is not the owner's stands for itself), else the line itself
 __device__ inline long energy_rep(const double *__restrict__ angles, long line, const unsigned *__restrict__ owner,
-                                  const unsigned *__restrict__ slot_of)
+                                  const unsigned *__restrict__ slot_of, int zenith_only)
 {
     const long o = owner[slot_of[line]];
     if (o == line) return line;
-    const SunKey a = sun_key(angles, line), b = sun_key(angles, o);
+    const SunKey a = sun_key(angles, line, zenith_only), b = sun_key(angles, o, zenith_only);
     return (a.z == b.z && a.a == b.a) ? o : line;
 }
 
@@ -109,12 +111,12 @@ __device__ inline long energy_rep(const double *__restrict__ angles, long line, 
 constexpr int TABLE_THREADS = 256;
 __global__ __launch_bounds__(TABLE_THREADS) void energy_rep_kernel(const double *__restrict__ angles, long nA,
                                                                     const unsigned *__restrict__ owner, unsigned *__restrict__ slot_of,
-                                                                    unsigned *__restrict__ blocks)
+                                                                    unsigned *__restrict__ blocks, int zenith_only)
 {
     const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool own = false;
     if (line < nA) {
-        const long rep = energy_rep(angles, line, owner, slot_of);
+        const long rep = energy_rep(angles, line, owner, slot_of, zenith_only);
         slot_of[line] = (unsigned)rep;
         own = rep == line;
     }
@@ -699,7 +701,7 @@ const unsigned *energy_table_count(const void *ws_dev, long nA) { return carve_t
 
 // rep[line] = the first line of the stream with `line`'s normalised sun direction; the list of those first lines in line
 // order (uniq[0] = their number, also written to *n_rows_out_dev if given); idx[line] = the place of rep[line] in the list
-int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream)
+int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream, bool zenith_only)
 {
     if (nA <= 0) return GORT_OK;
     if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
@@ -710,10 +712,10 @@ int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigne
         hipMemsetAsync(t.owner, 0xff, t.cap * sizeof(unsigned), s) != hipSuccess)
         return fail(GORT_ENODEVICE, "energy: cannot clear the sun-direction table");
     const dim3 grid((unsigned)t.n_blocks), block(TABLE_THREADS);
-    hipLaunchKernelGGL(energy_key_kernel, grid, block, 0, s, angles_dev, nA, t.tab, t.owner, (unsigned)(t.cap - 1), t.rep);
+    hipLaunchKernelGGL(energy_key_kernel, grid, block, 0, s, angles_dev, nA, t.tab, t.owner, (unsigned)(t.cap - 1), t.rep, zenith_only ? 1 : 0);
     int rc = check_launch("energy_key_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(energy_rep_kernel, grid, block, 0, s, angles_dev, nA, (const unsigned *)t.owner, t.rep, t.blocks);
+    hipLaunchKernelGGL(energy_rep_kernel, grid, block, 0, s, angles_dev, nA, (const unsigned *)t.owner, t.rep, t.blocks, zenith_only ? 1 : 0);
     if ((rc = check_launch("energy_rep_kernel"))) return rc;
     hipLaunchKernelGGL(energy_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, t.blocks, t.n_blocks, t.uniq, n_rows_out_dev);
     if ((rc = check_launch("energy_scan_kernel"))) return rc;
