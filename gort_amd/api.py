@@ -79,7 +79,7 @@ DECLARED_SYMBOLS = [
     "gort_engine_set_canopy", "gort_engine_set_spectra", "gort_engine_nw",
     "gort_engine_n_members", "gort_engine_set_members", "gort_engine_set_members_leaf", "gort_engine_reserve_members", "gort_engine_get_member",
     "gort_rsurf_members_grid_dev", "gort_rsurf_members_stream", "gort_rsurf_members_stream_dev",
-    "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev", "gort_engine_set_stream_sun_sharing",
+    "gort_rsurf_stream", "gort_rsurf_stream_dev", "gort_rsurf_grid_dev",
     "gort_energy_stream", "gort_energy_stream_dev", "gort_energy_members_dev",
     "gort_energy_stream_indexed", "gort_energy_stream_indexed_dev",
     "gort_host_malloc", "gort_host_free", "gort_set_device", "gort_get_device",
@@ -142,7 +142,6 @@ def lib():
         L.gort_pipe_destroy.restype = None
         L.gort_engine_stream_form.argtypes = [C.c_void_p]
         L.gort_engine_time_streams.argtypes = [C.c_void_p, C.c_int]
-        L.gort_engine_set_stream_sun_sharing.argtypes = [C.c_void_p, C.c_int]
         L.gort_engine_last_stream_ms.argtypes = [C.c_void_p]
         L.gort_engine_last_stream_ms.restype = D
         L.gort_engine_xcd_weights.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -604,16 +603,11 @@ class Engine:
                                            _ptr(scomp_t), _ptr(K_t)))
 
     def stream_form(self):
-        """'narrow' | 'flat' | 'lines' | 'suns': which kernel family expanded the last stream call (include/gort_amd_tuning.h)."""
+        """'narrow' | 'flat' | 'lines': which kernel family expanded the last stream call (include/gort_amd_tuning.h)."""
         m = lib().gort_engine_stream_form(self.h)
         if m < 0:
             _check(m)
-        return {0: "narrow", 1: "flat", 2: "lines", 3: "suns"}[m]
-
-    def set_stream_sun_sharing(self, mode):
-        """0 never | 1 where it pays (default) | 2 wherever possible: wide streams of few distinct sun zeniths through the
-        LUT family's five-term sample (include/gort_amd.h)."""
-        _check(lib().gort_engine_set_stream_sun_sharing(self.h, int(mode)))
+        return {0: "narrow", 1: "flat", 2: "lines"}[m]
 
     def time_streams(self, on=True):
         """Record the two events last_stream_ms() reads around the expansion stage of every stream call (6 us per call)."""

@@ -30,7 +30,6 @@ UNITS = [
     ("gort_lut_expand.hip", []),
     ("gort_stream_expand.hip", []),
     ("gort_stream_lines.hip", []),
-    ("gort_stream_suns.hip", []),
     ("gort_energy.hip", []),
     ("gort_xcd.hip", []),
     ("gort_pipe.hip", []),

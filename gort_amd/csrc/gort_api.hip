@@ -74,11 +74,8 @@ struct gort_engine {
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
     DevBuf glines, mbands;               // few-band grids: their nodes as angle lines; the members' StreamBand tables
     DevBuf edup;                         // sun-direction table of the energy path (gort_energy.hip)
-    DevBuf suns_ws, suns_table;          // wide streams that share sun zeniths (gort_stream_suns.hip): buckets + sorted records; sun[n][5][nw]
-    unsigned *suns_count = nullptr;      // pinned: the number of distinct sun zeniths of the stream in hand
-    int share_suns = 0;                  // gort_engine_set_stream_sun_sharing: 0 never, 1 where it pays, 2 wherever it is possible
     bool energy_dedup = true;            // GORT_ENERGY_DEDUP=0: every line evaluated (tests compare the two)
-    int stream_form = 0;                 // kernel family of the last stream call: 0 narrow, 1 flat panels, 2 lines, 3 shared sun zeniths (gort_amd_tuning.h)
+    int stream_form = 0;                 // kernel family of the last stream call: 0 narrow, 1 flat panels (gort_amd_tuning.h)
     hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call, if asked for
     bool time_streams = false;           // gort_engine_time_streams: the two events cost a short call 6 us of its 18
     char *stage = nullptr;               // pinned staging of the setters' small uploads (stage_begin / stage_h2d)
@@ -351,14 +348,12 @@ extern "C" void gort_engine_destroy(gort_engine *e)
         if (ev) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
-                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots, &e->edup,
-                      &e->suns_ws, &e->suns_table})
+                      &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots, &e->edup})
         b->release();
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->ev_stream) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_stage) (void)hipEventDestroy(e->ev_stage);
     if (e->stage) (void)hipHostFree(e->stage);
-    if (e->suns_count) (void)hipHostFree(e->suns_count);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -655,47 +650,6 @@ static int require_ready(const gort_engine *e, const char *who)
 
 // ----------------------------------------------------------------- BRDF stream
 
-// Streams of >= 256 bands whose lines share few sun zeniths (gort_stream_suns.hip).  Whether a stream is one is known only
-// after the table pass over its lines (five small launches and a wait for the count): it is tried where that is small
-// against the call (SUNS_MIN_SAMPLES), and taken where every sun zenith has enough lines to fill segments.
-constexpr int SUNS_MIN_BANDS = 256;
-constexpr long SUNS_MIN_SAMPLES = 1L << 27;      // a gigabyte of output: ~0.2 ms of the stream family
-constexpr long SUNS_MIN_LINES_PER_SUN = 256;
-
-static bool stream_may_share_suns(const gort_engine *e, long nA, bool want_scomp)
-{
-    if (want_scomp || e->share_suns == 0 || e->nw < 128) return false;      // a piece of a row is 128 doubles
-    if (e->share_suns == 2) return true;
-    return e->nw >= SUNS_MIN_BANDS && nA * (long)e->nw >= SUNS_MIN_SAMPLES;
-}
-
-static int stream_sharing_suns(gort_engine *e, const double *angles_dev, long nA, double *rsurf_dev, double *K_dev, bool timed,
-                               bool *taken)
-{
-    int rc;
-    *taken = false;
-    if (nA >= (1L << 31) - 1) return GORT_OK;
-    if (!e->suns_count) GORT_HIP(hipHostMalloc((void **)&e->suns_count, sizeof(unsigned), hipHostMallocDefault));
-    if ((rc = e->edup.reserve(energy_table_workspace(nA)))) return rc;
-    if ((rc = launch_energy_table(angles_dev, nA, e->edup.p, e->suns_count, e->stream, true))) return rc;
-    GORT_HIP(hipStreamSynchronize(e->stream));
-    const long n_suns = (long)*e->suns_count;
-    if (n_suns < 1 || n_suns > STREAM_SUNS_MAX) return GORT_OK;
-    if (e->share_suns != 2 && n_suns * SUNS_MIN_LINES_PER_SUN > nA) return GORT_OK;
-    if ((rc = e->suns_ws.reserve(stream_suns_workspace(nA, n_suns)))) return rc;
-    if ((rc = e->suns_table.reserve(sizeof(double) * 5 * (size_t)e->nw * (size_t)n_suns))) return rc;
-    const gort_canopy *c = e->canopy.as<gort_canopy>();
-    if ((rc = launch_sun_list_table(c, e->L.as<double>(), e->nw, angles_dev, energy_table_count(e->edup.p, nA) + 1, n_suns,
-                                    e->suns_table.as<double>(), e->stream)))
-        return rc;
-    if ((rc = launch_stream_suns(c, e->suns_table.as<double>(), e->nw, angles_dev, nA, energy_table_index(e->edup.p, nA), n_suns,
-                                 e->suns_ws.p, rsurf_dev, K_dev, e->stream, timed ? e->ev_stream[0] : nullptr,
-                                 timed ? e->ev_stream[1] : nullptr)))
-        return rc;
-    *taken = true;
-    return GORT_OK;
-}
-
 extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA, double *rsurf_dev,
                                      double *scomp_dev, double *K_dev)
 {
@@ -714,15 +668,6 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     const bool timed = e->time_streams;
     for (int i = 0; timed && i < 2; ++i)
         if (!e->ev_stream[i]) GORT_HIP(hipEventCreate(&e->ev_stream[i]));
-    // wide streams of few distinct sun zeniths: the LUT family's five-term sample on lines sorted by sun zenith
-    if (stream_may_share_suns(e, nA, scomp_dev != nullptr)) {
-        bool taken = false;
-        if ((rc = stream_sharing_suns(e, angles_dev, nA, rsurf_dev, K_dev, timed, &taken))) return rc;
-        if (taken) {
-            e->stream_form = 3;
-            return GORT_OK;
-        }
-    }
     // 17 ... ~250 bands (all the reference's command line can read): one kernel from the angle line to its row
     if (stream_takes_lines_kernel(e->nw, nA, scomp_dev != nullptr)) {
         if (timed) GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
@@ -897,13 +842,6 @@ extern "C" int gort_engine_stream_form(gort_engine *e)
 {
     if (!e) return fail(GORT_EINVAL, "gort_engine_stream_form: null engine");
     return e->stream_form;
-}
-
-extern "C" int gort_engine_set_stream_sun_sharing(gort_engine *e, int mode)
-{
-    if (!e || mode < 0 || mode > 2) return fail(GORT_EINVAL, "gort_engine_set_stream_sun_sharing: bad argument");
-    e->share_suns = mode;
-    return GORT_OK;
 }
 
 extern "C" int gort_engine_time_streams(gort_engine *e, int on)

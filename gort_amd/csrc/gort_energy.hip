@@ -56,15 +56,13 @@ __device__ __forceinline__ double wave_sum(double v)
 // only, and a store-bound copy kernel broadcasts their rows.  Bitwise equal to the per-line evaluation by construction.
 struct SunKey { unsigned long long z, a; };
 
-// zenith_only: the key of the wide streams that share (sun zenith, band) terms (gort_stream_suns.hip) - a BRDF sample's sun
-// scalars depend on the normalised zenith alone
-__device__ inline SunKey sun_key(const double *__restrict__ angles, long line, int zenith_only = 0)
+__device__ inline SunKey sun_key(const double *__restrict__ angles, long line)
 {
     double vza, sza, saa, raa;
     normalise_angles(angles[4 * line], angles[4 * line + 1], angles[4 * line + 2], angles[4 * line + 3], vza, sza, saa, raa);
     SunKey k;
     k.z = (unsigned long long)__double_as_longlong(sza);
-    k.a = zenith_only ? 0ull : (unsigned long long)__double_as_longlong(saa);
+    k.a = (unsigned long long)__double_as_longlong(saa);
     return k;
 }
 
@@ -77,46 +75,77 @@ __device__ inline unsigned long long sun_hash(SunKey k)
     return h ? h : 1ull;                                 // 0 marks an empty slot
 }
 
-// one thread per line: claim / find the slot of the line's key hash, lowest line index becomes the slot's owner
-__global__ __launch_bounds__(256) void energy_key_kernel(const double *__restrict__ angles, long nA,
-                                                          unsigned long long *__restrict__ tab, unsigned *__restrict__ owner,
-                                                          unsigned mask, unsigned *__restrict__ slot_of, int zenith_only)
+// one thread per line: claim / find the slot of the line's key hash, lowest line index becomes the slot's owner.
+// A stream has few sun directions far more often than many, and a million compare-and-swaps on ONE address are 13 ms
+// (profiles/r05/suns/README.md, energy_table_cost.log).  So the 256 lines of a workgroup first meet in a table in LDS - the
+// first line of every hash among them speaks for the others - and a speaker reads before it writes: a slot that holds its
+// hash needs no claim, an owner in front of it no minimum (slots are claimed once, owners only ever decrease: a stale read
+// costs an atomic, never a result).  The table it leaves is the one every line for itself would have left.
+constexpr int KEY_THREADS = 256, KEY_SLOTS = 2 * KEY_THREADS;
+__global__ __launch_bounds__(KEY_THREADS) void energy_key_kernel(const double *__restrict__ angles, long nA,
+                                                                  unsigned long long *__restrict__ tab, unsigned *__restrict__ owner,
+                                                                  unsigned mask, unsigned *__restrict__ slot_of)
 {
-    const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (line >= nA) return;
-    const unsigned long long h = sun_hash(sun_key(angles, line, zenith_only));
-    unsigned idx = (unsigned)h & mask;
-    for (unsigned tries = 0; tries <= mask; ++tries) {       // the table has >= 2 nA slots: ends long before
-        const unsigned long long old = atomicCAS(&tab[idx], 0ull, h);
-        if (old == 0ull || old == h) break;
-        idx = (idx + 1) & mask;
+    __shared__ unsigned long long s_hash[KEY_SLOTS];
+    __shared__ unsigned s_first[KEY_SLOTS], s_idx[KEY_SLOTS];
+    for (int t = threadIdx.x; t < KEY_SLOTS; t += KEY_THREADS) {
+        s_hash[t] = 0ull;
+        s_first[t] = 0xffffffffu;
     }
-    atomicMin(&owner[idx], (unsigned)line);
-    slot_of[line] = idx;
+    __syncthreads();
+    const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = line < nA;
+    unsigned long long h = 0ull;
+    unsigned mine = 0;
+    if (live) {
+        h = sun_hash(sun_key(angles, line));
+        mine = (unsigned)(h >> 40) & (KEY_SLOTS - 1);        // other bits than the device table's
+        for (;;) {                                           // at most 256 hashes in 512 slots
+            const unsigned long long old = atomicCAS(&s_hash[mine], 0ull, h);
+            if (old == 0ull || old == h) break;
+            mine = (mine + 1) & (KEY_SLOTS - 1);
+        }
+        atomicMin(&s_first[mine], (unsigned)line);
+    }
+    __syncthreads();
+    if (live && s_first[mine] == (unsigned)line) {
+        unsigned idx = (unsigned)h & mask;
+        for (unsigned tries = 0; tries <= mask; ++tries) {   // the table has >= 2 nA slots: ends long before
+            unsigned long long old = __hip_atomic_load(&tab[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == 0ull) old = atomicCAS(&tab[idx], 0ull, h);
+            if (old == 0ull || old == h) break;
+            idx = (idx + 1) & mask;
+        }
+        if (__hip_atomic_load(&owner[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)line) atomicMin(&owner[idx], (unsigned)line);
+        s_idx[mine] = idx;
+    }
+    __syncthreads();
+    if (live) slot_of[line] = s_idx[mine];
 }
 
 // the line whose row `line` shares: the owner of its slot if that one has the same key (two keys with one hash share a
 // slot; the one that is not the owner's stands for itself), else the line itself
 __device__ inline long energy_rep(const double *__restrict__ angles, long line, const unsigned *__restrict__ owner,
-                                  const unsigned *__restrict__ slot_of, int zenith_only)
+                                  const unsigned *__restrict__ slot_of)
 {
     const long o = owner[slot_of[line]];
     if (o == line) return line;
-    const SunKey a = sun_key(angles, line, zenith_only), b = sun_key(angles, o, zenith_only);
+    const SunKey a = sun_key(angles, line), b = sun_key(angles, o);
     return (a.z == b.z && a.a == b.a) ? o : line;
 }
 
 // one thread per line, behind energy_key_kernel: slot_of[line] becomes rep[line] (in place: a line reads its own slot
 // only), and every block of 256 lines counts its lines that stand for themselves
 constexpr int TABLE_THREADS = 256;
+static_assert(KEY_THREADS == TABLE_THREADS, "the key kernel is launched on the blocks of the other table kernels");
 __global__ __launch_bounds__(TABLE_THREADS) void energy_rep_kernel(const double *__restrict__ angles, long nA,
                                                                     const unsigned *__restrict__ owner, unsigned *__restrict__ slot_of,
-                                                                    unsigned *__restrict__ blocks, int zenith_only)
+                                                                    unsigned *__restrict__ blocks)
 {
     const long line = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool own = false;
     if (line < nA) {
-        const long rep = energy_rep(angles, line, owner, slot_of, zenith_only);
+        const long rep = energy_rep(angles, line, owner, slot_of);
         slot_of[line] = (unsigned)rep;
         own = rep == line;
     }
@@ -701,7 +730,7 @@ const unsigned *energy_table_count(const void *ws_dev, long nA) { return carve_t
 
 // rep[line] = the first line of the stream with `line`'s normalised sun direction; the list of those first lines in line
 // order (uniq[0] = their number, also written to *n_rows_out_dev if given); idx[line] = the place of rep[line] in the list
-int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream, bool zenith_only)
+int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream)
 {
     if (nA <= 0) return GORT_OK;
     if (nA >= (1L << 31) - 1) return fail(GORT_EINVAL, "energy: %ld lines in one call", nA);
@@ -712,10 +741,10 @@ int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigne
         hipMemsetAsync(t.owner, 0xff, t.cap * sizeof(unsigned), s) != hipSuccess)
         return fail(GORT_ENODEVICE, "energy: cannot clear the sun-direction table");
     const dim3 grid((unsigned)t.n_blocks), block(TABLE_THREADS);
-    hipLaunchKernelGGL(energy_key_kernel, grid, block, 0, s, angles_dev, nA, t.tab, t.owner, (unsigned)(t.cap - 1), t.rep, zenith_only ? 1 : 0);
+    hipLaunchKernelGGL(energy_key_kernel, grid, block, 0, s, angles_dev, nA, t.tab, t.owner, (unsigned)(t.cap - 1), t.rep);
     int rc = check_launch("energy_key_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(energy_rep_kernel, grid, block, 0, s, angles_dev, nA, (const unsigned *)t.owner, t.rep, t.blocks, zenith_only ? 1 : 0);
+    hipLaunchKernelGGL(energy_rep_kernel, grid, block, 0, s, angles_dev, nA, (const unsigned *)t.owner, t.rep, t.blocks);
     if ((rc = check_launch("energy_rep_kernel"))) return rc;
     hipLaunchKernelGGL(energy_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, t.blocks, t.n_blocks, t.uniq, n_rows_out_dev);
     if ((rc = check_launch("energy_scan_kernel"))) return rc;

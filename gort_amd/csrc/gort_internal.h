@@ -157,17 +157,6 @@ int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const doub
 int launch_member_stream_bands(const double *L_dev, int n_members, int nw, double *bands_dev, void *stream);
 // the nodes of n_rows LUT rows of one member's grid, from row row_first, as angle lines "vza phi sza 0": angles_dev[n_rows * nphi][4]
 int launch_grid_lines(const gort_grid &g, long row_first, long n_rows, double *angles_dev, void *stream);
-// ---- wide streams whose lines share few sun zeniths (gort_stream_suns.hip): the LUT family's five-term sample, lines bucketed
-// by (sun zenith, alignment of their row).  idx_dev[line] = the place of the line's sun zenith among the n_suns distinct ones and
-// list_dev = their first lines (launch_energy_table with zenith_only: energy_table_index, energy_table_count + 1);
-// sun_dev[n_suns][5][nw] from launch_sun_list_table; ws_dev: stream_suns_workspace(nA, n_suns) bytes; ev_*: hipEvent_t or null
-constexpr long STREAM_SUNS_MAX = 4096;
-size_t stream_suns_workspace(long nA, long n_suns);
-int launch_sun_list_table(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
-                          const unsigned *list_dev, long n, double *sun_dev, void *stream);
-int launch_stream_suns(const gort_canopy *canopy_dev, const double *sun_dev, int nw, const double *angles_dev, long nA,
-                       const unsigned *idx_dev, long n_suns, void *ws_dev, double *rsurf_dev, double *K_dev, void *stream,
-                       void *ev_begin, void *ev_end);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);
@@ -194,8 +183,7 @@ size_t energy_dedup_workspace(long nA);
 // *n_rows_out_dev (may be null) = the length of the list.  launch_energy_rows evaluates the list into
 // rows_dev[member][rows_cap][nw][3] (places beyond rows_cap are skipped; n_rows_known = the length if the host knows it, else -1).
 size_t energy_table_workspace(long nA);
-// zenith_only: lines are alike when their normalised sun ZENITHS are (the table of gort_stream_suns.hip)
-int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream, bool zenith_only = false);
+int launch_energy_table(const double *angles_dev, long nA, void *ws_dev, unsigned *n_rows_out_dev, void *stream);
 const unsigned *energy_table_index(const void *ws_dev, long nA);      // idx[nA]
 const unsigned *energy_table_count(const void *ws_dev, long nA);      // the length of the list
 int launch_energy_rows(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw, const double *angles_dev,

@@ -85,40 +85,7 @@ __global__ __launch_bounds__(256) void sun_table_kernel(const gort_canopy *__res
     o[4 * nw + i] = b.T;
 }
 
-// sun[j][5][nw] for the sun zeniths of the lines list[j] of a stream (gort_stream_suns.hip): the same terms from the same
-// normalised zenith as sun_table_kernel's, member 0
-__global__ __launch_bounds__(256) void sun_list_table_kernel(const gort_canopy *__restrict__ canopies, const double *__restrict__ L,
-                                                              int nw, const double *__restrict__ angles,
-                                                              const unsigned *__restrict__ list, int n, double *__restrict__ sun)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int js = blockIdx.y;
-    if (i >= nw || js >= n) return;
-    const gort_canopy &c = canopies[0];
-    const long line = list[js];
-    double vza, sza, saa, raa;
-    normalise_angles(angles[4 * line], angles[4 * line + 1], angles[4 * line + 2], angles[4 * line + 3], vza, sza, saa, raa);
-    const SunScalars s = sun_from_zenith(c, sza);
-    const SunTerms b = sun_terms(L, nw, i, s, c.k_open, c.k_openep);
-    double *o = sun + (long)js * 5 * nw;
-    o[0 * nw + i] = b.C0;
-    o[1 * nw + i] = b.B;
-    o[2 * nw + i] = b.Z;
-    o[3 * nw + i] = b.G;
-    o[4 * nw + i] = b.T;
-}
-
 }  // namespace
-
-int launch_sun_list_table(const gort_canopy *canopy_dev, const double *L_dev, int nw, const double *angles_dev,
-                          const unsigned *list_dev, long n, double *sun_dev, void *stream)
-{
-    if (n <= 0 || nw <= 0) return GORT_OK;
-    if (n > 65535) return fail(GORT_EINVAL, "sun_table: %ld sun zeniths in one launch (max 65535)", n);
-    hipLaunchKernelGGL(sun_list_table_kernel, dim3((nw + 255) / 256, (unsigned)n), dim3(256), 0, (hipStream_t)stream, canopy_dev,
-                       L_dev, nw, angles_dev, list_dev, (int)n, sun_dev);
-    return check_launch("sun_list_table_kernel");
-}
 
 int launch_lambda_table(const gort_canopy *canopies_dev, int n_members, int nw, const double *spectra_dev,
                         double *L_dev, void *stream)

@@ -273,15 +273,6 @@ int  gort_rsurf_stream(gort_engine *e, const double *angles, long nA,
                        double *rsurf, double *scomp, double *K);
 int  gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA,
                            double *rsurf_dev, double *scomp_dev, double *K_dev);
-/* Wide streams whose lines share few sun zeniths (a scene, an orbit: one sun per acquisition).  The sun enters a sample
- * through five numbers per (sun zenith, band) (gortt.c:484-557 regrouped: the LUT path's form), so a stream of >= 256 bands
- * and >= 2^27 samples with at most 4096 distinct sun zeniths of >= 256 lines each is sorted by sun zenith on the device and
- * expanded like a LUT: 5 instead of 28 arithmetic slots per sample.  The two forms of a sample differ by rounding (a few
- * 1e-16 relative; both are held to 1e-9 against the reference), so the last bits of a line's row may depend on which other
- * lines travel with it.  mode 0 = never (every stream takes the per-line form: one line, one result, whatever the call);
- * 1 = where it pays (the default; costs such a call the table of its sun zeniths and one wait for their number);
- * 2 = wherever it is possible (>= 128 bands, at most 4096 sun zeniths; tests). New surface; the reference evaluates line by line. */
-int  gort_engine_set_stream_sun_sharing(gort_engine *e, int mode);
 
 /* Regular-grid LUT: every (sun zenith, view zenith, relative azimuth) node in integer
  * steps, equivalent to streaming the lines "vza phi sza 0" (SURVEY.md 8d, C3):

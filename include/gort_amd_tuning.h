@@ -30,9 +30,8 @@ double gort_engine_last_stream_ms(gort_engine *e);
  * 0 = a narrow-stream kernel (per sample / band-major / fused with the geometry for up to 16 bands), 1 = the aligned
  * flat-panel kernel (expand_flat_stream_kernel: >= 128 bands, >= 4M samples, records in between), 2 = the fused line kernel
  * (stream_lines_kernel: 17 ... 255 bands, and up to 600 bands that are not a multiple of 128; >= 256K samples; geometry and
- * samples in one launch), 3 = lines sorted by sun zenith + the LUT family's five-term sample (suns_expand_kernel:
- * gort_engine_set_stream_sun_sharing, include/gort_amd.h).  Forms 0-2 write the same
- * bits, form 3 the LUT's; tests use this to know which one they have compared. */
+ * samples in one launch).  All of them write the same
+ * bits; tests use this to know which one they have compared. */
 int  gort_engine_stream_form(gort_engine *e);
 
 /* ---- XCDs ---- */

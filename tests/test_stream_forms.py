@@ -32,7 +32,6 @@ def setup():
     c = api.gap_probabilities(api.make_canopy(lai=4.0))
     eng = api.Engine()
     eng.set_canopy(c)
-    eng.set_stream_sun_sharing(0)       # the per-line forms, whatever the sun zeniths of a test's lines (the last tests switch it on)
     yield eng, c, torch
     eng.close()
 
@@ -153,7 +152,7 @@ def test_grid_lines_through_the_stream_equal_the_lut(setup):
     ang = np.array([[float(r % 91), float(l), float(r // 91), 0.0] for r in rows for l in range(361)])
     s, form = _run(eng, torch, ang, wl.size)
     assert form == "flat"
-    assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-12       # the two families differ by rounding: 1.4e-13 seen
+    assert relerr(s.cpu().numpy(), lut.cpu().numpy(), floor=1e-12) <= 1e-13
 
 
 @pytest.mark.ab
@@ -272,103 +271,3 @@ def test_lines_typed_at_90_degrees_skip_the_reference_route_only_for_reflectance
         assert np.isnan(p[at90]).all() and np.isfinite(p[~at90]).all()
         assert np.isfinite(k[np.abs(ang[:, 0]) == 90.0]).all()
     e.close()
-
-
-# ---- wide streams of few sun zeniths: lines sorted by sun zenith, the LUT family's five-term sample (gort_stream_suns.hip) ----
-
-def _sharing(eng, mode):
-    class _Ctx:
-        def __enter__(self_inner):
-            eng.set_stream_sun_sharing(mode)
-
-        def __exit__(self_inner, *exc):
-            eng.set_stream_sun_sharing(0)
-    return _Ctx()
-
-
-@pytest.mark.parametrize("nw", [128, 257, 300, 2101])
-def test_shared_suns_stream_of_grid_nodes_in_any_order_equals_the_lut_bitwise(setup, nw):
-    """The nodes of a LUT (3 sun zeniths x 7 view zeniths x 37 azimuths) as angle lines "vza phi sza 0" in random order, each
-    node several times: the stream sorted by sun zenith applies the LUT path's functions to the LUT path's numbers."""
-    eng, c, torch = setup
-    rng = np.random.default_rng(1000 + nw)
-    eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
-    g = api.Grid()
-    g.sza0, g.dsza, g.nsza = 15.0, 22.5, 3
-    g.vza0, g.dvza, g.nvza = 0.0, 14.0, 7
-    g.phi0, g.dphi, g.nphi = 0.0, 10.0, 37
-    lut = torch.empty((g.nsza * g.nvza * g.nphi, nw), dtype=torch.float64, device="cuda")
-    eng.rsurf_grid_dev(g, 0, g.nsza * g.nvza, lut)
-    eng.synchronize()
-    i, j, l = np.meshgrid(np.arange(g.nsza), np.arange(g.nvza), np.arange(g.nphi), indexing="ij")
-    nodes = np.stack([g.vza0 + j * g.dvza, g.phi0 + l * g.dphi, g.sza0 + i * g.dsza, np.zeros(i.shape)], -1).reshape(-1, 4)
-    pick = rng.integers(0, nodes.shape[0], 5000)
-    for offset in (0, 3):
-        buf = torch.full((pick.size * nw + 32,), -7.0, dtype=torch.float64, device="cuda")
-        out = buf[offset:offset + pick.size * nw].view(pick.size, nw)
-        with _sharing(eng, 2):
-            got, form = _run(eng, torch, nodes[pick], nw, out=out)
-        assert form == "suns"
-        assert _bits_equal(got, lut[torch.as_tensor(pick, device="cuda")]), (nw, offset)
-        assert float(buf[:offset].min() if offset else -7.0) == -7.0 and float(buf[offset + pick.size * nw:].max()) == -7.0
-
-
-@pytest.mark.parametrize("nw,n", [(129, 3000), (256, 40000), (1000, 9001), (2101, 70001)])
-def test_shared_suns_stream_against_the_per_line_forms_and_the_oracle(setup, nw, n):
-    """Random lines over a pool of sun zeniths (some negative: zenith -> |zenith|, azimuth + 180; one shared by a single line), the
-    two forms of a sample to 1e-13, the proportions of -prnprop bit for bit, a sample of lines against the oracle to 1e-9."""
-    eng, c, torch = setup
-    rng = np.random.default_rng(n + nw)
-    wl = np.linspace(400.0, 2500.0, nw)
-    rs, rl, tl = api.spectra(wl)
-    eng.set_spectra(rs, rl, tl)
-    pool = np.concatenate([np.arange(0.0, 89.0, 3.5), -np.arange(1.0, 45.0, 7.0)])
-    ang = _lines(rng, n, pool)
-    ang[n // 2, 2] = 33.125
-    a = torch.as_tensor(ang, device="cuda")
-    out = [torch.full((n, nw), -7.0, dtype=torch.float64, device="cuda") for _ in range(2)]
-    K = [torch.full((n, 4), -7.0, dtype=torch.float64, device="cuda") for _ in range(2)]
-    torch.cuda.synchronize()
-    forms = []
-    for k, mode in enumerate((0, 2)):
-        with _sharing(eng, mode):
-            eng.rsurf_stream_dev(a, out[k], None, K[k])
-            forms.append(eng.stream_form())
-        eng.synchronize()
-    assert forms[1] == "suns" and forms[0] != "suns"
-    assert _bits_equal(K[0], K[1])
-    x, y = out[0].cpu().numpy(), out[1].cpu().numpy()
-    assert relerr(y, x, floor=1e-6) <= 1e-12       # the two families differ by rounding: 1.4e-13 seen
-    idx = np.sort(rng.choice(n, 30, replace=False))
-    ref, _, _ = O.rsurf_stream(_oracle_like(c), ang[idx], rs, rl, tl, want_K=False)
-    assert relerr(y[idx], ref, floor=1e-12) <= REGRESSION
-
-
-def test_shared_suns_rule_and_fallbacks(setup):
-    """Mode 1 leaves small streams alone; more than 4096 sun zeniths (or, in mode 1, fewer than 256 lines per sun zenith) send
-    the stream back to the per-line forms - the same bits as with the sharing off; beyond the horizon and NaN: NaN rows."""
-    eng, c, torch = setup
-    rng = np.random.default_rng(5)
-    nw = 300
-    eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
-    ang = _lines(rng, 20000, np.array([10.0, 20.0, 30.0]))
-    base, form0 = _run(eng, torch, ang, nw)
-    with _sharing(eng, 1):
-        got, form = _run(eng, torch, ang, nw)
-    assert form == form0 and _bits_equal(got, base)
-    many = _lines(rng, 20000, rng.uniform(0, 89, 5000))
-    base, form0 = _run(eng, torch, many, nw)
-    with _sharing(eng, 2):
-        got, form = _run(eng, torch, many, nw)
-    assert form == form0 and _bits_equal(got, base)
-    bad = _lines(rng, 5000, np.array([30.0, 60.0]))
-    bad[rng.choice(5000, 40, replace=False), 2] = 95.0
-    bad[rng.choice(5000, 40, replace=False), 2] = np.nan
-    bad[rng.choice(5000, 40, replace=False), 0] = 90.0
-    base, _ = _run(eng, torch, bad, nw)
-    with _sharing(eng, 2):
-        got, form = _run(eng, torch, bad, nw)
-    assert form == "suns"
-    assert bool((torch.isnan(got) == torch.isnan(base)).all())
-    nan_rows = torch.isnan(got).all(dim=1).cpu().numpy()
-    assert np.array_equal(nan_rows, np.isnan(bad[:, 2]) | (np.abs(bad[:, 2]) > 90) | (np.abs(bad[:, 0]) >= 90))

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """The arbitrary-angle stream (gortt.c:232-329) on device-resident buffers: N random lines x 2101 bands, with
-91 distinct sun zeniths, every line its own sun zenith, one sun zenith, ... (the flat-panel kernel, include/gort_amd_tuning.h),
-each with the sun-zenith sharing of include/gort_amd.h off and on (BENCH_STREAM_MODES=0,1; BENCH_STREAM_BANDS: another band count).
+91 distinct sun zeniths, every line its own sun zenith, one sun zenith, ... (the flat-panel kernel, include/gort_amd_tuning.h).
 Prints, per case, the time of the expansion stage (HIP events on the engine's stream), the whole call (geometry included, wall clock around a stream synchronisation), the samples/s
 and the fraction of the 8 TB/s HBM peak at 8 B per sample + 32 B per line."""
 import os, sys, time
@@ -13,9 +12,7 @@ from gort_amd import api
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 only = sys.argv[3] if len(sys.argv) > 3 else None
-MODES = [int(m) for m in os.environ.get("BENCH_STREAM_MODES", "0,1").split(",")]
-NW = int(os.environ.get("BENCH_STREAM_BANDS", "2101"))
-wl = np.arange(400.0, 2501.0) if NW == 2101 else np.linspace(400.0, 2500.0, NW)
+wl = np.arange(400.0, 2501.0)
 c = api.gap_probabilities(api.make_canopy(lai=4.0))
 eng = api.Engine(); eng.set_canopy(c); eng.set_spectra(*api.spectra(wl))
 rng = np.random.default_rng(0)
@@ -47,8 +44,7 @@ for name, sza in cases.items():
     if only and not any(o in name for o in only.split(",")):
         continue
     a = torch.tensor(np.stack([rng.uniform(0, 89, n), rng.uniform(0, 360, n), sza, np.zeros(n)], 1), device="cuda")
-    for grouping in MODES:                                      # gort_engine_set_stream_sun_sharing: 0 never, 1 where it pays, 2 wherever possible
-        eng.set_stream_sun_sharing(grouping)
+    for grouping in (1,):
 
         _t = time.perf_counter()                                 # every case starts from a busy device (the clocks sag within
         while time.perf_counter() - _t < 0.1:                    # the milliseconds it takes to build the case's angles)
@@ -69,7 +65,7 @@ for name, sza in cases.items():
         form = eng.stream_form()
         byts = n * wl.size * 8 + n * 32
         e, w = float(np.median(ex)), float(np.median(wall))
-        print("%-16s sharing=%d %-6s expansion %7.1f us (%5.0f GB/s, %.3f of 8 TB/s) | call %7.1f us  %.3e samples/s (%.3f)"
+        print("%-16s form=%d %-6s expansion %7.1f us (%5.0f GB/s, %.3f of 8 TB/s) | call %7.1f us  %.3e samples/s (%.3f)"
               % (name, grouping, form, e * 1e6, byts / e / 1e9, byts / e / 8e12, w * 1e6, n * wl.size / w, byts / w / 8e12), flush=True)
         if os.environ.get("BENCH_STREAM_JSON"):              # the same in the shape of bench.py's line, one object per case and form
             import json
