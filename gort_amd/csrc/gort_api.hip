@@ -72,7 +72,6 @@ struct gort_engine {
     size_t ev_used = 0;
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
-    DevBuf glines, mbands;               // few-band grids: their nodes as angle lines; the members' StreamBand tables
     DevBuf edup;                         // sun-direction table of the energy path (gort_energy.hip)
     bool energy_dedup = true;            // GORT_ENERGY_DEDUP=0: every line evaluated (tests compare the two)
     int stream_form = 0;                 // kernel family of the last stream call: 0 narrow, 1 flat panels (gort_amd_tuning.h)
@@ -343,7 +342,7 @@ extern "C" void gort_engine_destroy(gort_engine *e)
     e->hpipe = nullptr;
     if (e->aux) (void)hipStreamSynchronize(e->aux);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->gcoef[0], &e->gcoef[1], &e->gsun[0], &e->gsun[1], &e->glines, &e->mbands}) b->release();
+    for (DevBuf *b : {&e->gcoef[0], &e->gcoef[1], &e->gsun[0], &e->gsun[1]}) b->release();
     for (hipEvent_t ev : {e->ev_tables, e->ev_geom[0], e->ev_geom[1], e->ev_expand[0], e->ev_expand[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
@@ -671,7 +670,7 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     // 17 ... ~250 bands (all the reference's command line can read): one kernel from the angle line to its row
     if (stream_takes_lines_kernel(e->nw, nA, scomp_dev != nullptr)) {
         if (timed) GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
-        rc = launch_stream_lines(e->canopy.as<gort_canopy>(), 1, stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw,
+        rc = launch_stream_lines(e->canopy.as<gort_canopy>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw,
                                  angles_dev, nA, rsurf_dev, K_dev, e->stream);
         if (timed) GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
         e->stream_form = 2;
@@ -922,35 +921,22 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         // own member's canopy and band constants (rows are global: member * rows_per_member + ...)
         static const bool fuse = !(ab_env("GORT_GRID_FUSE") && atoi(ab_env("GORT_GRID_FUSE")) == 0);
         if (nw <= 8 && fuse) return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream);
-        // 9 ... 127 bands.  Several members: whole members only (what gort_rsurf_members_grid_dev asks for)
+        // 9 ... 127 bands: the same kernel - lanes as bands, whole rows per store - with the LUT path's (sun zenith, band) table
+        // beside it.  [r5] A hemisphere x 100 bands in 0.50 ms (0.65 through the stream kernels on the nodes written out as
+        // angle lines, 2.7 through records + one thread per sample), x 16 bands 0.09 ms (0.29, 0.62); the LUT family's sample
+        // like every other LUT path
+        if (fuse) {
+            const int q0 = (int)(row_begin / g->nvza), q1 = (int)((row_end - 1) / g->nvza) + 1;   // sun rows q = member*nsza + isza
+            if ((rc = e->sun.reserve(sizeof(double) * 5 * (size_t)nw * (size_t)(q1 - q0)))) return rc;
+            if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, e->sun.as<double>(), e->stream))) return rc;
+            return launch_geometry_grid_fused(c, e->L.as<double>(), nw, *g, row_begin, row_end, lut_dev, e->stream, e->sun.as<double>(), q0);
+        }
+        // GORT_GRID_FUSE=0 (measuring build): the two-kernel path the fused forms are held to - full angle records, then one
+        // thread per sample (the LUT family's five-term sample), member = blockIdx.z.  Several members: whole members only
         const long rpm = (long)g->nsza * g->nvza;
         const long m0 = row_begin / rpm, m1 = (row_end - 1) / rpm + 1;
         if (m1 - m0 > 1 && (row_begin != m0 * rpm || row_end != m1 * rpm))
             return fail(GORT_EINVAL, "grid of %d bands: rows [%ld,%ld) are not whole members", nw, row_begin, row_end);
-        // [r5] Through the STREAM kernels, the nodes written out as the angle lines a user would stream for them: up to 16 bands
-        // the fused stream kernel, from 17 the line kernel (rows through LDS rings as whole cache lines) - a hemisphere x 100
-        // bands in 0.7 ms where records + one thread per sample took 2.7 (0.9 TB/s; 128 bands, the LUT kernel: 0.49 ms).
-        // The stream family's sample: within 1e-13 of the LUT family's, bit for bit what gortt prints for those lines.
-        {
-            const int nm = (int)(m1 - m0);
-            const long lines = nA / nm;                      // per member
-            const bool fused = stream_fuses(nw, false), by_lines = !fused && stream_takes_lines_kernel(nw, lines, false);
-            if (nw > 8 && (fused || by_lines)) {          // (up to 8 bands with GORT_GRID_FUSE=0: the two-kernel LUT path below)
-                if ((rc = e->glines.reserve(sizeof(double) * 4 * (size_t)lines))) return rc;
-                if ((rc = launch_grid_lines(*g, row_begin - m0 * rpm, lines / g->nphi, e->glines.as<double>(), e->stream))) return rc;
-                const double *Lm = e->L.as<double>() + (size_t)m0 * L_NSLOT * nw;
-                if (fused)
-                    return launch_geometry_stream_fused(c + m0, nm, Lm, nw, e->glines.as<double>(), lines, lut_dev, nullptr, e->stream);
-                const double *bands = stream_band_table(e->L.as<double>(), nw, e->n_members);      // the first member's
-                if (m0 != 0 || nm > 1) {
-                    if ((rc = e->mbands.reserve(sizeof(double) * STREAM_BAND_TABLE_DOUBLES * (size_t)nw * (size_t)nm))) return rc;
-                    if ((rc = launch_member_stream_bands(Lm, nm, nw, e->mbands.as<double>(), e->stream))) return rc;
-                    bands = e->mbands.as<double>();
-                }
-                return launch_stream_lines(c + m0, nm, bands, nw, e->glines.as<double>(), lines, lut_dev, nullptr, e->stream);
-            }
-        }
-        // small grids: full angle records, then one thread per sample (the LUT family's five-term sample), member = blockIdx.z
         if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA))) return rc;
         if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, e->coef.as<double>(), false, e->stream))) return rc;
         const double *Lm = e->L.as<double>() + (size_t)m0 * L_NSLOT * nw;

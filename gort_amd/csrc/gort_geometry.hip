@@ -114,13 +114,14 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
                                                                           gort_grid g, long row_begin, long n_rows,
                                                                           double *__restrict__ coef, int compact,
                                                                           const double *__restrict__ Lall, int nw,
-                                                                          double *__restrict__ rsurf, int mirror, int az_table)
+                                                                          double *__restrict__ rsurf, int mirror, int az_table,
+                                                                          const double *__restrict__ sun_tab, int q_begin)
 {
     __shared__ RowTerms s_row[GEOM_ROWS];
     __shared__ double s_az[3][GEOM_AZ_TABLE];
     __shared__ RowScratch s_scr[GEOM_ROWS];
     __shared__ double s_sun_terms[GEOM_ROWS][GEOM_FUSED_MAX_BANDS][5];      // fused form: C0, B, Z, G, T per (row, band)
-    __shared__ int s_member[GEOM_ROWS];
+    __shared__ int s_member[GEOM_ROWS], s_q[GEOM_ROWS];               // a row's member and its sun row member * nsza + isza
     __shared__ double s_vza_deg[GEOM_ROWS], s_sza_deg[GEOM_ROWS];
     const long rows_per_member = (long)g.nsza * g.nvza;
     const long member0 = row_begin / rows_per_member;                  // ONE_MEMBER: the member of every row
@@ -172,6 +173,10 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
         double vza_deg, sza_deg;
         row_of(i, member, vza_deg, sza_deg);
         s_member[i] = (int)member;
+        {
+            const long grow = row_begin + first + i;
+            s_q[i] = (int)(member * g.nsza + (grow - member * rows_per_member) / g.nvza);
+        }
         s_vza_deg[i] = vza_deg;
         s_sza_deg[i] = sza_deg;
     }
@@ -187,7 +192,7 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
     // ONE_MEMBER: what the node loop reads of the canopy and (fused form) the first band's constants, once, ahead of the loop
     // fused form: the five (sun zenith, band) terms of the sample depend on the row and the band only - once per (row, band)
     // here instead of once per node (sun_terms() is ~50 of a node's ~560 instructions)
-    if (compact == 2) {
+    if (compact == 2 && nw <= GEOM_FUSED_MAX_BANDS) {
         if ((int)threadIdx.x < rows_here * nw) {
             const int r = (int)threadIdx.x / nw, b = (int)threadIdx.x - r * nw;
             const long member = ONE_MEMBER ? member0 : (long)s_member[r];
@@ -208,13 +213,122 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
             finish_angle(c, s_row[r], raa, o);
         }
     };
+    // what a wave's 64 lanes hand each other before they store (compact records: four lanes to a record; few-band samples: the
+    // lanes' rows side by side) and where each lane's node - and its image - lies in the output
+    __shared__ dbl2 s_rec[THREADS / 64][64][4];
+    __shared__ long s_at[THREADS / 64][64][2];
+    static_assert(GEOM_FUSED_MAX_BANDS * sizeof(double) == 4 * sizeof(dbl2), "the fused form's samples take the records' place");
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    if (compact == 2 && nw > 1) {
+        // Few-band LUT: a node's nw samples are nw consecutive doubles, and a lane storing its own node's writes 8 bytes of
+        // every nw-th double per instruction - every cache line of the wave's span nw times, an eighth of it each time
+        // (12.5 us per band for the hemisphere).  The wave turns its samples through LDS instead, eight bands of its 64
+        // nodes at a time: lane k stores elements k, k + 64, ... of the 64 x 8, consecutive lanes consecutive doubles
+        // wherever consecutive nodes are consecutive in the output (a row's nodes are; its images run backwards, node by
+        // node): 2.2 us per band.  Up to eight bands the five (sun zenith, band) terms of the workgroup's rows sit in LDS;
+        // beyond, they come from the LUT path's table sun_tab[q - q_begin][5][nw] (launch_sun_table) - through the scalar
+        // cache where the wave's nodes share a row (two waves of three do, at 181 nodes per row), per lane where they do not.
+        double (*val)[GEOM_FUSED_MAX_BANDS] = reinterpret_cast<double (*)[GEOM_FUSED_MAX_BANDS]>(&s_rec[wave][0][0]);
+        const bool wide = nw > GEOM_FUSED_MAX_BANDS;
+        // element lane + 64 e of a pass of w bands: node (lane + 64 e) / w, band (lane + 64 e) % w
+        auto store_pass = [&](int b0, int w) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int node = w == GEOM_FUSED_MAX_BANDS ? lane >> 3 : lane / w, b = lane - node * w;
+            const int node_step = w == GEOM_FUSED_MAX_BANDS ? 8 : 64 / w, band_step = 64 - node_step * w;
+            for (int e = 0; e < w; ++e) {
+                const double x = val[node][b];
+                const long at = s_at[wave][node][0], at2 = s_at[wave][node][1];
+                if (at >= 0) rsurf[at * nw + b0 + b] = x;
+                if (at2 >= 0) rsurf[at2 * nw + b0 + b] = x;
+                b += band_step;
+                node += node_step;
+                if (b >= w) { b -= w;  ++node; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                  // before the next pass overwrites the samples
+        };
+        for (int n0 = rel0 + (wave << 6); n0 < rel1; n0 += THREADS) {       // wave-uniform bounds: every lane takes part in the turn
+            const int n = n0 + lane;
+            long i = -1, i2 = -1;
+            int r = n0 / per_row;                                            // lane 0's row: the lanes behind the span stay in it
+            double aC = 0.0, aB = 0.0, aZ = 0.0, aG = 0.0, aT = 0.0;
+            if (n < rel1) {
+                r = n / per_row;
+                const int l = n - r * per_row;
+                const gort_canopy &c = canopies[ONE_MEMBER ? member0 : (long)s_member[r]];
+                GeomOut o;
+                finish_node(c, r, l, o);
+                i = (first + r) * g.nphi + l;
+                const int l2 = g.nphi - 1 - l;
+                i2 = (mirror && l2 != l) ? (first + r) * g.nphi + l2 : -1;
+                double rec[GORT_COEF_STRIDE];
+                store_coef(rec, c, o);
+                aC = rec[A_C];  aB = rec[A_B];  aZ = rec[A_Z];  aG = rec[A_G];  aT = rec[A_T];
+            }
+            s_at[wave][lane][0] = i;
+            s_at[wave][lane][1] = i2;
+            if (!wide) {
+                for (int b = 0; b < nw; ++b) {
+                    const double *t = s_sun_terms[r][b];
+                    val[lane][b] = dot5(aC, aB, aZ, aG, aT, t[0], t[1], t[2], t[3], t[4]);
+                }
+                store_pass(0, nw);
+                continue;
+            }
+            // 9 ... 127 bands: the other way round.  Lanes are BANDS now - of as many nodes at a time as fit the wave (seven
+            // nodes of 9 bands, one of 33 ... 64; from 65 bands a lane has a second band 64 further on) - a lane keeps its bands'
+            // five (sun zenith, band) terms of its node's row in hand, and the wave walks its 64 nodes G at a time: a node's five
+            // coefficients come from the lane that made them (through LDS), five or ten FMAs, and whole rows - nw consecutive
+            // doubles each, G of them side by side - leave in one or two instructions; so do the images'.  (Turning eight bands
+            // at a time like the narrow form wrote 64 B of every row per pass: 1.8 TB/s at 100 bands; this way 4.8.)
+            val[lane][0] = aC;  val[lane][1] = aB;  val[lane][2] = aZ;  val[lane][3] = aG;  val[lane][4] = aT;
+            val[lane][5] = (double)r;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                  // the lanes' coefficients and s_at, before other lanes read them
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int n_here = rel1 - n0 < 64 ? rel1 - n0 : 64;              // wave-uniform
+            const int G = nw <= 64 ? 64 / nw : 1;                            // nodes per step
+            const int g = nw <= 64 ? lane / nw : 0, b_lo = lane - g * nw, b_hi = lane + 64;
+            const bool lo_live = g < G && b_lo < nw, hi_live = nw > 64 && b_hi < nw;
+            int r_cur = -1;
+            double tl[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, th[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int j0 = 0; j0 < n_here; j0 += G) {
+                const int j = j0 + g;
+                if (!lo_live || j >= n_here) continue;                       // (a lane without a band, or behind the wave's last node)
+                const int r_j = (int)val[j][5];
+                if (r_j != r_cur) {                                          // a new row (once or twice per 64 nodes): its sun terms
+                    r_cur = r_j;
+                    const double *__restrict__ t = sun_tab + (long)(s_q[r_j] - q_begin) * 5 * nw;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        tl[k] = t[(long)k * nw + b_lo];
+                        th[k] = hi_live ? t[(long)k * nw + b_hi] : 0.0;
+                    }
+                }
+                const double cC = val[j][0], cB = val[j][1], cZ = val[j][2], cG = val[j][3], cT = val[j][4];
+                const long at = s_at[wave][j][0], at2 = s_at[wave][j][1];
+                const double vl = dot5(cC, cB, cZ, cG, cT, tl[0], tl[1], tl[2], tl[3], tl[4]);
+                rsurf[at * nw + b_lo] = vl;
+                if (at2 >= 0) rsurf[at2 * nw + b_lo] = vl;
+                if (hi_live) {
+                    const double vh = dot5(cC, cB, cZ, cG, cT, th[0], th[1], th[2], th[3], th[4]);
+                    rsurf[at * nw + b_hi] = vh;
+                    if (at2 >= 0) rsurf[at2 * nw + b_hi] = vh;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                  // before the next round overwrites them
+        }
+        GORT_STAMP(2);
+        GORT_STAMPS_END(geometry, (long)blockIdx.x * 4 + (threadIdx.x >> 6), (threadIdx.x & 63) == 0);
+        return;
+    }
     if (compact == 1) {
         // LUT path: the five expansion coefficients of a node, one 64-B record - and its image's.  A lane holding its record
         // would store it as four 16-B pieces 64 B apart: every store instruction a quarter of 32 cache lines.  The wave
         // turns its 64 records through LDS instead, four lanes to a record: an instruction then writes 16 whole records.
-        __shared__ dbl2 s_rec[THREADS / 64][64][4];
-        __shared__ long s_at[THREADS / 64][64][2];
-        const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
         for (int n0 = rel0 + (wave << 6); n0 < rel1; n0 += THREADS) {       // wave-uniform bounds: every lane takes part in the turn
             const int n = n0 + lane;
             long i = -1, i2 = -1;
@@ -283,35 +397,9 @@ void geometry_grid_kernel(const gort_canopy *__restrict__ canopies,
     GORT_STAMPS_END(geometry, (long)blockIdx.x * 4 + (threadIdx.x >> 6), (threadIdx.x & 63) == 0);
 }
 
-// the nodes of LUT rows as the angle lines a user would stream for them, "vza phi sza 0" (SURVEY 8d, C3): rows
-// [row_first, row_first + n_rows) of ONE member's grid, node-major.  What grids of 9 ... 127 bands are evaluated from (gort_api.hip)
-__global__ __launch_bounds__(256) void grid_lines_kernel(gort_grid g, long row_first, long n_lines, double *__restrict__ angles)
-{
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_lines) return;
-    const long r = idx / g.nphi;
-    const int l = (int)(idx - r * g.nphi);
-    const long row = row_first + r;
-    const int isza = (int)(row / g.nvza), ivza = (int)(row % g.nvza);
-    double *a = angles + 4 * idx;
-    a[0] = g.vza0 + ivza * g.dvza;
-    a[1] = g.phi0 + l * g.dphi;
-    a[2] = g.sza0 + isza * g.dsza;
-    a[3] = 0.0;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------- launchers
-
-int launch_grid_lines(const gort_grid &g, long row_first, long n_rows, double *angles_dev, void *stream)
-{
-    const long n = n_rows * g.nphi;
-    if (n <= 0) return GORT_OK;
-    if ((n + 255) / 256 >= (1L << 31)) return fail(GORT_EINVAL, "grid lines: %ld nodes in one launch", n);
-    hipLaunchKernelGGL(grid_lines_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, row_first, n, angles_dev);
-    return check_launch("grid_lines_kernel");
-}
 
 // n_members > 1: blockIdx.z = member, canopy_dev[m], records coef_dev[m][nA][16], proportions K_dev[m][nA][4]
 int launch_geometry_stream(const gort_canopy *canopy_dev, int n_members, const double *angles_dev, long nA,
@@ -381,7 +469,8 @@ static int geom_rows_per_workgroup(long rows)
 }
 
 static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long rows, double *coef_dev,
-                                    int compact, const double *L_dev, int nw, double *rsurf_dev, void *stream)
+                                    int compact, const double *L_dev, int nw, double *rsurf_dev, void *stream,
+                                    const double *sun_dev = nullptr, int q_begin = 0)
 {
     const int mirror = grid_mirrors(g) ? 1 : 0;
     // the azimuth table: grids of non-negative zeniths (no line's azimuths are turned by pi, gortt.c:244-251) whose rows fit it
@@ -404,12 +493,12 @@ static int launch_geometry_grid_any(const gort_canopy *canopy_dev, const gort_gr
         if (G > slots) G = slots;
         if ((total + G - 1) / G > span_max) G = (total + span_max - 1) / span_max;
         hipLaunchKernelGGL((geometry_grid_kernel<GEOM_SPAN_ROWS, true>), dim3((unsigned)G), dim3(GEOM_SPAN_THREADS), 0, s, canopy_dev, g, row_begin, rows,
-                           coef_dev, compact, L_dev, nw, rsurf_dev, mirror, az_table);
+                           coef_dev, compact, L_dev, nw, rsurf_dev, mirror, az_table, sun_dev, q_begin);
         return check_launch("geometry_grid_kernel");
     }
     const int per = geom_rows_per_workgroup(rows);
     const dim3 grid((unsigned)((rows + per - 1) / per));
-#define GORT_GRID_LAUNCH(ROWS) hipLaunchKernelGGL((geometry_grid_kernel<ROWS, false>), grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror, az_table)
+#define GORT_GRID_LAUNCH(ROWS) hipLaunchKernelGGL((geometry_grid_kernel<ROWS, false>), grid, block, 0, s, canopy_dev, g, row_begin, rows, coef_dev, compact, L_dev, nw, rsurf_dev, mirror, az_table, sun_dev, q_begin)
     if (per == 4) GORT_GRID_LAUNCH(4);
     else if (per == 6) GORT_GRID_LAUNCH(6);
     else GORT_GRID_LAUNCH(8);
@@ -426,11 +515,12 @@ int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long
 }
 
 int launch_geometry_grid_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g, long row_begin,
-                               long row_end, double *rsurf_dev, void *stream)
+                               long row_end, double *rsurf_dev, void *stream, const double *sun_dev, int q_begin)
 {
     const long rows = row_end - row_begin;
     if (rows <= 0 || nw <= 0) return GORT_OK;
-    return launch_geometry_grid_any(canopy_dev, g, row_begin, rows, nullptr, 2, L_dev, nw, rsurf_dev, stream);
+    if (nw > GEOM_FUSED_MAX_BANDS && !sun_dev) return fail(GORT_EINVAL, "fused grid of %d bands: no sun table", nw);
+    return launch_geometry_grid_any(canopy_dev, g, row_begin, rows, nullptr, 2, L_dev, nw, rsurf_dev, stream, sun_dev, q_begin);
 }
 
 }  // namespace gort

@@ -100,9 +100,12 @@ int launch_geometry_stream_fused(const gort_canopy *canopy_dev, int n_members, c
 // compact: 8 doubles per node (A_C..A_T + pad) for the LUT kernel; else full GORT_COEF_STRIDE records
 int launch_geometry_grid(const gort_canopy *canopy_dev, const gort_grid &g, long row_begin, long row_end,
                          double *coef_dev, bool compact, void *stream);
-// grids of a few bands: samples formed in the geometry kernel itself, rsurf_dev[rows][nphi][nw], no records
+// grids of a few bands: samples formed in the geometry kernel itself, rsurf_dev[rows][nphi][nw], no records.  Up to 8 bands the
+// (sun zenith, band) terms are formed in the kernel; beyond, sun_dev[q - q_begin][5][nw] (launch_sun_table) holds them for the
+// sun rows q = member * nsza + isza of the launch
 int launch_geometry_grid_fused(const gort_canopy *canopy_dev, const double *L_dev, int nw, const gort_grid &g,
-                               long row_begin, long row_end, double *rsurf_dev, void *stream);
+                               long row_begin, long row_end, double *rsurf_dev, void *stream, const double *sun_dev = nullptr,
+                               int q_begin = 0);
 // per-XCD slot counters of the flat expansion kernels: 8 ints, one per 128-B line (XCD_SLOT_PITCH ints apart) so
 // that the eight XCDs' atomics do not serialise on one line; the caller zeroes XCD_SLOT_BYTES on the stream
 constexpr int XCD_SLOT_PITCH = 32;
@@ -150,13 +153,8 @@ int launch_expand_grid_members(const gort_canopy *canopies_dev, const double *L_
 // ---- streams of 17 ... ~250 bands without component spectra (gort_stream_lines.hip): geometry and samples in one kernel,
 // lanes = lines, rows leave LDS as whole 128-B lines whatever the band count; band_table_dev as above
 bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp);
-// n_members > 1: the same lines for canopy_dev[m] with band_table_dev[m][nw][12], rows rsurf_dev[m][nA][nw] (K_dev null)
-int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const double *band_table_dev, int nw, const double *angles_dev,
-                        long nA, double *rsurf_dev, double *K_dev, void *stream);
-// StreamBand tables of n_members members from their band tables L_dev[m][L_NSLOT][nw]: bands_dev[m][nw][12]
-int launch_member_stream_bands(const double *L_dev, int n_members, int nw, double *bands_dev, void *stream);
-// the nodes of n_rows LUT rows of one member's grid, from row row_first, as angle lines "vza phi sza 0": angles_dev[n_rows * nphi][4]
-int launch_grid_lines(const gort_grid &g, long row_first, long n_rows, double *angles_dev, void *stream);
+int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_dev, int nw, const double *angles_dev, long nA,
+                        double *rsurf_dev, double *K_dev, void *stream);
 // the same nA angle lines for n_members members: coef_dev[n][nA][GORT_COEF_STRIDE] scratch, rsurf_dev[n][nA][nw]
 int launch_members_stream(const gort_canopy *canopies_dev, int n_members, const double *L_dev, int nw,
                           const double *angles_dev, long nA, double *coef_dev, double *rsurf_dev, void *stream);

@@ -345,10 +345,12 @@ def test_grid_equals_stream_and_oracle(eng, nw):
 
 
 @pytest.mark.ab
-@pytest.mark.parametrize("nw", [1, 3, 8])
+@pytest.mark.parametrize("nw", [1, 3, 8, 9, 16, 50, 64, 65, 100, 127])
 def test_few_band_grid_fused_equals_two_kernel_path(nw):
-    """Grids of up to 8 bands (BASELINE config 3 has one) form their samples inside the geometry kernel; the
-    two-kernel path (records + per-sample expansion, GORT_GRID_FUSE=0) must give the same bits."""
+    """Grids below 128 bands (BASELINE config 3 has one) form their samples inside the geometry kernel - up to 8 bands a lane
+    its node's, turned through LDS into whole rows; from 9 bands lanes as bands, the (sun zenith, band) terms from the LUT
+    path's table; from 65 two bands per lane - and the two-kernel path (records + per-sample expansion, GORT_GRID_FUSE=0)
+    must give the same bits."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = r"""
 import hashlib, sys
@@ -1365,10 +1367,9 @@ def test_ensemble_members_one_launch(golden):
 
 @pytest.mark.parametrize("nw", [1, 7, 8, 9, 16, 100, 127])
 def test_member_grids_of_any_band_count(golden, nw):
-    """gort_rsurf_members_grid_dev below 128 bands (the MODIS-style ensemble the reference's README.md:8-9 names): up to 8
-    bands the fused node kernel with every row's own member; 9 ... 127 bands the stream kernels on the nodes written out as
-    angle lines (the fused stream kernel to 16 bands, the line kernel with the member in blockIdx.y beyond; small grids: records
-    + one thread per sample with the member in blockIdx.z).  32 members in one call == 32 single-canopy runs, bit for bit; the first 8 against the reference's own
+    """gort_rsurf_members_grid_dev below 128 bands (the MODIS-style ensemble the reference's README.md:8-9 names): the fused
+    node kernel with every row's own member (gort_geometry.hip: up to 8 bands a lane its node's samples, from 9 lanes as
+    bands).  32 members in one call == 32 single-canopy runs, bit for bit; the first 8 against the reference's own
     runs of those members (tests/golden/c5_members.npz) at the bands picked; a member sub-range; a mirrored full circle."""
     import torch
     g, canopies, leaf = _members(golden)
@@ -1381,11 +1382,12 @@ def test_member_grids_of_any_band_count(golden, nw):
     e = api.Engine()
     e.set_members(members, sp)
     single = api.Engine()
-    # the third grid is big enough for the line kernel (17 ... 127 bands: the nodes go through the stream kernels as angle lines)
+    # the third grid has rows longer than a wave (361 azimuths, mirrored: 181 nodes), the first rows of four
     for grid in (_grid((30.0, 1.0, 1), (0.0, 45.0, 3), (0.0, 90.0, 4)), _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 10.0, 37)),
                  _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 1.0, 361))):
         rows, nodes = grid.nsza * grid.nvza, grid.nsza * grid.nvza * grid.nphi
         lut = torch.full((n * nodes * nw + 16,), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()            # torch fills on ITS stream; the engine works on its own (non-blocking) one
         e.rsurf_members_grid_dev(grid, 0, n, lut)
         e.synchronize()
         assert float(lut[n * nodes * nw:].max()) == -7.0

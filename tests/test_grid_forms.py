@@ -39,7 +39,7 @@ GRIDS = {
 
 @pytest.mark.ab
 @pytest.mark.parametrize("name", sorted(GRIDS))
-@pytest.mark.parametrize("nw", [1, 3, 40])
+@pytest.mark.parametrize("nw", [1, 3, 40, 100])
 def test_node_partition_equals_row_partition(name, nw):
     import torch
     g = _grid(*GRIDS[name])
@@ -57,6 +57,7 @@ def test_node_partition_equals_row_partition(name, nw):
             try:
                 buf = torch.full(((r1 - r0) * g.nphi * nw + 16,), -7.0, dtype=torch.float64, device="cuda")
                 lut = buf[8:8 + (r1 - r0) * g.nphi * nw]
+                torch.cuda.synchronize()        # torch fills on ITS stream; the engine works on its own (non-blocking) one
                 e.rsurf_grid_dev(g, r0, r1, lut)
                 e.synchronize()
             finally:
@@ -86,6 +87,7 @@ def test_one_member_of_an_ensemble_takes_the_node_partition_with_its_own_canopy(
     every = torch.empty((3 * per,), dtype=torch.float64, device="cuda")
     e.rsurf_members_grid_dev(g, 0, 3, every)
     one = torch.full((per + 8,), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
     e.rsurf_members_grid_dev(g, 1, 2, one[:per])
     e.synchronize()
     assert float(one[per:].max()) == -7.0

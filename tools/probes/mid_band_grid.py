@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Hemisphere LUT at band counts below the LUT kernel's 128: which path, how fast (single canopy)."""
+"""Hemisphere LUT (91 x 91 x 361, single canopy, device-resident, best of 7) across band counts: below 128 bands the geometry
+kernel writes the samples itself (gort_geometry.hip, the fused forms), from 128 the LUT kernel expands records."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
@@ -7,7 +8,7 @@ import torch
 from gort_amd import api
 eng = api.Engine(); eng.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
 g = api.hemisphere_grid(); rows = g.nsza * g.nvza
-for nw in (1, 7, 8, 9, 16, 32, 64, 100, 127, 128, 200):
+for nw in (1, 2, 4, 7, 8, 9, 13, 16, 24, 32, 48, 64, 65, 100, 127, 128, 200):
     eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
     lut = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
     for _ in range(3):
