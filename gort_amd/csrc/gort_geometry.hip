@@ -34,10 +34,18 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
                                                                int layout, const double *__restrict__ L, int nw,
                                                                double *__restrict__ rsurf, int proportions_wanted)
 {
-    const long a = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // FUSED, 9 ... 16 bands: a wave's 64 lines x nw samples are consecutive doubles of the output, and a lane storing its own
+    // line's writes 8 bytes of every nw-th double per instruction; the wave turns them through LDS eight bands at a time instead
+    // and lane k stores elements k, k + 64, ... (the few-band LUT's turn, geometry_grid_kernel below: a million lines x 16
+    // bands 104 -> 92 us) - so every lane of a wave stays to the end, the lanes behind the stream evaluating its last line
+    // and storing nothing
+    __shared__ double s_val[FUSED ? 4 : 1][64][8];
+    const long a_own = (long)blockIdx.x * blockDim.x + threadIdx.x;
     GORT_STAMPS_BEGIN();
     GORT_STAMP(0);
-    if (a >= nA) return;
+    if (a_own >= nA && (!FUSED || (a_own & ~63L) >= nA)) return;      // (whole waves behind the stream leave)
+    const bool live = a_own < nA;
+    const long a = live ? a_own : nA - 1;
     // blockIdx.z = ensemble member: its canopy, its nA records (the angle lines are shared)
     const long member = blockIdx.z;
     const gort_canopy &c = canopy[member];
@@ -54,8 +62,34 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
         store_coef(rec, c, g);
         const LineTerms l = line_terms_of_record(rec, c.k_openep, c.k_open);
         const double *__restrict__ Lm = L + member * L_NSLOT * nw;
-        double *__restrict__ o = rsurf + (member * nA + a) * nw;
-        for (int i = 0; i < nw; ++i) o[i] = stream_sample(l, stream_band(load_band(Lm, nw, i)));
+        if (nw <= 8) {                 // up to eight bands a lane stores its own line's (measured: the turn costs what it saves)
+            double *__restrict__ o = rsurf + (member * nA + a) * nw;
+            if (live)
+                for (int i = 0; i < nw; ++i) o[i] = stream_sample(l, stream_band(load_band(Lm, nw, i)));
+        } else {
+            const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+            double (*val)[8] = s_val[wave];
+            const long a_wave = a_own - lane;                                  // the wave's first line
+            const int lines_here = nA - a_wave < 64 ? (int)(nA - a_wave) : 64;
+            double *__restrict__ o = rsurf + (member * nA + a_wave) * nw;      // its 64 x nw samples
+            for (int b0 = 0; b0 < nw; b0 += 8) {
+                const int w = nw - b0 < 8 ? nw - b0 : 8;
+                for (int b = 0; b < w; ++b) val[lane][b] = stream_sample(l, stream_band(load_band(Lm, nw, b0 + b)));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                int line = w == 8 ? lane >> 3 : lane / w, b = lane - line * w;
+                const int line_step = w == 8 ? 8 : 64 / w, band_step = 64 - line_step * w;
+                for (int e = 0; e < w; ++e) {                                    // element lane + 64 e of the pass's 64 x w
+                    if (line < lines_here) o[(long)line * nw + b0 + b] = val[line][b];
+                    b += band_step;
+                    line += line_step;
+                    if (b >= w) { b -= w;  ++line; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                              // before the next pass overwrites the samples
+            }
+        }
     } else if (layout == 0) {
         store_coef(coef + (member * nA + a) * GORT_COEF_STRIDE, c, g);
     } else {
@@ -66,7 +100,7 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
         o[0] = l.alpha;  o[1] = l.P1;  o[2] = l.P2;  o[3] = l.Q1;  o[4] = l.Q2;  o[5] = l.Q3;  o[6] = l.Q4;  o[7] = l.Q5;
         o[8] = l.Q6;  o[9] = l.mu;  o[10] = l.t0;  o[11] = l.m2;  o[12] = 0.0;  o[13] = 0.0;  o[14] = 0.0;  o[15] = 0.0;
     }
-    if (K) {
+    if (K && live) {
         double *k = K + 4 * (member * nA + a);
         k[0] = g.Kc;  k[1] = g.Kg;  k[2] = g.Kt;  k[3] = g.Kz;
     }

@@ -22,7 +22,7 @@ for _ in range(15):
     t0 = time.perf_counter(); eng.rsurf_stream_dev(a, None, K_t=Kt); eng.synchronize(); ts.append(time.perf_counter() - t0)
 geom = float(np.median(ts))
 print("geometry stage alone, %d lines (K only): call %.1f us" % (n, geom * 1e6), flush=True)
-for n, nw in ((1000000, 4), (1000000, 7), (1000000, 16), (1000000, 17), (1000000, 32), (1000000, 64), (1000000, 65), (1000000, 80), (1000000, 96), (1000000, 100), (1000000, 127), (1000000, 128), (1000000, 129), (1000000, 160), (1000000, 190), (1000000, 255), (1000000, 256), (500000, 300),
+for n, nw in ((1000000, 1), (1000000, 2), (1000000, 4), (1000000, 7), (1000000, 9), (1000000, 13), (1000000, 16), (1000000, 17), (1000000, 32), (1000000, 64), (1000000, 65), (1000000, 80), (1000000, 96), (1000000, 100), (1000000, 127), (1000000, 128), (1000000, 129), (1000000, 160), (1000000, 190), (1000000, 255), (1000000, 256), (500000, 300),
               (100000, 300), (1000, 2101), (1900, 2101), (2000, 2101), (10000, 1000), (4000000, 32)):
     wl = np.linspace(400.0, 2500.0, nw)
     eng.set_spectra(*api.spectra(wl))
