@@ -352,6 +352,16 @@ def configs_block(quick=False):
     out["C3"] = {"workload": "91x91x361 angles x 1 band, LUT entry point", "us": t * 1e6, "samples_per_s": rows * g.nphi / t,
                  "bound": "fp64_valu", "frac": None, "hbm_frac": rows * g.nphi * 8 / t / 8e12}
     del lut
+    # the same hemisphere as a LUT of 7 bands (MODIS land bands: the ensemble use the reference's README names) and of 100 (the band
+    # counts its command line can read): below 128 bands the geometry kernel writes the samples itself, whole rows per store
+    for nw, key in () if quick else ((7, "lut_hemisphere_x_7"), (100, "lut_hemisphere_x_100")):      # (not under the counters: C3's kernel again)
+        eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
+        lut = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
+        t = best(lambda: eng.rsurf_grid_dev(g, 0, rows, lut), eng)
+        out[key] = {"workload": "91x91x361 angles x %d bands, LUT entry point (geometry kernel writes the samples)" % nw, "us": t * 1e6,
+                    "samples_per_s": rows * g.nphi * nw / t, "bound": "fp64_valu" if nw < 32 else "hbm",
+                    "hbm_frac": rows * g.nphi * nw * 8 / t / 8e12}
+        del lut
     # C4: albedo / fAPAR table, 91 sun zeniths x 2101 bands
     wl = np.arange(400.0, 2501.0)
     eng.set_spectra(*api.spectra(wl))
