@@ -70,7 +70,7 @@ inline size_t stream_band_table_offset(int nw, int n_members)            // in d
     return ((size_t)L_NSLOT * n_members * (size_t)nw + 1) & ~(size_t)1;
 }
 constexpr int STREAM_BAND_TABLE_DOUBLES = 12;      // per band: sizeof(StreamBand) / sizeof(double) (gort_device.h asserts it)
-inline size_t lambda_table_doubles(int nw, int n_members) { return stream_band_table_offset(nw, n_members) + (size_t)12 * nw; }
+inline size_t lambda_table_doubles(int nw, int n_members) { return stream_band_table_offset(nw, n_members) + (size_t)STREAM_BAND_TABLE_DOUBLES * nw; }
 inline const double *stream_band_table(const double *L_dev, int nw, int n_members)
 {
     return L_dev + stream_band_table_offset(nw, n_members);
