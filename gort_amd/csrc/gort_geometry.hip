@@ -554,6 +554,7 @@ int launch_geometry_grid_fused(const gort_canopy *canopy_dev, const double *L_de
     const long rows = row_end - row_begin;
     if (rows <= 0 || nw <= 0) return GORT_OK;
     if (nw > GEOM_FUSED_MAX_BANDS && !sun_dev) return fail(GORT_EINVAL, "fused grid of %d bands: no sun table", nw);
+    if (nw > 128) return fail(GORT_EINVAL, "fused grid of %d bands: a lane holds two bands at most (128)", nw);
     return launch_geometry_grid_any(canopy_dev, g, row_begin, rows, nullptr, 2, L_dev, nw, rsurf_dev, stream, sun_dev, q_begin);
 }
 
