@@ -8,7 +8,7 @@ import torch
 from gort_amd import api
 eng = api.Engine(); eng.set_canopy(api.gap_probabilities(api.make_canopy(lai=4.0)))
 g = api.hemisphere_grid(); rows = g.nsza * g.nvza
-for nw in (1, 2, 4, 7, 8, 9, 13, 16, 24, 32, 48, 64, 65, 100, 127, 128, 200):
+for nw in [int(x) for x in sys.argv[1:]] or (1, 2, 4, 7, 8, 9, 13, 16, 24, 32, 48, 64, 65, 100, 127, 128, 200):      # argv: band counts (one, under a profiler)
     eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
     lut = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
     for _ in range(3):
