@@ -7,6 +7,7 @@
 #   C. `-energy`: the dense stream forms (measuring build), the CLI end to end (indexed against dense)
 #   D. the ALU / latency bound configs (C2, C3, C4): times, stats, SQ pass, phase stamps
 #   E. member grids below 128 bands: 1000 members x 7 bands (and x 100)
+#   F. the few-band LUT forms across band counts and under the HBM counters; the `-energy` table pass by number of sun directions
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/gpurun_out/prof5
@@ -18,7 +19,7 @@ prof() { # name, then rocprofv3 args..., then -- program
   ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 "$@" ) > "$OUT/$name.log" 2>&1
   echo "$name rc=$?"
 }
-which=${1:-ABCDE}
+which=${1:-ABCDEF}
 if [[ $which == *A* ]]; then
   cd "$R" && timeout -k 10 700 $PY bench.py > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"; echo "bench rc=$?"
   prof bench_stats --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- $PY "$R/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-parity --sustain-s 0 --no-config5 --no-configs --no-traffic --placement-evidence 0
@@ -46,6 +47,11 @@ fi
 if [[ $which == *E* ]]; then
   cd "$R" && timeout -k 10 300 $PY tools/bench_ensemble.py 1000 1000 7 > "$OUT/ensemble_few_bands.log" 2>&1
   cd "$R" && timeout -k 10 300 $PY tools/bench_ensemble.py 1000 250 100 >> "$OUT/ensemble_few_bands.log" 2>&1
+fi
+if [[ $which == *F* ]]; then
+  cd "$R" && timeout -k 10 300 $PY tools/probes/mid_band_grid.py > "$OUT/mid_band_grid.log" 2>&1
+  cd "$R" && timeout -k 10 300 tools/probes/few_band_lut_pmc.sh > "$OUT/few_band_lut_pmc.log" 2>&1
+  cd "$R" && timeout -k 10 300 $PY tools/probes/energy_table_cost.py > "$OUT/energy_table_cost.log" 2>&1
 fi
 # ---- summaries
 cd "$R"
