@@ -279,7 +279,10 @@ int  gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, long nA,
  *   sza = sza0 + i*dsza (i<nsza), vza = vza0 + j*dvza (j<nvza), phi = phi0 + l*dphi (l<nphi)
  *   lut_dev[nsza][nvza][nphi][nw], wavelength fastest.
  * [row_begin,row_end) selects (i,j) rows in flattened order i*nvza+j, so that ranks of a
- * multi-GPU job fill disjoint slabs; lut_dev points at the first selected row. */
+ * multi-GPU job fill disjoint slabs; lut_dev points at the first selected row.
+ * A LUT of any band count is formed with the five-term regrouping of gortt.c:484-557 (the sun enters a sample
+ * through five numbers per (sun zenith, band)); the stream entry points group the same arithmetic around two other terms.
+ * A LUT therefore equals the stream of its nodes to rounding (1e-13 relative), both within 1e-9 of the reference. */
 typedef struct gort_grid {
     double sza0, dsza; int32_t nsza;  int32_t pad0;
     double vza0, dvza; int32_t nvza;  int32_t pad1;
