@@ -147,3 +147,28 @@ def test_q08_canopy_on_the_horizon_matches_the_reference_restatement():
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert relerr(got, want, floor=1e-12) <= 1e-9, relerr(got, want, floor=1e-12)
     e.close()
+
+
+@pytest.mark.parametrize("nw", [1, 7, 9, 16, 64, 100, 127, 128, 300])
+def test_a_lut_equals_the_stream_of_its_nodes_to_rounding(nw):
+    """include/gort_amd.h: a LUT of any band count carries the five-term form of the sample, the stream entry points the form
+    grouped around two other terms - the LUT's nodes streamed as "vza phi sza 0" (gortt.c:232-329) agree to 1e-12, NaN for NaN
+    (the hemisphere's last view zenith is the horizon), mirrored images included.  Below 128 bands the geometry kernel writes the
+    LUT itself (up to 8 bands a lane its node's samples, from 9 lanes as bands), from 128 the LUT kernel expands records."""
+    import torch
+    from conftest import relerr
+    g = _grid((0.0, 22.5, 4), (0.0, 15.0, 7), (0.0, 2.0, 181))           # a full circle: mirrored
+    rows = g.nsza * g.nvza
+    e = api.Engine()
+    e.set_canopy(api.gap_probabilities(api.make_canopy(lai=2.7)))
+    e.set_spectra(*api.spectra(np.linspace(420.0, 2450.0, nw)))
+    lut = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
+    e.rsurf_grid_dev(g, 0, rows, lut)
+    i, j, l = np.meshgrid(np.arange(g.nsza), np.arange(g.nvza), np.arange(g.nphi), indexing="ij")
+    lines = np.stack([g.vza0 + j * g.dvza, g.phi0 + l * g.dphi, g.sza0 + i * g.dsza, np.zeros(i.shape)], -1).reshape(-1, 4)
+    a = torch.as_tensor(lines, device="cuda")
+    out = torch.empty_like(lut)
+    e.rsurf_stream_dev(a, out)
+    e.synchronize()
+    assert relerr(lut.cpu().numpy(), out.cpu().numpy(), floor=1e-6) <= 1e-12
+    e.close()
