@@ -1234,6 +1234,54 @@ def test_c3_full_hemisphere_one_band(eng, golden):
     assert err_K(K, Kref) <= REGRESSION
 
 
+@pytest.mark.parametrize("nw", [7, 100])
+def test_full_hemisphere_lut_of_a_few_bands(eng, nw):
+    """The hemisphere of config 3 as a LUT of 7 bands (the MODIS land bands of the reference's README.md:8-9) and of 100 (the band
+    counts its command line can read), written by the geometry kernel itself (gort_geometry.hip: up to 8 bands a lane its node's
+    samples turned through LDS, from 9 lanes as bands): a seeded sample of nodes against the oracle to 1e-9, NaN exactly where a
+    zenith is 90 degrees, every image equal to its original (a full circle is evaluated over 0 ... 180 degrees and written
+    twice), and the whole LUT against the stream of its nodes to rounding."""
+    import torch
+    c = gpu_canopy(lai=4.0)
+    wl = np.array([469.0, 555.0, 645.0, 858.5, 1240.0, 1640.0, 2130.0]) if nw == 7 else np.linspace(400.0, 2500.0, nw)
+    rs, rl, tl = api.spectra(wl)
+    eng.set_canopy(c); eng.set_spectra(rs, rl, tl)
+    g = _full_grid()
+    rows = g.nsza * g.nvza
+    lut = torch.full((rows * g.nphi * nw + 32,), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    eng.rsurf_grid_dev(g, 0, rows, lut[:rows * g.nphi * nw])
+    eng.synchronize()
+    assert float(lut[rows * g.nphi * nw:].max()) == -7.0
+    full = lut[:rows * g.nphi * nw].view(g.nsza, g.nvza, g.nphi, nw)
+    nan = torch.isnan(full)
+    want = torch.zeros_like(nan)
+    want[90] = True
+    want[:, 90] = True
+    assert bool((nan == want).all())
+    assert torch.equal(full[:89, :89, 1:180].view(torch.int64), full[:89, :89, 181:360].flip(2).view(torch.int64))
+    rng = np.random.default_rng(nw)
+    idx = rng.integers(0, rows * g.nphi, 400)
+    r, l = idx // g.nphi, idx % g.nphi
+    ang = np.stack([(r % g.nvza).astype(float), l.astype(float), (r // g.nvza).astype(float), np.zeros(idx.size)], 1)
+    ref, _, _ = O.rsurf_stream(oracle_like(c), ang, rs, rl, tl, want_K=False)
+    got = full.view(-1, nw)[torch.as_tensor(idx, device="cuda")].cpu().numpy()
+    assert err(got, ref) <= REGRESSION
+    # the stream of the LUT's nodes, a sun zenith at a time
+    j, ll = np.meshgrid(np.arange(g.nvza), np.arange(g.nphi), indexing="ij")
+    worst = 0.0
+    out = torch.empty((g.nvza * g.nphi, nw), dtype=torch.float64, device="cuda")
+    for isza in (0, 30, 60, 89, 90):
+        lines = np.stack([j.astype(float), ll.astype(float), np.full(j.shape, float(isza)), np.zeros(j.shape)], -1).reshape(-1, 4)
+        eng.rsurf_stream_dev(torch.as_tensor(lines, device="cuda"), out)
+        eng.synchronize()
+        a, b = full[isza].reshape(-1, nw), out
+        assert bool((torch.isnan(a) == torch.isnan(b)).all())
+        ok = ~torch.isnan(a)
+        worst = max(worst, float(((a[ok] - b[ok]).abs() / b[ok].abs().clamp_min(1e-6)).max()) if bool(ok.any()) else 0.0)
+    assert worst <= 1e-12
+
+
 def test_metric_grid_full_size_properties(eng):
     """The benchmark workload itself (2 989 441 tuples x 2101 bands, 50 GB): properties that do not need a
     CPU pass over 6e9 samples.
