@@ -73,6 +73,7 @@ struct gort_engine {
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
     DevBuf edup;                         // sun-direction table of the energy path (gort_energy.hip)
+    DevBuf mbands;                       // gort_rsurf_members_stream through the line kernel: the members' StreamBand tables
     bool energy_dedup = true;            // GORT_ENERGY_DEDUP=0: every line evaluated (tests compare the two)
     int stream_form = 0;                 // kernel family of the last stream call: 0 narrow, 1 flat panels (gort_amd_tuning.h)
     hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call, if asked for
@@ -342,7 +343,7 @@ extern "C" void gort_engine_destroy(gort_engine *e)
     e->hpipe = nullptr;
     if (e->aux) (void)hipStreamSynchronize(e->aux);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->gcoef[0], &e->gcoef[1], &e->gsun[0], &e->gsun[1]}) b->release();
+    for (DevBuf *b : {&e->gcoef[0], &e->gcoef[1], &e->gsun[0], &e->gsun[1], &e->mbands}) b->release();
     for (hipEvent_t ev : {e->ev_tables, e->ev_geom[0], e->ev_geom[1], e->ev_expand[0], e->ev_expand[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
@@ -670,7 +671,7 @@ extern "C" int gort_rsurf_stream_dev(gort_engine *e, const double *angles_dev, l
     // 17 ... ~250 bands (all the reference's command line can read): one kernel from the angle line to its row
     if (stream_takes_lines_kernel(e->nw, nA, scomp_dev != nullptr)) {
         if (timed) GORT_HIP(hipEventRecord(e->ev_stream[0], e->stream));
-        rc = launch_stream_lines(e->canopy.as<gort_canopy>(), stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw,
+        rc = launch_stream_lines(e->canopy.as<gort_canopy>(), 1, stream_band_table(e->L.as<double>(), e->nw, e->n_members), e->nw,
                                  angles_dev, nA, rsurf_dev, K_dev, e->stream);
         if (timed) GORT_HIP(hipEventRecord(e->ev_stream[1], e->stream));
         e->stream_form = 2;
@@ -874,6 +875,16 @@ extern "C" int gort_rsurf_members_stream_dev(gort_engine *e, const double *angle
         return fail(GORT_EINVAL, "gort_rsurf_members_stream_dev: bad argument");
     const int nm = member_end - member_begin;
     if (nA == 0 || nm == 0) return GORT_OK;
+    // the line kernel's band counts (17 ... 255, to 600 off the 128-band grid), the member in blockIdx.y: geometry and samples in
+    // one launch, rows as whole cache lines - a thousand members x 2000 lines x 100 bands in 0.5 ms where records + one thread
+    // per sample took 1.9 (a cliff at 17 bands: 16 bands, the fused kernel, 0.19 ms; 17 bands 0.52)
+    if (stream_takes_lines_kernel(e->nw, nA * (long)nm, false)) {
+        const double *Lm = e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw;
+        if ((rc = e->mbands.reserve(sizeof(double) * STREAM_BAND_TABLE_DOUBLES * (size_t)e->nw * (size_t)nm))) return rc;
+        if ((rc = launch_member_stream_bands(Lm, nm, e->nw, e->mbands.as<double>(), e->stream))) return rc;
+        return launch_stream_lines(e->canopy.as<gort_canopy>() + member_begin, nm, e->mbands.as<double>(), e->nw, angles_dev, nA,
+                                   rsurf_dev, nullptr, e->stream);
+    }
     if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA * (size_t)nm))) return rc;
     return launch_members_stream(e->canopy.as<gort_canopy>() + member_begin, nm,
                                  e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw, e->nw, angles_dev, nA,

@@ -90,6 +90,11 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
 {
     extern __shared__ __attribute__((aligned(16))) double s_ring[];
     const int lane = threadIdx.x;
+    // blockIdx.y = ensemble member (gort_rsurf_members_stream: the same angle lines for every member): its canopy, its band
+    // constants, its nA rows of the output
+    canopy += blockIdx.y;
+    bands += (long)blockIdx.y * nw;
+    out += (long)blockIdx.y * nA * nw;
     GORT_STAMPS_BEGIN();
     GORT_STAMP(0);
     const long a0 = (long)blockIdx.x * 64;
@@ -296,10 +301,11 @@ bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp)
     return nw <= LINES_MAX_BANDS || (nw <= LINES_MAX_BANDS_OFF_GRID && nw % 128 != 0);
 }
 
-int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_dev, int nw, const double *angles_dev, long nA,
-                        double *rsurf_dev, double *K_dev, void *stream)
+int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const double *band_table_dev, int nw, const double *angles_dev,
+                        long nA, double *rsurf_dev, double *K_dev, void *stream)
 {
-    if (nA <= 0) return GORT_OK;
+    if (nA <= 0 || n_members <= 0) return GORT_OK;
+    if (n_members > 65535 || (n_members > 1 && K_dev)) return fail(GORT_EINVAL, "stream lines kernel: %d members", n_members);
     if (!band_table_dev) return fail(GORT_EINVAL, "stream lines kernel: no band table");
     if (nw < LINES_MIN_BANDS) return fail(GORT_EINVAL, "stream lines kernel: %d bands (needs at least %d)", nw, LINES_MIN_BANDS);
     const long blocks = (nA + 63) / 64;
@@ -313,11 +319,11 @@ int launch_stream_lines(const gort_canopy *canopy_dev, const double *band_table_
 #ifdef GORT_AB
     static const bool nt = !(ab_env("GORT_EXPAND_NT") && atoi(ab_env("GORT_EXPAND_NT")) == 0);
     if (!nt)
-        hipLaunchKernelGGL(stream_lines_kernel<false>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
+        hipLaunchKernelGGL(stream_lines_kernel<false>, dim3((unsigned)blocks, (unsigned)n_members), dim3(64), lds, (hipStream_t)stream, canopy_dev,
                            angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
     else
 #endif
-        hipLaunchKernelGGL(stream_lines_kernel<true>, dim3((unsigned)blocks), dim3(64), lds, (hipStream_t)stream, canopy_dev,
+        hipLaunchKernelGGL(stream_lines_kernel<true>, dim3((unsigned)blocks, (unsigned)n_members), dim3(64), lds, (hipStream_t)stream, canopy_dev,
                            angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
     return check_launch("stream_lines_kernel");
 }

@@ -50,6 +50,16 @@ __global__ __launch_bounds__(256) void lambda_table_kernel(const gort_canopy *__
     if (m == 0 && stream_bands) stream_bands[i] = stream_band(load_band(L, nw, i));
 }
 
+// the twelve StreamBand constants per band of every member, out[m][nw] (the line kernel's scalar loads; the engine's own
+// table behind L is the first member's)
+__global__ __launch_bounds__(256) void member_stream_bands_kernel(const double *__restrict__ Lall, int nw, StreamBand *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const long m = blockIdx.y;
+    out[m * nw + i] = stream_band(load_band(Lall + m * L_NSLOT * nw, nw, i));
+}
+
 // sun[q - q_begin][5][nw] with q = member * nsza + isza: the "sun rows" of an ensemble are (member, sun zenith)
 __global__ __launch_bounds__(256) void sun_table_kernel(const gort_canopy *__restrict__ canopies,
                                                          const double *__restrict__ Lall, int nw, gort_grid g,
@@ -84,6 +94,15 @@ int launch_lambda_table(const gort_canopy *canopies_dev, int n_members, int nw, 
     hipLaunchKernelGGL(lambda_table_kernel, dim3((nw + 255) / 256, n_members), dim3(256), 0, (hipStream_t)stream,
                        canopies_dev, nw, spectra_dev, L_dev, reinterpret_cast<StreamBand *>(L_dev + stream_band_table_offset(nw, n_members)));
     return check_launch("lambda_table_kernel");
+}
+
+int launch_member_stream_bands(const double *L_dev, int n_members, int nw, double *bands_dev, void *stream)
+{
+    if (nw <= 0 || n_members <= 0) return GORT_OK;
+    if (n_members > 65535) return fail(GORT_EINVAL, "band tables: %d members in one launch (max 65535)", n_members);
+    hipLaunchKernelGGL(member_stream_bands_kernel, dim3((nw + 255) / 256, n_members), dim3(256), 0, (hipStream_t)stream, L_dev, nw,
+                       reinterpret_cast<StreamBand *>(bands_dev));
+    return check_launch("member_stream_bands_kernel");
 }
 
 int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int nw, const gort_grid &g, int q_begin,

@@ -1569,6 +1569,51 @@ def test_members_stream_equals_forward_runs():
         Ensemble(wl).set_states(states[:2]).eng.rsurf_members_stream(angles, 1, 5)
 
 
+@pytest.mark.parametrize("nw", [17, 100, 300])
+def test_members_stream_through_the_line_kernel(nw):
+    """gort_rsurf_members_stream_dev at the line kernel's band counts (17 ... 255, to 600 off the 128-band grid): the member is
+    the kernel's second grid dimension, every member with its own canopy and band constants.  40 members x 800 lines (a ragged
+    last wave) bit for bit the single-canopy stream of each member (the narrow kernels there: below 262 144 samples), and a member
+    sub-range at the sub-range's own base."""
+    import torch
+    from gort_amd.ensemble import DEFAULT, Ensemble
+    rng = np.random.default_rng(170 + nw)
+    wl = np.linspace(420.0, 2400.0, nw)
+    n, M = 800, 40
+    angles = np.stack([rng.uniform(-80, 80, n), rng.uniform(-360, 360, n), rng.uniform(0, 85, n), rng.uniform(0, 360, n)], 1)
+    states = []
+    for _ in range(M):
+        s_ = dict(DEFAULT)
+        s_.update(HB=rng.uniform(1, 3), BR=rng.uniform(1, 3.5), PCC=rng.uniform(0.2, 0.8), LAI=rng.uniform(0.5, 6),
+                  N=rng.uniform(1, 2.5), Cab=rng.uniform(10, 60), Cw=rng.uniform(0.005, 0.03), Cm=rng.uniform(0.002, 0.015))
+        states.append(s_)
+    ens = Ensemble(wl).set_states(states)
+    a = torch.as_tensor(angles, device="cuda")
+    out = torch.full((M * n * nw + 16,), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    api._check(api.lib().gort_rsurf_members_stream_dev(ens.eng.h, api._ptr(a), n, 0, M, api._ptr(out)))
+    ens.eng.synchronize()
+    assert float(out[M * n * nw:].max()) == -7.0
+    got = out[:M * n * nw].view(M, n, nw)
+    assert not bool((got == -7.0).any())
+    single = api.Engine()
+    one = torch.empty((n, nw), dtype=torch.float64, device="cuda")
+    for m in (0, 17, M - 1):
+        c, rs, rl, tl = ens.eng.get_member(m)
+        single.set_canopy(c)
+        single.set_spectra(rs, rl, tl)
+        single.rsurf_stream_dev(a, one)
+        single.synchronize()
+        assert single.stream_form() == "narrow"
+        assert torch.equal(got[m].view(torch.int64), one.view(torch.int64)), (nw, m)
+    part = torch.empty((7, n, nw), dtype=torch.float64, device="cuda")
+    api._check(api.lib().gort_rsurf_members_stream_dev(ens.eng.h, api._ptr(a), n, 20, 27, api._ptr(part)))
+    ens.eng.synchronize()
+    assert torch.equal(part.view(torch.int64), got[20:27].contiguous().view(torch.int64))
+    single.close()
+    ens.close()
+
+
 def test_finite_difference_jacobian_is_the_forward_model():
     """The Jacobian is nothing but forward runs: each column equals the central difference of two oracle runs
     at the same (float32-rounded) parameters, and the ensemble of 2P+1 members ran in one launch pair."""
