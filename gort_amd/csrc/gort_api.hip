@@ -875,10 +875,10 @@ extern "C" int gort_rsurf_members_stream_dev(gort_engine *e, const double *angle
         return fail(GORT_EINVAL, "gort_rsurf_members_stream_dev: bad argument");
     const int nm = member_end - member_begin;
     if (nA == 0 || nm == 0) return GORT_OK;
-    // the line kernel's band counts (17 ... 255, to 600 off the 128-band grid), the member in blockIdx.y: geometry and samples in
-    // one launch, rows as whole cache lines - a thousand members x 2000 lines x 100 bands in 0.5 ms where records + one thread
-    // per sample took 1.9 (a cliff at 17 bands: 16 bands, the fused kernel, 0.19 ms; 17 bands 0.52)
-    if (stream_takes_lines_kernel(e->nw, nA * (long)nm, false)) {
+    // from 17 bands: the line kernel, the member in blockIdx.y - geometry and samples in one launch, rows as whole cache lines: a
+    // thousand members x 2000 lines x 100 bands in 0.58 ms where records + one thread per sample took 1.9 (a cliff at 17 bands:
+    // 16 bands, the fused kernel, 0.19 ms; 17 bands 0.52).  Any band count: the flat-panel kernel has no member dimension
+    if (members_stream_takes_lines_kernel(e->nw, nA * (long)nm)) {
         const double *Lm = e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw;
         if ((rc = e->mbands.reserve(sizeof(double) * STREAM_BAND_TABLE_DOUBLES * (size_t)e->nw * (size_t)nm))) return rc;
         if ((rc = launch_member_stream_bands(Lm, nm, e->nw, e->mbands.as<double>(), e->stream))) return rc;

@@ -301,6 +301,13 @@ bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp)
     return nw <= LINES_MAX_BANDS || (nw <= LINES_MAX_BANDS_OFF_GRID && nw % 128 != 0);
 }
 
+// the same lines for several members: the flat-panel kernel has no member dimension, so the line kernel keeps every band count
+// from 17 (a thousand members x 2000 lines x 2101 bands: 0.61 of HBM against 0.11 through records + one thread per sample)
+bool members_stream_takes_lines_kernel(int nw, long lines_of_all_members)
+{
+    return nw >= LINES_MIN_BANDS && lines_of_all_members * (long)nw >= (1L << 18);
+}
+
 int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const double *band_table_dev, int nw, const double *angles_dev,
                         long nA, double *rsurf_dev, double *K_dev, void *stream)
 {

@@ -1569,9 +1569,9 @@ def test_members_stream_equals_forward_runs():
         Ensemble(wl).set_states(states[:2]).eng.rsurf_members_stream(angles, 1, 5)
 
 
-@pytest.mark.parametrize("nw", [17, 100, 300])
+@pytest.mark.parametrize("nw", [17, 100, 300, 640])
 def test_members_stream_through_the_line_kernel(nw):
-    """gort_rsurf_members_stream_dev at the line kernel's band counts (17 ... 255, to 600 off the 128-band grid): the member is
+    """gort_rsurf_members_stream_dev from 17 bands (any band count: the flat-panel kernel has no member dimension): the member is
     the kernel's second grid dimension, every member with its own canopy and band constants.  40 members x 800 lines (a ragged
     last wave) bit for bit the single-canopy stream of each member (the narrow kernels there: below 262 144 samples), and a member
     sub-range at the sub-range's own base."""
@@ -1579,7 +1579,7 @@ def test_members_stream_through_the_line_kernel(nw):
     from gort_amd.ensemble import DEFAULT, Ensemble
     rng = np.random.default_rng(170 + nw)
     wl = np.linspace(420.0, 2400.0, nw)
-    n, M = 800, 40
+    n, M = (800 if nw <= 300 else 400), 40            # (the single-canopy stream below stays under 262 144 samples: narrow kernels)
     angles = np.stack([rng.uniform(-80, 80, n), rng.uniform(-360, 360, n), rng.uniform(0, 85, n), rng.uniform(0, 360, n)], 1)
     states = []
     for _ in range(M):
