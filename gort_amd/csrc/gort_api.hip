@@ -73,7 +73,8 @@ struct gort_engine {
     DevBuf canopy, spectra, L, coef, K, sun, nodes, angles, out, out2;
     DevBuf leaf, wl, tab_coef, tab_t12, tab_talf, tab_eof;
     DevBuf edup;                         // sun-direction table of the energy path (gort_energy.hip)
-    DevBuf mbands;                       // gort_rsurf_members_stream through the line kernel: the members' StreamBand tables
+    DevBuf mbands;                       // gort_rsurf_members_stream through the line kernel: the members' StreamBand tables,
+    bool mbands_current = false;         // built with the first call behind a setter (every setter ends in refresh_lambda_table)
     bool energy_dedup = true;            // GORT_ENERGY_DEDUP=0: every line evaluated (tests compare the two)
     int stream_form = 0;                 // kernel family of the last stream call: 0 narrow, 1 flat panels (gort_amd_tuning.h)
     hipEvent_t ev_stream[2] = {nullptr, nullptr};     // around the expansion of the last stream call, if asked for
@@ -442,6 +443,7 @@ static int refresh_lambda_table(gort_engine *e)
         rc = launch_lambda_table(e->canopy.as<gort_canopy>(), e->n_members, e->nw, e->spectra.as<double>(),
                                  e->L.as<double>(), e->stream);
     }
+    e->mbands_current = false;
     GORT_HIP(hipEventRecord(e->ev_tables, e->stream));
     e->tables_recorded = true;
     return rc;
@@ -878,12 +880,17 @@ extern "C" int gort_rsurf_members_stream_dev(gort_engine *e, const double *angle
     // from 17 bands: the line kernel, the member in blockIdx.y - geometry and samples in one launch, rows as whole cache lines: a
     // thousand members x 2000 lines x 100 bands in 0.58 ms where records + one thread per sample took 1.9 (a cliff at 17 bands:
     // 16 bands, the fused kernel, 0.19 ms; 17 bands 0.52).  Any band count: the flat-panel kernel has no member dimension
-    if (members_stream_takes_lines_kernel(e->nw, nA * (long)nm)) {
-        const double *Lm = e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw;
-        if ((rc = e->mbands.reserve(sizeof(double) * STREAM_BAND_TABLE_DOUBLES * (size_t)e->nw * (size_t)nm))) return rc;
-        if ((rc = launch_member_stream_bands(Lm, nm, e->nw, e->mbands.as<double>(), e->stream))) return rc;
-        return launch_stream_lines(e->canopy.as<gort_canopy>() + member_begin, nm, e->mbands.as<double>(), e->nw, angles_dev, nA,
-                                   rsurf_dev, nullptr, e->stream);
+    if (members_stream_takes_lines_kernel(e->nw, nA, nm)) {
+        // the members' StreamBand tables (96 B per member and band: 200 MB for 1000 x 2101): of the whole ensemble, once per setter
+        // call - a filter asks for its observations many times per cycle, and the 95 us of this kernel were 2 % of every call
+        const size_t per_member = STREAM_BAND_TABLE_DOUBLES * (size_t)e->nw;
+        if (!e->mbands_current) {
+            if ((rc = e->mbands.reserve(sizeof(double) * per_member * (size_t)e->n_members))) return rc;
+            if ((rc = launch_member_stream_bands(e->L.as<double>(), e->n_members, e->nw, e->mbands.as<double>(), e->stream))) return rc;
+            e->mbands_current = true;
+        }
+        return launch_stream_lines(e->canopy.as<gort_canopy>() + member_begin, nm, e->mbands.as<double>() + per_member * (size_t)member_begin,
+                                   e->nw, angles_dev, nA, rsurf_dev, nullptr, e->stream);
     }
     if ((rc = e->coef.reserve(sizeof(double) * GORT_COEF_STRIDE * (size_t)nA * (size_t)nm))) return rc;
     return launch_members_stream(e->canopy.as<gort_canopy>() + member_begin, nm,

@@ -153,7 +153,7 @@ int launch_expand_grid_members(const gort_canopy *canopies_dev, const double *L_
 // ---- streams of 17 ... ~250 bands without component spectra (gort_stream_lines.hip): geometry and samples in one kernel,
 // lanes = lines, rows leave LDS as whole 128-B lines whatever the band count; band_table_dev as above
 bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp);
-bool members_stream_takes_lines_kernel(int nw, long lines_of_all_members);
+bool members_stream_takes_lines_kernel(int nw, long lines_per_member, int n_members);
 // n_members > 1: the same lines for canopy_dev[m] with band_table_dev[m][nw][12], rows rsurf_dev[m][nA][nw] (K_dev null)
 int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const double *band_table_dev, int nw, const double *angles_dev,
                         long nA, double *rsurf_dev, double *K_dev, void *stream);

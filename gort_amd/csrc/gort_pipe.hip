@@ -228,16 +228,24 @@ extern "C" int gort_pipe_submit(gort_pipe *p, long n)
             s.energy_rows = (long)*static_cast<volatile uint32_t *>(s.h_rows);
             if (s.energy_rows > s.energy_cap) {
                 // more distinct rows than the slot has room for: nothing of this slot is in flight (the chunk that used it last has
-                // been released), so its buffers can be exchanged for bigger ones here
+                // been released), so its buffers can be exchanged for bigger ones here.  The new ones first: a slot whose allocation
+                // fails keeps what it had (the chunk fails with GORT_ENOMEM, the chunks in flight and the slot stay whole)
                 long cap = 2 * s.energy_cap > s.energy_rows ? 2 * s.energy_cap : s.energy_rows;
                 if (cap > p->max_lines) cap = p->max_lines;
+                double *h_new = nullptr, *d_new = nullptr;
+                const size_t bytes = D * 3 * (size_t)cap * nw;
+                const bool mock_failure = ab_env("GORT_PIPE_FAIL_GROW") != nullptr;          // measuring build: the test of this path
+                hipError_t err = mock_failure ? hipErrorOutOfMemory : hipHostMalloc((void **)&h_new, bytes, hipHostMallocDefault);
+                if (err == hipSuccess && (err = hipMalloc((void **)&d_new, bytes)) != hipSuccess) (void)hipHostFree(h_new);
+                if (err != hipSuccess) {
+                    (void)hipGetLastError();
+                    return fail(err == hipErrorOutOfMemory ? GORT_ENOMEM : GORT_ENODEVICE, "gort_pipe_submit: %ld distinct sun directions in "
+                                "one chunk need %zu bytes of row buffers twice (pinned and device): %s", s.energy_rows, bytes, hipGetErrorString(err));
+                }
                 PIPE_HIP(hipHostFree(s.h_energy));
-                s.h_energy = nullptr;
+                s.h_energy = h_new;
                 PIPE_HIP(hipFree(s.d_energy));
-                s.d_energy = nullptr;
-                s.energy_cap = 0;
-                PIPE_HIP(hipHostMalloc((void **)&s.h_energy, D * 3 * (size_t)cap * nw, hipHostMallocDefault));
-                PIPE_HIP(hipMalloc((void **)&s.d_energy, D * 3 * (size_t)cap * nw));
+                s.d_energy = d_new;
                 s.energy_cap = cap;
             }
         }

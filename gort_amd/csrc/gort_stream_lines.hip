@@ -81,34 +81,128 @@ __device__ __forceinline__ void emit_cache_line(const double *__restrict__ ring,
     }
 }
 
+// What a member's waves read of its StreamBand table (96 B per band: 200 KB at 2101 bands, another for every member) a little
+// ahead of the scalar loads, into the XCD's L2: 32 consecutive 128-B lines per instruction, a dword each, straight into LDS
+// (global_load_lds: no destination register; nothing ever waits for them or reads what they bring).  One canopy's table is hot in
+// every L2 after the first waves; with a thousand members every wave found its band constants in HBM (or the Infinity Cache) and
+// the band loop - one request ahead, ~150 ns of cover - waited: 69 % of a wave's life at 2101 bands, and every table was fetched
+// eight times, once per XCD (FETCH_SIZE 1.6 GB per launch; profiles/r06/members_stream_counters.log).
+// WHERE in LDS: ring row 0 - the cache line in front of the wave's first row - holds that row's head in ONE of its two
+// 16-double halves and is read there only; the other half is dead for the whole life of the wave: 128 bytes, 32 lanes.  (256 bytes
+// of their own behind the rings cost a wave per CU wherever the pitch is 34: eight instead of nine.)
+struct TouchRange {
+    const char *base;       // the first byte's 128-B line
+    int n_lines;            // lines up to the one of the last byte
+    int lead;               // bytes between `base` and the first byte
+};
+__device__ __forceinline__ TouchRange touch_range(const void *first, long bytes)
+{
+    const uintptr_t a = reinterpret_cast<uintptr_t>(first);
+    TouchRange r;
+    r.lead = (int)(a & 127);
+    r.base = reinterpret_cast<const char *>(a - r.lead);
+    r.n_lines = (int)((r.lead + bytes + 127) >> 7);
+    return r;
+}
+constexpr int TOUCH_LANES = 32;
+// lines first_line + lane of the range (those behind its end: the last one again), a dword of each; lanes 0 ... 31
+__device__ __forceinline__ void touch_lines(const TouchRange &r, int first_line, int lane, double *dead_half)
+{
+    typedef __attribute__((address_space(1))) const void global_cv;
+    typedef __attribute__((address_space(3))) void lds_v;
+    if (lane < TOUCH_LANES) {
+        int line = first_line + lane;
+        line = line < r.n_lines ? line : r.n_lines - 1;
+        __builtin_amdgcn_global_load_lds((global_cv *)(r.base + 128L * line), (lds_v *)dead_half, 4, 0, 0);
+    }
+}
+constexpr int TOUCH_AHEAD_LINES = 192;          // = 256 bands: six instructions at the start of a wave, under its geometry
+constexpr int TOUCH_EVERY_BLOCKS = 2;           // then 32 lines (of which 24 are new) every two band blocks
+constexpr int TOUCH_MIN_BANDS = 160;            // below, the XCD-local mapping alone does it: the member's first wave has fetched the
+                                                // 10 KB of a 100-band table before the others get to their bands (1000 members x 1000
+                                                // lines x 100 / 200 / 640 / 2101 bands, with | without: 233 | 229-235, 383 | 395-403,
+                                                // 1180-1244 | 1362-1377, 3490-3520 | 4267-4306 us; profiles/r06/members_stream_ab.log)
+
 // ring rows: 0 = the cache line in front of the wave's first row (its head only), 1 + l = line l of the wave
-template <bool NT>
+// MEMBERS (gort_rsurf_members_stream: the same angle lines for every member): a one-dimensional grid of members x waves_per_member
+// waves (+ up to 7), XCD x - which takes the workgroups x, x + 8, ... of a launch - works through the contiguous range x of them,
+// so the waves of a member share one L2: its band table is fetched from memory once (not once per XCD), the first wave to touch a
+// line fetches it for the others, and every XCD writes one window of the output, as in the LUT kernel.
+template <bool NT, bool MEMBERS>
 __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__restrict__ canopy,
                                                           const double *__restrict__ angles, long nA,
                                                           const StreamBand *__restrict__ bands, int nw, int pitch,
-                                                          double *__restrict__ out, double *__restrict__ K)
+                                                          double *__restrict__ out, double *__restrict__ K,
+                                                          unsigned waves_per_member, unsigned total_waves)
 {
     extern __shared__ __attribute__((aligned(16))) double s_ring[];
     const int lane = threadIdx.x;
-    // blockIdx.y = ensemble member (gort_rsurf_members_stream: the same angle lines for every member): its canopy, its band
-    // constants, its nA rows of the output
-    canopy += blockIdx.y;
-    bands += (long)blockIdx.y * nw;
-    out += (long)blockIdx.y * nA * nw;
+    unsigned wave_of_member = blockIdx.x;
+    if (MEMBERS) {
+        const unsigned per_xcd = (total_waves + 7) >> 3;
+        const unsigned j = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (j >= total_waves) return;
+        const unsigned member = j / waves_per_member;
+        wave_of_member = j - member * waves_per_member;
+        canopy += member;
+        bands += (long)member * nw;
+        out += (long)member * nA * nw;
+    }
     GORT_STAMPS_BEGIN();
     GORT_STAMP(0);
-    const long a0 = (long)blockIdx.x * 64;
+    const long a0 = (long)wave_of_member * 64;
     const int lines_here = nA - a0 < 64 ? (int)(nA - a0) : 64;
     const bool live = lane < lines_here;
     const long a = a0 + (live ? lane : lines_here - 1);       // lanes behind the stream compute the last line again, store nothing
+
+    // ---- where the wave's span lies: positions are relative to `origin`, a 256-B aligned address at or below its
+    // first element (never dereferenced below `out`)
+    const int base_off = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & (RING - 1));
+    const long G0 = base_off + a0 * nw;
+    const int g0 = (int)(G0 & (RING - 1));
+    // ring row 0 is read at the seams only, 16 doubles from (((g0 + 15) & ~15) - 16) & 31: the other half takes the touches
+    double *const dead_half = s_ring + (((((g0 + 15) & ~15) - 16) & (RING - 1)) ^ 16);
 
     // ---- the line: geometry -> record -> line terms, all in registers
     const gort_canopy &c = *canopy;
     LineTerms l;
     {
         const double *ap = angles + 4 * a;
+        double in_vza, in_vaa, in_sza, in_saa;
+        if (MEMBERS && nw >= TOUCH_MIN_BANDS) {
+            // the line's angles, then the first touches - of the canopy record and of the band table's first TOUCH_AHEAD_LINES lines -
+            // and a wait for the angles ALONE (the counter retires in order; the compiler would wait for all nine, a trip to HBM at
+            // the head of every wave: written out, M0 - the LDS address of global_load_lds - put back as it was)
+            static_assert(TOUCH_AHEAD_LINES == 6 * TOUCH_LANES, "six touches of the band table below");
+            const TouchRange cr = touch_range(canopy, sizeof(gort_canopy)), tr = touch_range(bands, (long)nw * (long)sizeof(StreamBand));
+            auto line_of = [&](const TouchRange &r, int first) {
+                int line = first + (lane & (TOUCH_LANES - 1));
+                line = line < r.n_lines ? line : r.n_lines - 1;
+                return r.base + 128L * line;
+            };
+            const char *tc = line_of(cr, 0), *t0 = line_of(tr, 0), *t1 = line_of(tr, 32), *t2 = line_of(tr, 64), *t3 = line_of(tr, 96),
+                       *t4 = line_of(tr, 128), *t5 = line_of(tr, 160);
+            typedef __attribute__((address_space(3))) void lds_v;
+            const unsigned scratch = (unsigned)(uintptr_t)(lds_v *)dead_half;
+            dbl2 lo, hi;
+            unsigned m0_was;
+            unsigned long long exec_was;
+            asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                         "s_mov_b32 %2, m0\n\ts_mov_b32 m0, %12\n\t"
+                         "s_mov_b64 %3, exec\n\ts_mov_b32 exec_hi, 0\n\t"
+                         "global_load_lds_dword %5, off\n\tglobal_load_lds_dword %6, off\n\tglobal_load_lds_dword %7, off\n\t"
+                         "global_load_lds_dword %8, off\n\tglobal_load_lds_dword %9, off\n\tglobal_load_lds_dword %10, off\n\t"
+                         "global_load_lds_dword %11, off\n\t"
+                         "s_mov_b64 exec, %3\n\ts_mov_b32 m0, %2\n\ts_waitcnt vmcnt(7)"
+                         : "=&v"(lo), "=&v"(hi), "=&s"(m0_was), "=&s"(exec_was)
+                         : "v"(ap), "v"(tc), "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "s"(scratch)
+                         : "memory");
+            in_vza = lo.x;  in_vaa = lo.y;  in_sza = hi.x;  in_saa = hi.y;
+        } else {
+            in_vza = ap[0];  in_vaa = ap[1];  in_sza = ap[2];  in_saa = ap[3];
+        }
         double vza, sza, saa, raa;
-        normalise_angles(ap[0], ap[1], ap[2], ap[3], vza, sza, saa, raa);
+        normalise_angles(in_vza, in_vaa, in_sza, in_saa, vza, sza, saa, raa);
         GeomOut g;
         geometry_core(c, vza, sza, raa, g, K == nullptr);              // reflectances only: gort_geometry.h, row_terms
         double rec[GORT_COEF_STRIDE];
@@ -122,11 +216,6 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
 
     GORT_STAMP_ANCHOR(l.alpha);
     GORT_STAMP(1);                                           // the line's geometry and terms
-    // ---- where the wave's span lies: positions are relative to `origin`, a 256-B aligned address at or below its
-    // first element (never dereferenced below `out`)
-    const int base_off = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & (RING - 1));
-    const long G0 = base_off + a0 * nw;
-    const int g0 = (int)(G0 & (RING - 1));
     double *const origin = out - base_off + (G0 - g0);
     const int pos = g0 + lane * nw;                           // my row starts here
     double *const my_ring = s_ring + (lane + 1) * pitch;
@@ -177,12 +266,13 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         char *const line = origin_bytes + 128L * j;               // wave-uniform
         if (j < n_full_everywhere) {
             // the eight stores in their scalar-base form, spelled out: the compiler forms one 64-bit vector address per store
-            // (it shares the address arithmetic with the predicated path below).  The wait state behind each store is the one
-            // the hardware wants between a store of more than 8 bytes and a write to its data registers.
+            // (it shares the address arithmetic with the predicated path below).  gfx94x / gfx950 want TWO wait states between a
+            // store of more than 8 bytes and a VALU write to its data registers (the compiler emits s_nop 1 for the pattern; its
+            // hazard recognizer does not look inside asm, and what it schedules behind the block may write v[i]).
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" : : "v"(at[i]), "v"(v[i]), "s"(line) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" : : "v"(at[i]), "v"(v[i]), "s"(line) : "memory");
+                if (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" : : "v"(at[i]), "v"(v[i]), "s"(line) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(at[i]), "v"(v[i]), "s"(line) : "memory");
             }
             return;
         }
@@ -221,6 +311,11 @@ __global__ __launch_bounds__(64) void stream_lines_kernel(const gort_canopy *__r
         // A holds the request for band 16 already
         while (t < nw) {
             const int block_end = t + BLOCK_BANDS < nw ? t + BLOCK_BANDS : nw;
+            if (MEMBERS && nw >= TOUCH_MIN_BANDS && (t & (BLOCK_BANDS * TOUCH_EVERY_BLOCKS - 1)) == 0) {        // wave-uniform
+                const TouchRange table = touch_range(bands, (long)nw * (long)sizeof(StreamBand));
+                const int ahead = ((table.lead + t * (int)sizeof(StreamBand)) >> 7) + TOUCH_AHEAD_LINES;
+                if (ahead < table.n_lines) touch_lines(table, ahead, lane, dead_half);
+            }
             while (t + 1 < block_end) {
                 band_wait(A);
                 band_request(B, bands + t + 1);
@@ -302,36 +397,50 @@ bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp)
 }
 
 // the same lines for several members: the flat-panel kernel has no member dimension, so the line kernel keeps every band count
-// from 17 (a thousand members x 2000 lines x 2101 bands: 0.61 of HBM against 0.11 through records + one thread per sample)
-bool members_stream_takes_lines_kernel(int nw, long lines_of_all_members)
+// from 17 (a thousand members x 1000 lines x 2101 bands: 0.60 of HBM against 0.11 through records + one thread per sample).  A wave
+// is 64 lines of ONE member (its band constants come through the scalar unit): with few lines per member the waves are mostly idle
+// lanes, and the narrow path - a thread per sample - keeps the machine busier
+constexpr long MEMBERS_MIN_LINES = 24;
+bool members_stream_takes_lines_kernel(int nw, long lines_per_member, int n_members)
 {
-    return nw >= LINES_MIN_BANDS && lines_of_all_members * (long)nw >= (1L << 18);
+    long min_lines = MEMBERS_MIN_LINES;
+    if (const char *v = ab_env("GORT_MEMBERS_MIN_LINES")) min_lines = atol(v);      // measuring build: tools/probes/members_stream.py
+    return nw >= LINES_MIN_BANDS && lines_per_member >= min_lines && lines_per_member * n_members * (long)nw >= (1L << 18);
 }
 
 int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const double *band_table_dev, int nw, const double *angles_dev,
                         long nA, double *rsurf_dev, double *K_dev, void *stream)
 {
     if (nA <= 0 || n_members <= 0) return GORT_OK;
-    if (n_members > 65535 || (n_members > 1 && K_dev)) return fail(GORT_EINVAL, "stream lines kernel: %d members", n_members);
+    if (n_members > 1 && K_dev) return fail(GORT_EINVAL, "stream lines kernel: %d members", n_members);
     if (!band_table_dev) return fail(GORT_EINVAL, "stream lines kernel: no band table");
     if (nw < LINES_MIN_BANDS) return fail(GORT_EINVAL, "stream lines kernel: %d bands (needs at least %d)", nw, LINES_MIN_BANDS);
     const long blocks = (nA + 63) / 64;
-    if (blocks >= (1L << 31) || (long)nw * 64 + RING >= (1L << 30))
-        return fail(GORT_EINVAL, "stream lines kernel: %ld lines x %d bands in one launch", nA, nw);
+    if (blocks * n_members + 7 >= (1L << 31) || (long)nw * 64 + RING >= (1L << 30))
+        return fail(GORT_EINVAL, "stream lines kernel: %ld lines x %d bands x %d members in one launch", nA, nw, n_members);
     // ring pitch: even (16-B aligned rows); lanes' ring positions differ by nw, so a multiple of four bands wants
     // rows two doubles apart in the banks (two-way conflicts at worst), any other count none
     const int pitch = (nw % 4 == 0) ? RING + 2 : RING;
-    const size_t lds = sizeof(double) * 65 * (size_t)pitch;
     const StreamBand *tb = reinterpret_cast<const StreamBand *>(band_table_dev);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_members > 1) {
+        // members: one dimension, ranges of waves per XCD
+        const unsigned total = (unsigned)(blocks * n_members);
+        const size_t lds = sizeof(double) * 65 * (size_t)pitch;
+        hipLaunchKernelGGL((stream_lines_kernel<true, true>), dim3((total + 7) / 8 * 8), dim3(64), lds, s, canopy_dev, angles_dev, nA, tb, nw,
+                           pitch, rsurf_dev, K_dev, (unsigned)blocks, total);
+        return check_launch("stream_lines_kernel<members>");
+    }
+    const size_t lds = sizeof(double) * 65 * (size_t)pitch;
 #ifdef GORT_AB
     static const bool nt = !(ab_env("GORT_EXPAND_NT") && atoi(ab_env("GORT_EXPAND_NT")) == 0);
     if (!nt)
-        hipLaunchKernelGGL(stream_lines_kernel<false>, dim3((unsigned)blocks, (unsigned)n_members), dim3(64), lds, (hipStream_t)stream, canopy_dev,
-                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
+        hipLaunchKernelGGL((stream_lines_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, s, canopy_dev, angles_dev, nA, tb, nw,
+                           pitch, rsurf_dev, K_dev, 0u, 0u);
     else
 #endif
-        hipLaunchKernelGGL(stream_lines_kernel<true>, dim3((unsigned)blocks, (unsigned)n_members), dim3(64), lds, (hipStream_t)stream, canopy_dev,
-                           angles_dev, nA, tb, nw, pitch, rsurf_dev, K_dev);
+        hipLaunchKernelGGL((stream_lines_kernel<true, false>), dim3((unsigned)blocks), dim3(64), lds, s, canopy_dev, angles_dev, nA, tb, nw,
+                           pitch, rsurf_dev, K_dev, 0u, 0u);
     return check_launch("stream_lines_kernel");
 }
 

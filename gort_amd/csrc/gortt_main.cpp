@@ -108,7 +108,10 @@ int main(int argc, char **argv)
     // rows come from the device in the INDEXED form - each distinct row once + one index per line (GORT_PIPE_ENERGY_INDEXED) -
     // and each is formatted once; GORTT_ENERGY_DENSE=1 keeps a row per line on the device, over PCIe and in the formatter
     const bool energy_dense = o.energy && std::getenv("GORTT_ENERGY_DENSE") && std::atoi(std::getenv("GORTT_ENERGY_DENSE")) != 0;
-    const size_t per_line_out = (size_t)nw * (1 + (o.prnspec ? 4 : 0) + (energy_dense ? 3 : 0)) + 8;
+    // numbers a line leaves in the OUTPUT: in text every line carries its own copy of its albedo row's formatted bytes whether the row
+    // came once per chunk or once per line (without the 3 nw term a chunk of 180 bands was 220 MB of text in the
+    // formatting threads' buffers); only the binary output of the indexed form points at shared rows
+    const size_t per_line_out = (size_t)nw * (1 + (o.prnspec ? 4 : 0) + (o.energy && (energy_dense || !o.binary_out) ? 3 : 0)) + 8;
     size_t chunk_mb = 48;                                        // GORTT_CHUNK_MB: output bytes per chunk
     if (const char *v = std::getenv("GORTT_CHUNK_MB")) { const long m = atol(v); if (m >= 1 && m <= 4096) chunk_mb = (size_t)m; }
     const bool verbose = std::getenv("GORTT_VERBOSE") != nullptr;   // stage timings on stderr

@@ -17,7 +17,7 @@ AB_LIB = os.path.join(ROOT, "gort_amd", "libgort_amd_ab.so")
 AB_SWITCHES = [b"GORT_EXPAND_DEPTH", b"GORT_EXPAND_NT", b"GORT_EXPAND_XCD", b"GORT_EXPAND_STEPS", b"GORT_EXPAND_WAVES", b"GORT_STREAM_WAVES",
                b"GORT_STREAM_STEPS", b"GORT_STREAM_FUSE", b"GORT_GRID_FUSE", b"GORT_GRID_MIRROR", b"GORT_GRID_BY_ROWS", b"GORT_GRID_PIPELINE", b"GORT_GRID_AZ_TABLE",
                b"GORT_LINES_MAX_BANDS", b"GORT_ENERGY_DEDUP", b"GORT_ENERGY_SHARE_ROWS", b"GORT_ENERGY_BATCH", b"GORT_ENERGY_BROADCAST",
-               b"GORT_XCD_CALIBRATE", b"GORT_XCD_WEIGHTS"]
+               b"GORT_XCD_CALIBRATE", b"GORT_XCD_WEIGHTS", b"GORT_PIPE_FAIL_GROW"]
 
 
 def test_the_product_library_has_no_ab_switches():
@@ -87,11 +87,18 @@ def test_ab_forms_on_the_measuring_build(tmp_path):
     cmd = [sys.executable, "-X", "faulthandler", "-m", "pytest", os.path.join(ROOT, "tests"), "-q", "-x", "-m", "gpu and ab", "-p", "no:cacheprovider"]
     run = subprocess.run(cmd, capture_output=True, timeout=2400, env=env, cwd=ROOT)
     if run.returncode < 0:
-        # the child was killed by a signal (seen once in round 5: SIGSEGV a few seconds in, on one box, not reproduced in
-        # three further runs): what it left is printed, and the suite is given ONE more process - a failing test fails again
-        print("A/B child died with signal %d; its output:\n%s\n%s" % (-run.returncode, run.stdout.decode()[-2000:], run.stderr.decode()[-6000:]),
-              file=sys.stderr)
-        run = subprocess.run(cmd, capture_output=True, timeout=2400, env=env, cwd=ROOT)
+        # the child was killed by a signal (seen once in round 5: SIGSEGV a few seconds in, on one box).  The measuring build's
+        # default forms are the product's: a crash of it is a failure, not something a second process may absolve.  What the child
+        # left - pytest's progress and the faulthandler's stacks - is kept as a file (and under gpurun_out/, which travels back)
+        report = "A/B child died with signal %d\n--- stdout ---\n%s\n--- stderr (faulthandler) ---\n%s" % (
+            -run.returncode, run.stdout.decode(errors="replace"), run.stderr.decode(errors="replace"))
+        kept = [str(tmp_path / "ab_child_crash.log")]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            kept.append(os.path.join(ROOT, "gpurun_out", "ab_child_crash_%d.log" % os.getpid()))
+        for path in kept:
+            with open(path, "w") as f:
+                f.write(report)
+        pytest.fail("the A/B suite's process died with signal %d (kept: %s)\n%s" % (-run.returncode, ", ".join(kept), report[-8000:]))
     tail = run.stdout.decode()[-3000:]
     assert run.returncode == 0, "rc %d\n" % run.returncode + tail + "\n--- stderr ---\n" + run.stderr.decode()[-8000:]
     m = re.search(r"(\d+) passed", tail)

@@ -569,7 +569,7 @@ def test_cli_random_command_lines_identical_to_reference():
     (relative differences of 1e-13 meet boundaries 1e-6 apart: a handful of the ~30 000 numbers at most)."""
     cases = json.load(open(os.path.join(GOLDEN, "cli_fuzz_cases.json")))
     assert len(cases) >= 150
-    identical, ulp6, numbers = 0, 0, 0
+    identical, ulp6, numbers, differ_off_the_horizon = 0, 0, 0, 0
     for case, run in zip(cases, _run_cases(cases, encoding="utf-8")):
         out, errtxt = run.stdout.decode("latin-1"), run.stderr.decode("latin-1").replace(api.GORTT_BIN, "gortt")
         assert run.returncode == case["rc"], (case["name"], case["args"], errtxt)
@@ -580,6 +580,7 @@ def test_cli_random_command_lines_identical_to_reference():
             continue
         a, b = out.split("\n"), case["stdout"].split("\n")
         assert len(a) == len(b) and a[0] == b[0], (case["name"], case["args"])
+        ulp6_before = ulp6
         for la, lb in zip(a[1:], b[1:]):
             ta, tb = la.split(), lb.split()
             assert len(ta) == len(tb), (case["name"], la, lb)
@@ -597,9 +598,12 @@ def test_cli_random_command_lines_identical_to_reference():
                 fx, fy = float(x), float(y)
                 assert abs(fx - fy) <= max(1.0000001e-6, 1e-12 * abs(fy)), (case["name"], case["args"], x, y)
                 ulp6 += 1
-    print("cli fuzz: %d of %d outputs byte-identical, %d of %d numbers one unit of the 6th decimal apart" %
-          (identical, len(cases), ulp6, numbers))
-    assert ulp6 <= 20 and identical >= len(cases) - 20
+        differ_off_the_horizon += ulp6 > ulp6_before
+    print("cli fuzz: %d of %d outputs byte-identical (%d of the others differ in rows off a view zenith of 90 degrees), %d of %d numbers "
+          "one unit of the 6th decimal apart" % (identical, len(cases), differ_off_the_horizon, ulp6, numbers))
+    # measured (rounds 3-6): 150 of 160 identical, nine of the ten others in rows at |view zenith| = 90 only, one number of 12 745 a
+    # unit of the sixth decimal apart
+    assert ulp6 <= 3 and differ_off_the_horizon <= 3 and identical >= len(cases) - 12
 
 
 def test_ensemble_layer_against_forward_runs_of_the_reference():
@@ -1569,17 +1573,18 @@ def test_members_stream_equals_forward_runs():
         Ensemble(wl).set_states(states[:2]).eng.rsurf_members_stream(angles, 1, 5)
 
 
-@pytest.mark.parametrize("nw", [17, 100, 300, 640])
+@pytest.mark.parametrize("nw", [17, 100, 300, 640, 2101])
 def test_members_stream_through_the_line_kernel(nw):
-    """gort_rsurf_members_stream_dev from 17 bands (any band count: the flat-panel kernel has no member dimension): the member is
-    the kernel's second grid dimension, every member with its own canopy and band constants.  40 members x 800 lines (a ragged
-    last wave) bit for bit the single-canopy stream of each member (the narrow kernels there: below 262 144 samples), and a member
-    sub-range at the sub-range's own base."""
+    """gort_rsurf_members_stream_dev from 17 bands (any band count: the flat-panel kernel has no member dimension): the waves of
+    all members in one launch, every XCD a contiguous range of them, every member with its own canopy and band constants (its
+    band table touched ahead of the scalar loads).  40 members x 800 lines (a ragged last wave) bit for bit the single-canopy stream
+    of each member (the narrow kernels there: below 262 144 samples), and a member sub-range at the sub-range's own base (7 members:
+    a wave count that is no multiple of 8)."""
     import torch
     from gort_amd.ensemble import DEFAULT, Ensemble
     rng = np.random.default_rng(170 + nw)
     wl = np.linspace(420.0, 2400.0, nw)
-    n, M = (800 if nw <= 300 else 400), 40            # (the single-canopy stream below stays under 262 144 samples: narrow kernels)
+    n, M = (800 if nw <= 300 else 400 if nw <= 640 else 120), 40   # (the single-canopy stream below stays under 262 144 samples: narrow kernels)
     angles = np.stack([rng.uniform(-80, 80, n), rng.uniform(-360, 360, n), rng.uniform(0, 85, n), rng.uniform(0, 360, n)], 1)
     states = []
     for _ in range(M):
@@ -1612,6 +1617,39 @@ def test_members_stream_through_the_line_kernel(nw):
     assert torch.equal(part.view(torch.int64), got[20:27].contiguous().view(torch.int64))
     single.close()
     ens.close()
+
+
+def test_members_stream_full_spectrum_against_the_reference_members(golden):
+    """The observation operator at full spectral size against the REFERENCE: the eight C5 members the reference ran (c5_members.npz:
+    16 lines x 2101 bands each, /root/reference/gortt.c:385-578 once per member) among 24 drawn ones, their sixteen lines five times
+    over (80 lines: a full wave and a ragged one per member; 32 x 80 x 2101 samples take the line kernel)."""
+    import torch
+    g = golden("c5_members.npz")
+    rng = np.random.default_rng(5)
+    canopies, leaf = [], []
+    for i in range(32):
+        if i < 8:
+            hb, br, pcc, lai, cab, cw, cm, N, rsl1 = g["m%d/params" % i]
+        else:
+            hb, br, pcc, lai = (float(np.float32(v)) for v in (rng.uniform(1, 3), rng.uniform(1, 3.5), rng.uniform(0.2, 0.8), rng.uniform(0.5, 6)))
+            cab, cw, cm, N, rsl1 = rng.uniform(10, 60), rng.uniform(0.005, 0.03), rng.uniform(0.002, 0.015), rng.uniform(1, 2.5), rng.uniform(0.05, 0.4)
+        canopies.append(api.make_canopy(newstyle=(hb, br, pcc), lai=lai))
+        leaf.append(api.leaf_soil(prospect=dict(N=N, Cab=cab, Cw=cw, Cm=cm), rsl=(rsl1, 0.1, 0.03726, -0.002426)))
+    order = [3, 0, 5, 1, 7, 2, 6, 4] + list(range(8, 32))          # the reference's members not in front and not in order
+    e = api.Engine()
+    e.set_members_leaf([canopies[i] for i in order], [leaf[i] for i in order], g["wl"], compute_gaps=True)
+    angles = np.tile(g["angles"], (5, 1))
+    n, nw, M = angles.shape[0], g["wl"].size, 32
+    a = torch.as_tensor(angles, device="cuda")
+    out = torch.full((M, n, nw), -7.0, dtype=torch.float64, device="cuda")
+    api._check(api.lib().gort_rsurf_members_stream_dev(e.h, api._ptr(a), n, 0, M, api._ptr(out)))
+    e.synchronize()
+    got = out.cpu().numpy()
+    e.close()
+    assert not (got == -7.0).any()
+    for k in range(8):
+        for rep in range(5):
+            assert err(got[k, 16 * rep:16 * rep + 16], g["m%d/rsurf" % order[k]]) <= REGRESSION, (k, rep)
 
 
 def test_finite_difference_jacobian_is_the_forward_model():

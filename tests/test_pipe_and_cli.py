@@ -143,6 +143,94 @@ def test_pipe_indexed_energy_equals_dense_energy(eng):
         api.Pipe(eng, 16, depth=1, flags=api.PIPE_ENERGY_INDEXED)
 
 
+def _suns_chunk(rng, n, distinct):
+    a = _lines(rng, n, distinct=distinct)
+    if not distinct:
+        a[:, 3] = rng.choice([0.0, 123.0], n)
+    return a
+
+
+def test_pipe_indexed_energy_grows_a_slot(eng):
+    """A slot of the indexed pipe starts with 16 MiB of row buffers (332 rows of 2101 bands) and exchanges them for bigger ones
+    when a chunk has more distinct sun directions than that (gort_pipe.hip, gort_pipe_submit): 700 lines of 2101 bands with every
+    line its own sun - what `gortt -energy` meets on a full-spectrum stream whose lines have their own suns, gortt.c:321-327 - then
+    a chunk of few suns on the grown slot, growth of the other slot by a chunk in between the two capacities, and a chunk that
+    fits what a slot grew to; chunk by chunk the bits of the dense pipe."""
+    rng = np.random.default_rng(23)
+    wl = np.arange(400.0, 2501.0)
+    eng.set_spectra(*api.spectra(wl))
+    assert (16 << 20) // (8 * 3 * wl.size) == 332
+    plan = [(700, False), (700, True), (700, True), (600, False), (700, False), (500, True), (690, True), (0, False), (400, True)]
+    dense_pipe = api.Pipe(eng, 700, depth=2, flags=api.PIPE_ENERGY_ONLY)
+    pipe = api.Pipe(eng, 700, depth=2, flags=api.PIPE_ENERGY_ONLY | api.PIPE_ENERGY_INDEXED)
+    for k, (n, distinct) in enumerate(plan):
+        ang = _suns_chunk(rng, n, distinct)
+        for q in (dense_pipe, pipe):
+            a = q.acquire(); a[:n] = ang; q.submit(n)
+        d, c = dense_pipe.wait(), pipe.wait()
+        assert c["n"] == n == d["n"]
+        if n:
+            want_rows = n if distinct else len({(x, y) for x, y in ang[:, 2:].tolist()})
+            assert c["energy_rows"] == want_rows and c["energy"].shape == (want_rows, wl.size, 3), k
+            assert np.array_equal(c["energy"][c["energy_index"]].view(np.int64), d["energy"].view(np.int64)), k
+        dense_pipe.release(); pipe.release()
+    dense_pipe.close(); pipe.close()
+
+
+@pytest.mark.ab
+def test_pipe_slot_that_cannot_grow_fails_the_chunk_and_stays_whole(eng, monkeypatch):
+    """The allocation of the bigger row buffers fails (GORT_PIPE_FAIL_GROW, measuring build): the chunk fails with GORT_ENOMEM at
+    submit and at wait, the slot keeps the buffers it had - the chunk in flight beside it and the next chunk on the same slot are
+    served - and the pipe closes cleanly."""
+    rng = np.random.default_rng(24)
+    wl = np.arange(400.0, 2501.0)
+    eng.set_spectra(*api.spectra(wl))
+    dense = api.Pipe(eng, 700, depth=1, flags=api.PIPE_ENERGY_ONLY)
+    pipe = api.Pipe(eng, 700, depth=2, flags=api.PIPE_ENERGY_ONLY | api.PIPE_ENERGY_INDEXED)
+    few, many, few2 = _suns_chunk(rng, 700, False), _suns_chunk(rng, 700, True), _suns_chunk(rng, 650, False)
+
+    def dense_rows(ang):
+        a = dense.acquire(); a[:len(ang)] = ang; dense.submit(len(ang))
+        r = dense.wait()["energy"].copy(); dense.release()
+        return r
+    a = pipe.acquire(); a[:700] = few; pipe.submit(700)              # slot 0, in flight
+    monkeypatch.setenv("GORT_PIPE_FAIL_GROW", "1")
+    a = pipe.acquire(); a[:700] = many
+    with pytest.raises(api.GortError, match="distinct sun directions"):
+        pipe.submit(700)                                              # slot 1 cannot grow
+    monkeypatch.delenv("GORT_PIPE_FAIL_GROW")
+    c = pipe.wait()
+    assert np.array_equal(c["energy"][c["energy_index"]].view(np.int64), dense_rows(few).view(np.int64))
+    pipe.release()
+    with pytest.raises(api.GortError):
+        pipe.wait()                                                   # the failed chunk reports its failure
+    pipe.release()
+    a = pipe.acquire(); a[:650] = few2; pipe.submit(650)             # slot 0 again
+    a = pipe.acquire(); a[:700] = many; pipe.submit(700)             # slot 1 again: grows now
+    c = pipe.wait()
+    assert np.array_equal(c["energy"][c["energy_index"]].view(np.int64), dense_rows(few2).view(np.int64))
+    pipe.release()
+    c = pipe.wait()
+    assert c["energy_rows"] == 700 and np.array_equal(c["energy"][c["energy_index"]].view(np.int64), dense_rows(many).view(np.int64))
+    pipe.release()
+    pipe.close(); dense.close()
+
+
+def test_cli_energy_full_spectrum_stream_of_own_suns_grows_the_slots():
+    """`gortt -energy --binary-out` on 1500 lines x 2101 bands, every line its own sun direction (one chunk, 1500 distinct rows: the
+    slot's row buffers grow from 332 rows), and the same stream with three sun directions: the bytes of GORTT_ENERGY_DENSE=1."""
+    rng = np.random.default_rng(25)
+    wl = np.arange(400, 2501)
+    head = ("1500 %d %s\n" % (len(wl), " ".join("%d" % w for w in wl))).encode()
+    for distinct in (True, False):
+        ang = np.round(_suns_chunk(rng, 1500, distinct), 4)
+        text = head + "".join("%.4f %.4f %.4f %.4f\n" % tuple(r) for r in ang).encode()
+        rc, out, err = _gortt(["-LAI", "4.0", "-energy", "--binary-out"], text)
+        rc2, out2, err2 = _gortt(["-LAI", "4.0", "-energy", "--binary-out"], text, {"GORTT_ENERGY_DENSE": "1"})
+        assert rc == 0 and rc2 == 0 and err == b"" and err2 == b"", (err, err2)
+        assert len(out) > 1500 * 2101 * 8 * 4 and out == out2, distinct
+
+
 def test_cli_energy_rows_formatted_once_equal_rows_formatted_per_line():
     """`gortt -energy`: the indexed pipe (each distinct albedo row copied and formatted once per chunk) writes the bytes of
     the dense path (GORTT_ENERGY_DENSE=1: a row per line, as gortt.c:321-327 evaluates them) - text over several chunks and

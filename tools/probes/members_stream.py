@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """gort_rsurf_members_stream_dev - the observation operator of an ensemble filter: the same angle lines for every member -
-across band counts: tools/probes/members_stream.py [MEMBERS [LINES]]"""
+across band counts: tools/probes/members_stream.py [MEMBERS [LINES [BANDS ...]]]
+(under rocprofv3: the interpreter binary itself after `--`, see tools/bench_lines.py)"""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
@@ -17,7 +18,7 @@ for _ in range(M):
                               rsl=(rng.uniform(0.05, 0.4), 0.1, 0.03726, -0.002426)))
 ang = torch.as_tensor(np.stack([rng.uniform(0, 70, n), rng.uniform(0, 360, n), rng.uniform(10, 70, n), rng.uniform(0, 360, n)], 1), device="cuda")
 e = api.Engine()
-for nw in (7, 16, 17, 32, 100, 200, 640, 2101):
+for nw in ([int(v) for v in sys.argv[3:]] or (7, 16, 17, 32, 100, 200, 640, 2101)):
     wl = np.linspace(400.0, 2500.0, nw)
     e.set_members_leaf(canopies, leaf, wl, compute_gaps=True); e.synchronize()
     out = torch.empty((M, n, nw), dtype=torch.float64, device="cuda")
