@@ -173,6 +173,7 @@ def cpu_baseline_grid(wl, procs, budget_s=12.0):
                       % (procs, n_each, len(wl), busy, wall, model)}
 
 
+PARK_DEADLINE_S = 420.0      # N > 1: how long the other ranks wait for rank 0's traffic pass and cpu_baseline
 XGMI_BOUND_GBS = 7 * 153.0   # receive bound of one GPU: seven xGMI links x ~153 GB/s (MI355X_MICROARCH.md)
 
 
@@ -191,7 +192,14 @@ def reference_build_id():
     return h.hexdigest()[:16]
 
 
-def measure_traffic(args, timeout_s=150):
+def _single_process_env():
+    """The environment of a child that runs alone on this rank's GPU: none of the launcher's rendezvous variables."""
+    drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+            "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+    return {k: v for k, v in os.environ.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+
+
+def measure_traffic(args, timeout_s=150, world=1):
     """HBM bytes per launch of the dominant kernel, measured in THIS run: two child passes of this script under
     `rocprofv3 --pmc` (WRITE_SIZE, then FETCH_SIZE: separate passes, as MI355X_MICROARCH.md prescribes), 3 steps each, no
     parity / baselines / config 5; bytes = (WRITE_SIZE + 2 x FETCH_SIZE) x 1024, averaged over the launches of
@@ -205,11 +213,13 @@ def measure_traffic(args, timeout_s=150):
         return None, "rocprofv3 not found"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity",
              "--sustain-s", "0", "--no-config5", "--no-configs", "--lut-draws", "1", "--placement-evidence", "0", "--no-traffic", "--nsza", str(args.nsza), "--nw", str(args.nw)]
+    if world > 1:
+        child += ["--slab-of-world", str(world)]          # rank 0's launch: its slab, in its window of the gatherable buffer
     kb = {}
     for counter in ("WRITE_SIZE", "FETCH_SIZE"):
         d = tempfile.mkdtemp(prefix="gort_pmc_", dir="/tmp")
         try:
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(_single_process_env(), TMPDIR="/tmp")
             r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
                                capture_output=True, timeout=timeout_s)
             vals = {}
@@ -446,6 +456,42 @@ def config5_block(args, rank, world, dist, barrier):
     return out
 
 
+def kernel_spread(per_draw):
+    """(max - min) / min of the draws' kernel times; None without two draws."""
+    if not per_draw or len(per_draw) < 2:
+        return None
+    k = [x["kernel_ms"] for x in per_draw]
+    return (max(k) - min(k)) / min(k) if min(k) > 0 else None
+
+
+def _ranks(v):
+    order = sorted(range(len(v)), key=lambda i: v[i])
+    r = [0.0] * len(v)
+    i = 0
+    while i < len(order):
+        j = i
+        while j + 1 < len(order) and v[order[j + 1]] == v[order[i]]:
+            j += 1
+        for k in range(i, j + 1):
+            r[order[k]] = (i + j) / 2.0
+        i = j + 1
+    return r
+
+
+def probe_kernel_rank_correlation(per_draw, min_spread=0.02):
+    """Spearman's rho between the allocator's probe (GB/s) and the kernel's rate on the same plain allocations; None unless
+    the kernel times spread over more than `min_spread` (an argmin coincidence is not evidence)."""
+    spread = kernel_spread(per_draw)
+    if spread is None or spread <= min_spread:
+        return None
+    a, b = _ranks([x["probe_gbs"] for x in per_draw]), _ranks([-x["kernel_ms"] for x in per_draw])
+    ma, mb = sum(a) / len(a), sum(b) / len(b)
+    va, vb = sum((x - ma) ** 2 for x in a), sum((y - mb) ** 2 for y in b)
+    if va == 0 or vb == 0:
+        return None
+    return sum((x - ma) * (y - mb) for x, y in zip(a, b)) / (va * vb) ** 0.5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -456,12 +502,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lut-draws", type=int, default=None,
                     help="max_draws of gort_lut_alloc, the C ABI's allocator for LUT buffers: > 1 = the placement of this rank's "
-                         "window is measured (1 = plain allocation).  Default: 3 at N = 1 (best of three 50 GB allocations by the "
-                         "store-pattern probe, >= 64 GB of the device left free; `per_draw` is the evidence that the probe ranks "
-                         "placements as the kernel does, DESIGN.md 5.1), 5 at N > 1 (a rank's slab is placed by a scan through slack)")
+                         "window is measured (1 = plain allocation).  Default at N = 1: 3 (best of three 50 GB allocations by the "
+                         "store-pattern probe, >= 64 GB of the device left free) where the `per_draw` record of the run shows placements "
+                         "that differ by more than 2 %, else 1 (`placement_selection` says which, DESIGN.md 5.1); 5 at N > 1 (a rank's "
+                         "slab is placed by a scan through slack)")
     ap.add_argument("--placement-evidence", type=int, default=3,
                     help="N = 1: before the headline's buffer is allocated, this many plain allocations alive together (the first "
-                         "draw's buffer among them) are each probed with gort_lut_alloc's store-pattern probe and written by 1 + 3 "
+                         "draw's buffer among them) are each probed with gort_lut_alloc's store-pattern probe and written by 5 + 10 "
                          "steps of the kernel: `per_draw`")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle spot check (profiler passes)")
     ap.add_argument("--sustain-s", type=float, default=3.0,
@@ -488,6 +535,9 @@ def main():
                     help="N = 1: do not count the configs' vector instructions with a rocprofv3 --pmc child pass (~40 s); the committed counts are used")
     ap.add_argument("--no-traffic", action="store_true",
                     help="N = 1: do not measure the kernel's HBM traffic with two rocprofv3 --pmc child passes (~30 s)")
+    ap.add_argument("--slab-of-world", type=int, default=1,
+                    help="N = 1 only: compute rank 0's slab of a world of this many ranks, in its window of that world's gatherable "
+                         "buffer (the child of the N > 1 run's traffic pass: one rank, rank 0's launch)")
     ap.add_argument("--traffic-gb", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc pass (GB)")
     args = ap.parse_args()
@@ -495,7 +545,8 @@ def main():
     import torch
     from gort_amd import api
 
-    if args.lut_draws is None:
+    lut_draws_default = args.lut_draws is None
+    if lut_draws_default:
         args.lut_draws = 3 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 5
     if args.configs_only:
         torch.cuda.set_device(0)
@@ -518,7 +569,7 @@ def main():
         import datetime
         import torch.distributed as dist
         # the library's own watchdog fires well after our deadline: a hung collective must cost its own record, not the line
-        pg_timeout = datetime.timedelta(seconds=args.collective_timeout + 180.0)
+        pg_timeout = datetime.timedelta(seconds=max(args.collective_timeout, PARK_DEADLINE_S) + 180.0)
         if args.rehearse:
             dist.init_process_group("gloo", timeout=pg_timeout)
         else:
@@ -576,14 +627,15 @@ def main():
     grid = api.hemisphere_grid(nsza=args.nsza)
     rows = grid.nsza * grid.nvza
     from gort_amd.shard import all_gather_in_place, gatherable_rows, row_slab
-    r0, r1 = row_slab(rank, world, rows)
+    layout_world = args.slab_of_world if (world == 1 and args.slab_of_world > 1) else world
+    r0, r1 = row_slab(rank, layout_world, rows)
     row_elems = grid.nphi * nw
     my_samples = (r1 - r0) * row_elems
     total_samples = rows * row_elems
     # The layout that is timed IS the layout a reassembled LUT needs: every rank allocates the whole LUT (+ < world rows
     # of padding) once and computes straight into its own window of it; the all-gather after the timed steps lands in
     # place.  At world 1 the window is the buffer.
-    buf_rows = gatherable_rows(world, rows)
+    buf_rows = gatherable_rows(layout_world, rows)
     window = (r0 * row_elems, max(r1 - r0, 0) * row_elems)
 
     def timed_steps(lut_ptr, warmup, steps):
@@ -623,15 +675,19 @@ def main():
                 if free_b < buf_rows * row_elems * 8 + (64 << 30):          # >= 64 GB stay free beside the draws
                     break
                 held.append(eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=1))
-            b = held[i]
-            probe = eng.probe_store_pattern(b.at(window[0]), win_bytes)
-            _, k3 = timed_steps(b.at(window[0]), 1, 3)
             free_b, total_b = torch.cuda.mem_get_info()
             peak_used_gb = max(peak_used_gb or 0.0, (total_b - free_b) / 1e9)
-            per_draw.append({"probe_gbs": probe, "kernel_ms": k3})
+        # every draw the same treatment, draw 0 included (it has first_draw's steps behind it, the others their first touch):
+        # the probe, then 5 untimed + 10 timed steps, HIP events around the 10
+        for b in held:
+            probe = eng.probe_store_pattern(b.at(window[0]), win_bytes)
+            _, k10 = timed_steps(b.at(window[0]), 5, 10)
+            per_draw.append({"probe_gbs": probe, "kernel_ms": k10})
         for b in held[1:]:
             b.free()
-    first.free()
+    if world > 1:
+        first.free()                                     # before the slack sweep's allocations, as ever
+        first = None
     # ---- (2) the product allocator of the C ABI (gort_lut_alloc: best of <= --lut-draws placements by a store-pattern
     #          probe of the window this rank writes); the number of record is measured on its buffer ----
     #          At world > 1 the window is placed by a scan through slack that stays allocated: the
@@ -646,7 +702,25 @@ def main():
             slack_sweep[str(cap)] = {"dt": s_dt, "kernel_ms": s_k, "slack_gb": b2.placement["slack_bytes"] / 1e9}
             b2.free()
     eng.set_lut_slack_gib(args.lut_slack_gib)
-    buf = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
+    # N = 1: the selection among whole-buffer placements is used where this box's placements DIFFER (kernel times of the plain
+    # draws above more than 2 % apart: seen on some boxes of the pool, 4-11 %) and retired where they do not (the driver's records
+    # of rounds 4 and 5: the selected buffer within 0.5 % of the plain first one) - decided by this run's own record, and said
+    # in the line (`placement_selection`).  --lut-draws given explicitly is taken as given.
+    placement_selection, buf = None, None
+    if world == 1 and lut_draws_default:
+        spread = kernel_spread(per_draw)
+        if spread is not None and spread <= 0.02:
+            args.lut_draws = 1
+            placement_selection = ("retired in this run: the kernel times of %d plain allocations lie within %.2f %% of each other; the "
+                                   "headline runs on the plain first allocation (first_draw's buffer)" % (len(per_draw), spread * 100))
+            buf = first                                  # a plain allocation is a plain allocation: the one already there
+        else:
+            placement_selection = "used: " + ("no per_draw evidence" if spread is None else
+                                              "the kernel times of %d plain allocations spread over %.2f %%" % (len(per_draw), spread * 100))
+    if buf is None:
+        if first is not None:
+            first.free()
+        buf = eng.lut_alloc(buf_rows * row_elems, window=window, max_draws=args.lut_draws)
     lut_ptr = buf.at(window[0])
     free_b, total_b = torch.cuda.mem_get_info()
     hbm = {"lut_buffer_gb": buf_rows * row_elems * 8 / 1e9, "placement_slack_gb": buf.placement["slack_bytes"] / 1e9,
@@ -680,6 +754,51 @@ def main():
             dist.all_gather_object(got, mine)
             return got
         per_rank = guarded("all_gather_object(per-rank records)", gather_records, default=[mine])
+
+    # ---- RCCL pre-flight through the C ABI, before the 50 GB exchanges: gort_rccl_unique_id -> gort_rccl_comm_init_rank ->
+    #      gort_lut_allgather of ONE double per rank, every rank's slot checked afterwards.  An exception is recorded beside the
+    #      result (the ranks agree on the outcome before anybody goes on); a hang costs the run like any other collective.
+    #      A rehearsal (all ranks on one GPU, gloo) cannot run RCCL between its ranks: there every rank drives the same calls
+    #      on a communicator of one.
+    rccl_preflight, preflight_comm = None, {}
+    if world > 1 and not args.no_gather:
+        from gort_amd.shard import rccl_comm_for_group
+
+        def preflight():
+            st = {}
+            try:
+                t0 = time.perf_counter()
+                comm = api.RcclComm(1, api.rccl_unique_id(), 0) if args.rehearse else rccl_comm_for_group()
+                st["init_ms"] = (time.perf_counter() - t0) * 1e3
+                slots = eng.lut_alloc(comm.world, max_draws=1)
+                mine_at = comm.rank
+                slots.tensor((comm.world,)).fill_(-1.0)
+                slots.tensor((comm.world,))[mine_at] = float(rank + 1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.lut_allgather(slots, 1, 1, comm)
+                eng.synchronize()
+                st["allgather_ms"] = (time.perf_counter() - t0) * 1e3
+                got = slots.to_numpy(comm.world, 0)
+                want = np.array([float(rank + 1)]) if args.rehearse else np.arange(1.0, world + 1.0)
+                slots.free()
+                if not np.array_equal(got, want):
+                    raise RuntimeError("pre-flight all-gather delivered %r, expected %r" % (got.tolist(), want.tolist()))
+                if args.rehearse:
+                    comm.destroy()
+                else:
+                    preflight_comm["comm"] = comm           # kept for the LUT's all-gather through the C ABI
+            except Exception as ex:                        # noqa: BLE001
+                st["error"] = repr(ex)
+            bad, init_ms, ag_ms = reduce_max([1.0 if "error" in st else 0.0, st.get("init_ms", 0.0), st.get("allgather_ms", 0.0)])
+            st["failed_on_some_rank"] = bad != 0.0
+            st["init_ms_slowest_rank"], st["allgather_ms_slowest_rank"] = init_ms, ag_ms
+            return st
+        rccl_preflight = guarded("RCCL pre-flight (gort_rccl_* + gort_lut_allgather of one double per rank)", preflight)
+        if rccl_preflight is None:
+            rccl_preflight = {"error": errors[-1] if errors else "skipped: an earlier collective failed"}
+        rccl_preflight["what"] = ("every rank its own communicator of one (rehearsal on one GPU: RCCL cannot connect ranks that share a device)"
+                                  if args.rehearse else "one communicator over all ranks (the unique id travels over the process group)")
 
     # ---- OUTSIDE the timed step: reassemble the LUT on every rank with one in-place RCCL all-gather ----
     allgather = None
@@ -716,7 +835,7 @@ def main():
 
         def gather_c_abi():
             try:
-                comm = rccl_comm_for_group()
+                comm = preflight_comm.pop("comm", None) or rccl_comm_for_group()
                 torch.cuda.synchronize(); barrier()
                 tg = time.perf_counter()
                 all_gather_in_place_c_abi(eng, buf, rows, row_elems, comm)
@@ -798,18 +917,17 @@ def main():
                                       "the placement of the rank's window is measured (the C ABI's allocator); first_draw = a plain "
                                       "allocation, same steps; per_draw = probe and kernel time on plain allocations side by side")},
             "per_draw": per_draw,
-            # does the probe order the draws as the kernel does?  (the slowest-probing draw is the slowest-running one; null
-            # where the draws lie within 1 % of each other by both measures: nothing to order)
-            "per_draw_probe_orders_kernel": None if not per_draw or len(per_draw) < 2 or
-                (max(x["probe_gbs"] for x in per_draw) < 1.01 * min(x["probe_gbs"] for x in per_draw) and
-                 max(x["kernel_ms"] for x in per_draw) < 1.01 * min(x["kernel_ms"] for x in per_draw)) else
-                bool(min(range(len(per_draw)), key=lambda i: per_draw[i]["probe_gbs"]) ==
-                     max(range(len(per_draw)), key=lambda i: per_draw[i]["kernel_ms"])),
+            # does the probe order the draws as the kernel does?  Spearman's rank correlation of the probe's GB/s with the kernel's
+            # rate (-kernel_ms) over the draws; null where the kernel times lie within 2 % of each other (nothing to order: the
+            # noise of ten steps is ~0.5 %).  With three draws the values are -1, -0.5, 0.5, 1.
+            "per_draw_probe_orders_kernel": probe_kernel_rank_correlation(per_draw),
+            "per_draw_kernel_spread": kernel_spread(per_draw),
+            "placement_selection": placement_selection,
             "per_draw_what": None if per_draw is None else
                              "plain allocations alive together (peak %.0f GB of the device in use), draw 0 = first_draw's buffer: "
-                             "gort_lut_alloc's store-pattern probe of each, then 1 + 3 steps of the real kernel on it (HIP events around "
-                             "the 3; a buffer's first steps run a few %% slower than its twentieth).  The headline's buffer is "
-                             "allocated afterwards by gort_lut_alloc(max_draws %d), which ranks its own candidates by that probe" % (peak_used_gb, args.lut_draws),
+                             "gort_lut_alloc's store-pattern probe of each, then 5 untimed + 10 timed steps of the real kernel on it (HIP "
+                             "events around the 10), every draw alike.  The headline's buffer is allocated afterwards by "
+                             "gort_lut_alloc(max_draws %d); with more than one draw it ranks its own candidates by that probe" % (peak_used_gb, args.lut_draws),
             "first_draw": {"value": total_samples * args.steps / fd_dt, "ms_per_step": fd_dt / args.steps * 1e3,
                            "kernel_ms_slowest_rank": fd_kernel_max,
                            "what": "the same warm-up + steps on a plain first allocation (gort_lut_alloc with max_draws 1), max over ranks"},
@@ -824,6 +942,8 @@ def main():
             "parity": parity,
             "reference_build": reference_build_id(),
         }
+        if rccl_preflight is not None:
+            out["rccl_preflight"] = rccl_preflight
         if allgather is not None:
             out["allgather"] = allgather
             out["allgather_c_abi"] = allgather_c_abi
@@ -846,15 +966,18 @@ def main():
             out["configs"]["valu_counts"] = how
         except Exception as ex:                           # noqa: BLE001
             out["configs"] = {"error": repr(ex)}
-    if rank == 0 and world == 1 and not args.no_traffic and args.traffic_gb is None:
-        # HBM traffic of the dominant kernel from the PMC counters, in this very run (the LUT buffers are gone: the child
-        # passes need the memory); a failure leaves `traffic` null and says why
-        t_bytes, how = measure_traffic(args)
+    # ---- what makes the line stand on its own, at every N (the CPU number "in the same run"):
+    #      on rank 0, with the engine still open - the HBM traffic of rank 0's launch from the PMC counters (child passes of
+    #      this script, one rank, rank 0's slab in its window) and the reference on the host's cores.  At N > 1 the other
+    #      ranks are parked at a barrier with a deadline of its own meanwhile.
+    if rank == 0 and not errors and not args.no_traffic and args.traffic_gb is None and out["roofline"].get("algorithmic_bytes_per_launch"):
+        # (the LUT buffers are gone: the child passes need the memory); a failure leaves `traffic` null and says why
+        t_bytes, how = measure_traffic(args, timeout_s=150 if world == 1 else 110, world=world)
         out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t_bytes, how
-        if t_bytes and out["roofline"].get("algorithmic_bytes_per_launch"):
+        if t_bytes:
             out["roofline"]["traffic_over_algorithmic"] = t_bytes / out["roofline"]["algorithmic_bytes_per_launch"]
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not errors:
             # the LUT of the timed region is gone (config 5 needed the memory): the check against the reference's own rows
             # recomputes the few rows it compares, with the same entry point
             # all host cores of the box's share (16 per GPU on this pool), one reference process per core
@@ -878,14 +1001,22 @@ def main():
                 out["parity_reference"] = dict(compare(np.stack(mine_rows), cr, "%d nodes x %d bands" % cr.shape),
                                                against="the reference's gortt_rsurf itself (oracle/_ref/libgortt_ref.so)")
             # (2) the reference as a user runs it: the CLI with a -P LUT, random lines x 180 bands, text to /dev/null
-            cli = cpu_baseline(wl, budget_s=10.0, procs=ncores)
+            #     (N = 1 only, like (3): the other ranks of an N > 1 run are waiting)
+            cli = cpu_baseline(wl, budget_s=10.0, procs=ncores) if (world == 1 or same is None) else None
             out["cpu_baseline"] = same if same is not None else cli
-            if same is not None:
+            if same is not None and cli is not None:
                 out["cpu_baseline_cli"] = cli
-            # (3) our own hoisted scalar-C restatement (no text I/O), one core: the strongest per-core CPU number we have
-            out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
-            out["gpu_over_cpu"] = {"vs_cpu_baseline_same_shape_all_cores": out["value"] / out["cpu_baseline"]["value"],
-                                   "vs_port_one_core": out["value"] / out["cpu_baseline_port"]["value"]}
+            if world == 1:
+                # (3) our own hoisted scalar-C restatement (no text I/O), one core: the strongest per-core CPU number we have
+                out["cpu_baseline_port"] = cpu_baseline(wl, budget_s=6.0, force_port=True)
+                out["gpu_over_cpu"] = {"vs_cpu_baseline_same_shape_all_cores": out["value"] / out["cpu_baseline"]["value"],
+                                       "vs_port_one_core": out["value"] / out["cpu_baseline_port"]["value"]}
+            else:
+                out["gpu_over_cpu"] = {"vs_cpu_baseline_same_shape_all_cores_of_rank_0s_share": out["value"] / out["cpu_baseline"]["value"]}
+    if world > 1 and not (args.no_cpu_baseline and args.no_traffic):
+        # the other ranks wait here while rank 0 measures (two profiler passes and ~20 s of the reference: a minute or two)
+        guarded("barrier behind rank 0's traffic pass and cpu_baseline", barrier, deadline=PARK_DEADLINE_S)
+    if rank == 0:
         if errors:
             out["errors"] = errors
         print(json.dumps(out), flush=True)
