@@ -927,13 +927,18 @@ static int size_class(long doubles)
 }
 
 // rows are GLOBAL: member * (nsza*nvza) + isza * nvza + ivza
+constexpr size_t PIPELINE_MAX_BYTES = 64u << 20;        // records + sun table of a call whose geometry runs under the previous expansion
+
 static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long row_end, double *lut_dev)
 {
     int rc;
     const long rows = row_end - row_begin, nA = rows * g->nphi;
     const int nw = e->nw;
     const gort_canopy *c = e->canopy.as<gort_canopy>();
-    const bool few_bands = nw < 128;     // the aligned LUT kernel needs a chunk (128 doubles) to span at most two angles
+    // below 128 bands a chunk of the aligned LUT kernel (128 doubles) spans more than two angles: small grids and up to 64 bands the
+    // geometry kernel writes the samples itself; [r6] 65 ... 127 bands of a grid worth three launches: records + expand_flat_few_kernel
+    const bool few_flat = grid_takes_few_flat_kernel(nw, nA * (long)nw);
+    const bool few_bands = nw < 128 && !few_flat;
     if (few_bands) {
         // up to 8 bands (config 3 has one): no records at all, the geometry kernel writes the samples itself - every row with its
         // own member's canopy and band constants (rows are global: member * rows_per_member + ...)
@@ -969,11 +974,11 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     // fit, the record and sun-term fetches in the waves' prologues then come from HBM, and those short-lived
     // waves are latency-bound.  Small slabs (the per-rank slabs of a multi-GPU run): both halves fit, and the
     // pipeline hides the 0.04-0.06 ms of geometry, sun table and launch gaps per call (4 % at N = 8).
-    const long tail = expand_grid_tail_pad_records(nw, nA * (long)nw);
-    const size_t coef_bytes = sizeof(double) * 8 * (size_t)(nA + 1 + tail);
+    long front = 1, tail = expand_grid_tail_pad_records(nw, nA * (long)nw);
+    if (few_flat) expand_grid_few_pad_records(nw, nA * (long)nw, &front, &tail);
+    const size_t coef_bytes = sizeof(double) * 8 * (size_t)(nA + front + tail);
     const int q0 = (int)(row_begin / g->nvza), q1 = (int)((row_end - 1) / g->nvza) + 1;   // sun rows q = member*nsza + isza
     const size_t sun_bytes = sizeof(double) * 5 * (size_t)nw * (size_t)(q1 - q0);
-    constexpr size_t PIPELINE_MAX_BYTES = 64u << 20;
     const bool piped = e->pipeline && coef_bytes + sun_bytes <= PIPELINE_MAX_BYTES;
     const int half = piped ? (int)(e->grid_calls++ & 1) : 0;
     DevBuf &coef_buf = piped ? e->gcoef[half] : e->coef, &sun_buf = piped ? e->gsun[half] : e->sun;
@@ -985,7 +990,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     const bool fresh = coef_bytes > coef_buf.cap;
     if ((rc = coef_buf.reserve(coef_bytes))) return rc;
     if (fresh) GORT_HIP(hipMemsetAsync(coef_buf.p, 0, coef_bytes, gs));      // pads: readable, contents don't-care (padded lanes are never stored)
-    double *coef8 = coef_buf.as<double>() + 8;
+    double *coef8 = coef_buf.as<double>() + 8 * front;
     if ((rc = launch_geometry_grid(c, *g, row_begin, row_end, coef8, true, gs))) return rc;
     if ((rc = sun_buf.reserve(sun_bytes))) return rc;
     if ((rc = launch_sun_table(c, e->L.as<double>(), nw, *g, q0, q1, sun_buf.as<double>(), gs))) return rc;
@@ -1017,8 +1022,10 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
         }
         GORT_HIP(hipEventRecord(e->ev[e->ev_used], e->stream));
     }
-    rc = launch_expand_grid(sun_buf.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
-                            xcd_slots, e->xcd_weights, e->stream);
+    rc = few_flat ? launch_expand_grid_few(sun_buf.as<double>(), q0, q1 - q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
+                                           xcd_slots, e->xcd_weights, e->stream)
+                  : launch_expand_grid(sun_buf.as<double>(), q0, coef8, nw, g->nvza, g->nphi, row_begin, row_end, lut_dev,
+                                       xcd_slots, e->xcd_weights, e->stream);
     if (timed) {
         GORT_HIP(hipEventRecord(e->ev[e->ev_used + 1], e->stream));
         e->ev_used += 2;
@@ -1029,6 +1036,12 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     }
     return rc;
 }
+
+// (Round 6 tried cutting a call whose records do not fit the pipeline's double buffer - a hemisphere: 191 MB - into slabs that
+// do, so that the geometry of slab i + 1 runs under the expansion of slab i as it does between the calls of a slabbed grid: five
+// slabs of a hemisphere x 100 / 128 / 512 bands took 545 / 640 / 1930 us against 450 / 480 / 1690 in one piece - every slab's
+// expansion has a head and a tail of its own, and the geometry kernel is sized for the machine, not for a fifth of it.
+// profiles/r06/few_band_flat_ab.log)
 
 // ---- LUT buffers with a measured placement (include/gort_amd.h) ----
 // buffers handed out as a pointer INTO their allocation (shifted windows): pointer -> what hipFree needs

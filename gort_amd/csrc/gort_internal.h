@@ -168,6 +168,12 @@ int launch_sun_table(const gort_canopy *canopies_dev, const double *L_dev, int n
 // coef_dev for launch_expand_grid: compact records, with ONE readable pad record in front of coef_dev
 // and expand_grid_tail_pad_records() readable records behind the last angle
 long expand_grid_tail_pad_records(int nw, long n_total);
+// LUTs of 33 ... 127 bands through the aligned-chunk form (expand_flat_few_kernel): which grids take it, the readable records it
+// wants in front of node 0 and behind the last node, and its launcher (sun_dev: n_sun rows from isza_base on)
+bool grid_takes_few_flat_kernel(int nw, long n_total);
+void expand_grid_few_pad_records(int nw, long n_total, long *front, long *tail);
+int launch_expand_grid_few(const double *sun_dev, int isza_base, int n_sun, const double *coef_dev, int nw, int nvza, int nphi,
+                           long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, const int *xcd_weights, void *stream);
 // xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the call (per-XCD slot counters), or nullptr for the static
 // XCD mapping, for which xcd_weights[8] (32nds, nullptr = all 32) are the XCDs' duty weights
 int launch_expand_grid(const double *sun_dev, int isza_base, const double *coef_dev, int nw, int nvza, int nphi,

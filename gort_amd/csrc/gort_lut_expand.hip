@@ -228,7 +228,215 @@ __global__ __launch_bounds__(256) void expand_flat_kernel(const double *__restri
                                     angles_per_sza, da, step, k_wave, rec_w, out_w, lane);
 }
 
+// ---- LUTs of 33 ... 127 bands in the same absolutely aligned 1-KiB chunks (gortt.c:484-557 per node and band) ----
+// Below 128 bands a chunk of 128 doubles spans up to ceil(127 / nw) + 1 nodes, so the step's record is not wave-uniform any
+// more: element e of the chunk belongs to node a_w + (band_w + e) / nw.  What stays true (the stride argument at the top of this
+// file holds for any nw): a lane keeps its two elements' BANDS and their node OFFSETS off_j = (band_w + 2 lane + j) / nw for
+// life.  The records of all K steps of the wave - K x n_rec of them, 64 B each, the nodes a_w + k da + r - are staged in LDS by
+// the prologue (two or three vector loads, waited for once, before the wave's first store), and a step reads its elements' records
+// from there: LDS operations count on lgkmcnt, so no wait in the loop ever stands in front of a store (per-lane vector loads of
+// the records would put a vmcnt wait - which the stores count on too - into every step).  The sun zenith of a lane's node is
+// tracked per lane (its rows change once per nvza x nphi nodes, at different steps for different lanes).
+// Round 5 wrote such LUTs from the geometry kernel itself, whole rows of nw doubles per store instruction - on 8-byte boundaries:
+// the first and last cache line of every row shared with the neighbours, 0.60-0.71 of HBM where this pattern writes 0.78 at 128
+// bands (profiles/r05/few_band_lut_pmc.log).
+constexpr int FEW_MIN_BANDS = 33;            // what the kernel can do
+constexpr int FEW_DEFAULT_MIN_BANDS = 65;    // what it is used for
+constexpr int FEW_MAX_RECS = 5;             // ceil(127 / 33) + 1
+constexpr int FEW_MAX_STEPS = 16;
+constexpr int FEW_FRONT_PAD_RECORDS = 8;    // readable records in front of node 0 (the chunk that holds element 0 starts up to 127
+                                            // elements = 4 nodes in front of it)
+
+template <bool NT>
+__global__ __launch_bounds__(256) void expand_flat_few_kernel(const double *__restrict__ sun, int isza_base, int n_sun,
+                                                               const double *__restrict__ coef, int nw,
+                                                               int angles_per_sza, long angle0, long n_total, int shift,
+                                                               long stride_chunks, int da, int steps_per_wave, int n_rec,
+                                                               FastDiv div_stride, FastDiv div_nw, FastDiv div_aps,
+                                                               double *__restrict__ lut, int xcd_mode,
+                                                               XcdDuty duty, long useful_blocks,
+                                                               int *__restrict__ xcd_slots)
+{
+    __shared__ dbl2 s_rec[4][FEW_MAX_STEPS * FEW_MAX_RECS * 4];
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long block = xcd_logical_block(xcd_mode, duty, useful_blocks, xcd_slots);
+    if (block < 0) return;
+    // the wave's chunks: as in expand_flat_kernel (wave-uniform, 32-bit, divisions by multiply-shift)
+    const unsigned wave = (unsigned)(block * 4 + wave_in_block);
+    const unsigned stride = (unsigned)stride_chunks;
+    const unsigned panel = fast_div(wave, div_stride);
+    const unsigned w_in_panel = wave - panel * stride;
+    const int lane = threadIdx.x & 63;
+    const long step = stride_chunks * CHUNK;       // elements per step = da * nw
+    const long c0 = (long)panel * steps_per_wave * stride_chunks + w_in_panel;
+    const long last = n_total - 1 + shift;
+    const long last_chunk = last / CHUNK;
+    const int last_off = (int)(last % CHUNK);
+    if (c0 > last_chunk) return;
+    const long e0 = c0 * CHUNK - shift;
+    const unsigned local = w_in_panel * CHUNK + (unsigned)step - (unsigned)shift;
+    const unsigned a_loc = fast_div(local, div_nw);
+    const int band_w = (int)(local - a_loc * (unsigned)nw);
+    const long a_w = (long)panel * steps_per_wave * da + a_loc - da;          // node of the chunk's first element at step 0, >= -4
+    const long rel = last_chunk - c0;
+    int k_wave = steps_per_wave, last_step = -1;
+    if (rel < (long)steps_per_wave * stride_chunks) {
+        const unsigned k_last = fast_div((unsigned)rel, div_stride);
+        k_wave = (int)k_last + 1;
+        if ((unsigned)rel == k_last * stride) last_step = (int)k_last;
+    }
+    const int first_off = c0 == 0 ? shift : 0;
+
+    // ---- the records of the wave's steps into LDS: slot (k n_rec + r) 4 + q = quarter q of the record of node a_w + k da + r
+    dbl2 *const rec_w = s_rec[wave_in_block];
+    {
+        const int slots = k_wave * n_rec * 4;
+        for (int s = lane; s < slots; s += 64) {
+            const int kr = s >> 2, k = kr / n_rec, r = kr - k * n_rec;
+            const long node = a_w + (long)k * da + r;
+            rec_w[s] = reinterpret_cast<const dbl2 *>(coef + node * GRID_COEF_STRIDE)[s & 3];
+        }
+    }
+    // ---- what a lane keeps for life: bands, node offsets, the sun zenith of each element's node and its five terms there
+    double b[EPL][5];
+    int band[EPL], off[EPL], isza[EPL], rem[EPL];
+    auto load_sun_terms = [&](int j, int src) {          // (src: the element whose tracker holds; rows outside the table: clamped,
+        int row = isza[src] - isza_base;                  //  they belong to elements in front of or behind the slab, never stored)
+        row = row < 0 ? 0 : (row >= n_sun ? n_sun - 1 : row);
+        const double *bp = sun + (long)row * 5 * nw + band[j];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) b[j][q] = bp[(long)q * nw];
+    };
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const unsigned pos = (unsigned)(band_w + EPL * lane + j);
+        off[j] = (int)fast_div(pos, div_nw);
+        band[j] = (int)(pos - (unsigned)off[j] * (unsigned)nw);
+        const long A = angle0 + a_w + off[j];                                 // >= -4: only the first chunk of a slab that starts at angle 0
+        long q = A >= 0 ? (A < (1L << 31) ? (long)fast_div((unsigned)A, div_aps) : A / angles_per_sza) : -((-A + angles_per_sza - 1) / angles_per_sza);
+        isza[j] = (int)q;
+        rem[j] = (int)(A - q * angles_per_sza);
+        load_sun_terms(j, j);
+    }
+    // does any lane of this wave have its two elements in two nodes?  (fixed for the wave's life)
+    const bool split = __any(off[1] != off[0]) != 0;
+    const int at0 = off[0] * 4, at1 = off[1] * 4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                     // the records are in LDS before other lanes read them (one wave: no s_barrier)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    double *o = lut + e0 + EPL * lane;
+    const int rec_stride = n_rec * 4;
+    for (int k = 0; k < k_wave; ++k) {
+        const dbl2 *rk = rec_w + k * rec_stride;
+        const dbl2 a01 = rk[at0], a23 = rk[at0 + 1];
+        const double a4 = rk[at0 + 2].x;
+        double v[EPL];
+        v[0] = dot5(a01.x, a01.y, a23.x, a23.y, a4, b[0][0], b[0][1], b[0][2], b[0][3], b[0][4]);
+        if (split) {
+            const dbl2 c01 = rk[at1], c23 = rk[at1 + 1];
+            const double c4 = rk[at1 + 2].x;
+            v[1] = dot5(c01.x, c01.y, c23.x, c23.y, c4, b[1][0], b[1][1], b[1][2], b[1][3], b[1][4]);
+        } else {
+            v[1] = dot5(a01.x, a01.y, a23.x, a23.y, a4, b[1][0], b[1][1], b[1][2], b[1][3], b[1][4]);
+        }
+        const bool front = k == 0 && first_off > 0, back = k == last_step;
+        if (!front && !back) {
+            dbl2 vv;
+            vv.x = v[0];
+            vv.y = v[1];
+            if (NT) __builtin_nontemporal_store(vv, reinterpret_cast<dbl2 *>(o));
+            else *reinterpret_cast<dbl2 *>(o) = vv;
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int e = EPL * lane + j;
+                if (!(front && e < first_off) && !(back && e > last_off)) o[j] = v[j];
+            }
+        }
+        o += step;
+        // the next step's nodes: da further on; a lane whose node crosses into the next sun zenith fetches that row's terms
+        if (k + 1 < k_wave) {
+            bool ch[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                ch[j] = false;
+                if (j == 0 || split) {
+                    rem[j] += da;
+                    while (rem[j] >= angles_per_sza) { rem[j] -= angles_per_sza;  ++isza[j];  ch[j] = true; }
+                }
+            }
+            if (__any(ch[0] || ch[1])) {
+                if (ch[0]) load_sun_terms(0, 0);
+                if (split ? ch[1] : ch[0]) load_sun_terms(1, split ? 1 : 0);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+bool grid_takes_few_flat_kernel(int nw, long n_total)
+{
+    if (nw < FEW_MIN_BANDS || nw >= CHUNK) return false;
+    if (const char *v = ab_env("GORT_GRID_FEW_FLAT")) return atoi(v) != 0;        // measuring build: either form for any grid
+    // from 65 bands (a hemisphere x 33 / 48 / 64 / 65 / 100 / 127 bands, fused | this: 204 | 202, 247 | 272-287, 285-302 | 327,
+    // 309-356 | 317-326, 492 | 427, 668 | 508 us: profiles/r06/few_band_flat_ab.log) and for grids worth three launches
+    return nw >= FEW_DEFAULT_MIN_BANDS && n_total >= (1L << 23);
+}
+
+static int few_steps(int xcd_mode)
+{
+    int steps = tuning().steps;
+    if (steps <= 0) steps = xcd_mode == 2 ? 16 : 6;
+    return steps > FEW_MAX_STEPS ? FEW_MAX_STEPS : steps;
+}
+
+// readable records in front of node 0 and behind the last node for expand_flat_few_kernel
+void expand_grid_few_pad_records(int nw, long n_total, long *front, long *tail)
+{
+    (void)nw;  (void)n_total;
+    *front = FEW_FRONT_PAD_RECORDS;
+    *tail = 2 * FEW_MAX_RECS + 6;          // a wave stages the records of the steps it has inside the slab: n_rec - 1 nodes past its last one at most
+}
+
+int launch_expand_grid_few(const double *sun_dev, int isza_base, int n_sun, const double *coef_dev, int nw, int nvza, int nphi,
+                           long row_begin, long row_end, double *lut_dev, int *xcd_slots_dev, const int *xcd_weights, void *stream)
+{
+    const long rows = row_end - row_begin;
+    if (rows <= 0) return GORT_OK;
+    if (nw < FEW_MIN_BANDS || nw >= CHUNK) return fail(GORT_EINVAL, "expand_grid_few: %d bands", nw);
+    const ExpandTuning &tune = tuning();
+    const long n_total = rows * nphi * (long)nw;
+    const int shift = (int)((reinterpret_cast<uintptr_t>(lut_dev) / sizeof(double)) % CHUNK);
+    const long chunks = (n_total + shift + CHUNK - 1) / CHUNK;
+    const long stride = flat_stride(nw, chunks, tune.waves);
+    const int xcd_mode = resolve_xcd_mode(xcd_slots_dev);
+    const int steps = few_steps(xcd_mode);
+    const long panels = (chunks + (long)steps * stride - 1) / ((long)steps * stride);
+    if (panels * stride >= (1L << 31) || chunks >= (1L << 31) || stride * CHUNK >= (1L << 30))
+        return fail(GORT_EINVAL, "expand_grid_few: slab of %ld chunks in %ld waves is beyond the kernel's 32-bit indices", chunks, panels * stride);
+    const int da = (int)(stride * CHUNK / nw);
+    const int n_rec = (CHUNK - 1 + nw - 1) / nw + 1;               // nodes a chunk can touch: ceil(127 / nw) + 1
+    if (n_rec > FEW_MAX_RECS) return fail(GORT_EINVAL, "expand_grid_few: %d records per chunk", n_rec);
+    const long useful = (panels * stride + 3) / 4;
+    XcdDuty duty;
+    const long nblocks = plan_xcd_duty(xcd_mode, useful, xcd_weights, duty);
+    if (nblocks >= (1L << 31)) return fail(GORT_EINVAL, "expand_grid_few: %ld workgroups in one launch", nblocks);
+    const int angles_per_sza = nvza * nphi;
+    const long angle0 = row_begin * nphi;
+#define GORT_FEW(N)                                                                                                              \
+    hipLaunchKernelGGL((expand_flat_few_kernel<N>), dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, sun_dev, isza_base, \
+                       n_sun, coef_dev, nw, angles_per_sza, angle0, n_total, shift, stride, da, steps, n_rec,                   \
+                       make_fast_div((unsigned)stride), make_fast_div((unsigned)nw), make_fast_div((unsigned)angles_per_sza),   \
+                       lut_dev, xcd_mode, duty, useful, xcd_slots_dev)
+#ifdef GORT_AB
+    if (!tune.nt) GORT_FEW(false); else
+#endif
+    GORT_FEW(true);
+#undef GORT_FEW
+    return check_launch("expand_flat_few_kernel");
+}
 
 // records the LUT kernel may read past the last angle (prefetch depth x angles per step, + wrap, + slack)
 long expand_grid_tail_pad_records(int nw, long n_total)

@@ -347,6 +347,7 @@ static int launch_expand_stream_flat(const double *band_table_dev, int nw, const
                                      int *xcd_slots_dev, hipStream_t s)
 {
     const ExpandTuning &tune = tuning();
+    (void)tune;                                 // (read by the measuring build only)
     if (!band_table_dev) return fail(GORT_EINVAL, "stream expansion: wide stream without the band table");
     const StreamBand *bands = reinterpret_cast<const StreamBand *>(band_table_dev);
     const long n_total = nA * (long)nw;

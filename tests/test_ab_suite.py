@@ -17,7 +17,8 @@ AB_LIB = os.path.join(ROOT, "gort_amd", "libgort_amd_ab.so")
 AB_SWITCHES = [b"GORT_EXPAND_DEPTH", b"GORT_EXPAND_NT", b"GORT_EXPAND_XCD", b"GORT_EXPAND_STEPS", b"GORT_EXPAND_WAVES", b"GORT_STREAM_WAVES",
                b"GORT_STREAM_STEPS", b"GORT_STREAM_FUSE", b"GORT_GRID_FUSE", b"GORT_GRID_MIRROR", b"GORT_GRID_BY_ROWS", b"GORT_GRID_PIPELINE", b"GORT_GRID_AZ_TABLE",
                b"GORT_LINES_MAX_BANDS", b"GORT_ENERGY_DEDUP", b"GORT_ENERGY_SHARE_ROWS", b"GORT_ENERGY_BATCH", b"GORT_ENERGY_BROADCAST",
-               b"GORT_XCD_CALIBRATE", b"GORT_XCD_WEIGHTS", b"GORT_PIPE_FAIL_GROW"]
+               b"GORT_XCD_CALIBRATE", b"GORT_XCD_WEIGHTS", b"GORT_PIPE_FAIL_GROW", b"GORT_GRID_FEW_FLAT",
+               b"GORT_MEMBERS_MIN_LINES"]
 
 
 def test_the_product_library_has_no_ab_switches():

@@ -345,12 +345,14 @@ def test_grid_equals_stream_and_oracle(eng, nw):
 
 
 @pytest.mark.ab
-@pytest.mark.parametrize("nw", [1, 3, 8, 9, 16, 50, 64, 65, 100, 127])
+@pytest.mark.parametrize("nw", [1, 3, 8, 9, 16, 32, 33, 34, 50, 64, 65, 100, 127])
 def test_few_band_grid_fused_equals_two_kernel_path(nw):
     """Grids below 128 bands (BASELINE config 3 has one) form their samples inside the geometry kernel - up to 8 bands a lane
     its node's, turned through LDS into whole rows; from 9 bands lanes as bands, the (sun zenith, band) terms from the LUT
     path's table; from 65 two bands per lane - and the two-kernel path (records + per-sample expansion, GORT_GRID_FUSE=0)
-    must give the same bits."""
+    must give the same bits.  So must, from 33 bands, the aligned-chunk form large grids take since round 6 (records staged in
+    LDS + expand_flat_few_kernel, GORT_GRID_FEW_FLAT=1; =0: the fused form whatever the size) - into a LUT that starts 24 bytes
+    off a chunk boundary, rows 5 ... 1176 of 13 sun zeniths (the sun rows change inside the waves' steps)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = r"""
 import hashlib, sys
@@ -361,18 +363,22 @@ nw = %d
 c = api.gap_probabilities(api.make_canopy(newstyle=(2.0, 2.0, 0.6), lai=3.3))
 e = api.Engine(); e.set_canopy(c); e.set_spectra(*api.spectra(np.linspace(450.0, 2300.0, nw)))
 g = api.hemisphere_grid(13, 91, 361)
-lut = torch.empty((13 * 91 * 361, nw), dtype=torch.float64, device="cuda")
+n = (13 * 91 - 12) * 361 * nw
+buf = torch.full((n + 64,), -7.0, dtype=torch.float64, device="cuda")
+lut = buf[3:3 + n]
 torch.cuda.synchronize()
 e.rsurf_grid_dev(g, 5, 13 * 91 - 7, lut)
 e.synchronize()
-print(hashlib.sha256(lut[: (13 * 91 - 12) * 361].cpu().numpy().tobytes()).hexdigest())
+assert float(buf[:3].max()) == -7.0 and float(buf[3 + n:].max()) == -7.0 and not bool((lut == -7.0).any())
+print(hashlib.sha256(lut.cpu().numpy().tobytes()).hexdigest())
 """ % (root, nw)
     digests = []
-    for fuse in ("1", "0"):
-        run = subprocess.run(["python3", "-c", script], capture_output=True, timeout=300, env=dict(os.environ, GORT_GRID_FUSE=fuse))
+    for fuse, few_flat in [("1", "0"), ("0", "0")] + ([("1", "1")] if nw >= 33 else []):
+        run = subprocess.run(["python3", "-c", script], capture_output=True, timeout=300,
+                             env=dict(os.environ, GORT_GRID_FUSE=fuse, GORT_GRID_FEW_FLAT=few_flat))
         assert run.returncode == 0, run.stderr.decode()[-2000:]
         digests.append(run.stdout.decode().strip().split("\n")[-1])
-    assert digests[0] == digests[1] and len(digests[0]) == 64
+    assert len(set(digests)) == 1 and len(digests[0]) == 64, digests
 
 
 @pytest.mark.ab
@@ -1253,11 +1259,12 @@ def test_c3_full_hemisphere_one_band(eng, golden):
     assert err_K(K, Kref) <= REGRESSION
 
 
-@pytest.mark.parametrize("nw", [7, 100])
+@pytest.mark.parametrize("nw", [7, 8, 9, 16, 33, 64, 65, 100, 127])
 def test_full_hemisphere_lut_of_a_few_bands(eng, nw):
     """The hemisphere of config 3 as a LUT of 7 bands (the MODIS land bands of the reference's README.md:8-9) and of 100 (the band
     counts its command line can read), written by the geometry kernel itself (gort_geometry.hip: up to 8 bands a lane its node's
-    samples turned through LDS, from 9 lanes as bands): a seeded sample of nodes against the oracle to 1e-9, NaN exactly where a
+    samples turned through LDS, from 9 lanes as bands; from 33 bands - a grid of this size - compact records and the aligned chunks
+    of expand_flat_few_kernel; the band counts are the edges of those lane mappings): a seeded sample of nodes against the oracle to 1e-9, NaN exactly where a
     zenith is 90 degrees, every image equal to its original (a full circle is evaluated over 0 ... 180 degrees and written
     twice), and the whole LUT against the stream of its nodes to rounding."""
     import torch
