@@ -407,7 +407,8 @@ def config5_block(args, rank, world, dist, barrier):
     from gort_amd.ensemble import sharded_albedo_table
     wl = np.arange(400.0, 2501.0)
     n = args.c5_members
-    table, t = sharded_albedo_table(n, wl, rank, world, lut_chunk=args.c5_chunk, gather_on_cpu=args.rehearse, barrier=barrier)
+    table, t = sharded_albedo_table(n, wl, rank, world, lut_chunk=args.c5_chunk, gather_on_cpu=args.rehearse, barrier=barrier,
+                                    lut_slack_gib=args.lut_slack_gib, warmup_cycles=args.c5_warmup)
     red_dev = "cpu" if args.rehearse else "cuda"
     keys = ("setup_s", "lut_s", "energy_s", "gather_s", "total_s")
     mine = torch.tensor([t[k] for k in keys], dtype=torch.float64, device=red_dev)
@@ -427,7 +428,7 @@ def config5_block(args, rank, world, dist, barrier):
     samples = n * 91 * 361 * wl.size if args.c5_chunk else 0
     out = {"workload": "EnKF ensemble: %d members (SURVEY 8d draw, seed 12345) x hemisphere 91x361 x %d bands + albedo/fAPAR table, "
                        "members sharded over %d rank(s)" % (n, wl.size, world),
-           "members": n, "lut_chunk_members": args.c5_chunk, "samples": samples, "scaling": "strong",
+           "members": n, "lut_chunk_members": args.c5_chunk, "warmup_cycles": t.get("warmup_cycles"), "samples": samples, "scaling": "strong",
            "value": samples / worst["total_s"] if samples else None, "unit": "samples/s",
            "ms": {k[:-2] + "_ms": worst[k] * 1e3 for k in keys}, "timing": "max over ranks of each stage; total = first setup call "
            "to gathered table on every rank",
@@ -521,6 +522,9 @@ def main():
     ap.add_argument("--c5-chunk", type=int, default=25,
                     help="members per LUT chunk of the config-5 block (0 = no LUTs); 25 keeps a chunk's records under the 64 MB "
                          "up to which the engine overlaps the next chunk's geometry with this chunk's expansion")
+    ap.add_argument("--c5-warmup", type=int, default=1,
+                    help="whole cycles of the config-5 block run untimed before the timed one (a filter cycles many times; the first "
+                         "cycle of a process allocates the chunks' record buffers and calibrates the XCD weights of their size class)")
     ap.add_argument("--lut-slack-gib", type=int, default=48,
                     help="world > 1: cap (GiB) of the slack gort_lut_alloc keeps beside the buffer to place this rank's window "
                          "(GORT_LUT_SLACK_GIB; 0 = plain allocation).  The timed steps are also run with 0 and 16: `slack_sweep`")
@@ -970,6 +974,8 @@ def main():
     #      on rank 0, with the engine still open - the HBM traffic of rank 0's launch from the PMC counters (child passes of
     #      this script, one rank, rank 0's slab in its window) and the reference on the host's cores.  At N > 1 the other
     #      ranks are parked at a barrier with a deadline of its own meanwhile.
+    if rank == 0 and args.no_traffic and args.traffic_gb is None:
+        out["roofline"]["traffic_source"] = "not measured: --no-traffic"
     if rank == 0 and not errors and not args.no_traffic and args.traffic_gb is None and out["roofline"].get("algorithmic_bytes_per_launch"):
         # (the LUT buffers are gone: the child passes need the memory); a failure leaves `traffic` null and says why
         t_bytes, how = measure_traffic(args, timeout_s=150 if world == 1 else 110, world=world)

@@ -553,10 +553,14 @@ class Engine:
         self.nw = sp.shape[2]
 
     def set_members_leaf(self, members, leaf, wl, compute_gaps=False):
-        """Spectra of every member computed on the device from its LeafSoil parameters."""
-        arr = (Canopy * len(members))(*members)
-        larr = (LeafSoil * len(leaf))(*leaf)
-        assert len(leaf) == len(members)
+        """Spectra of every member computed on the device from its LeafSoil parameters.  members / leaf: lists of Canopy /
+        LeafSoil, or the C arrays of member_arrays() (a driver that cycles keeps its ensemble in those: marshalling a thousand
+        records out of Python objects costs a millisecond per call)."""
+        arr, larr = members, leaf
+        if not isinstance(arr, C.Array):
+            arr, larr = member_arrays(members, leaf)
+        assert len(larr) == len(arr)
+        members, leaf = arr, larr
         w = _f64(wl)
         _check(lib().gort_engine_set_members_leaf(self.h, arr, larr, len(members), int(compute_gaps), _ptr(w), w.size))
         self.nw = w.size
@@ -608,6 +612,14 @@ class Engine:
         if m < 0:
             _check(m)
         return {0: "narrow", 1: "flat", 2: "lines"}[m]
+
+    def time_expand(self, on=True):
+        """The two events around every LUT expansion launch that last_expand_ms() reads (gort_engine_time_expand)."""
+        _check(lib().gort_engine_time_expand(self.h, 1 if on else 0))
+
+    def energy_beside_grids(self, on=True):
+        """energy_members_dev on a stream of its own, so that a table asked for before the LUT chunks runs under them."""
+        _check(lib().gort_engine_energy_beside_grids(self.h, 1 if on else 0))
 
     def time_streams(self, on=True):
         """Record the two events last_stream_ms() reads around the expansion stage of every stream call (6 us per call)."""
@@ -701,6 +713,12 @@ class Engine:
         """energy_t[member][nA][nw][3] for the ensemble members [member_begin, member_end)."""
         _check(lib().gort_energy_members_dev(self.h, _ptr(angles_t), angles_t.shape[0], member_begin, member_end,
                                              _ptr(energy_t)))
+
+
+def member_arrays(members, leaf):
+    """(Canopy[n], LeafSoil[n]) as contiguous C arrays: what gort_engine_set_members_leaf takes."""
+    assert len(leaf) == len(members)
+    return (Canopy * len(members))(*members), (LeafSoil * len(leaf))(*leaf)
 
 
 def hemisphere_grid(nsza=91, nvza=91, nphi=361):

@@ -101,6 +101,10 @@ struct gort_engine {
     // still writing.  Only while both halves stay in the 256 MB Infinity Cache (PIPELINE_MAX_BYTES per half):
     // for the 191 MB of records of the full grid it costs 14 % instead (see grid_rows).
     hipStream_t aux = nullptr;
+    hipEvent_t ev_side = nullptr;
+    hipStream_t side = nullptr;          // gort_energy_members_dev beside the LUT chunks of an ensemble (gort_engine_energy_beside_grids)
+    bool energy_on_side = false;
+    bool time_expand = true;             // gort_engine_time_expand: two events around every LUT expansion launch
     hipEvent_t ev_tables = nullptr, ev_geom[2] = {nullptr, nullptr}, ev_expand[2] = {nullptr, nullptr};
     bool tables_recorded = false, expand_recorded[2] = {false, false};
     DevBuf gcoef[2], gsun[2];
@@ -348,6 +352,8 @@ extern "C" void gort_engine_destroy(gort_engine *e)
     for (hipEvent_t ev : {e->ev_tables, e->ev_geom[0], e->ev_geom[1], e->ev_expand[0], e->ev_expand[1]})
         if (ev) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    if (e->ev_side) (void)hipEventDestroy(e->ev_side);
     for (DevBuf *b : {&e->canopy, &e->spectra, &e->L, &e->coef, &e->K, &e->sun, &e->nodes, &e->angles, &e->out,
                       &e->out2, &e->leaf, &e->wl, &e->tab_coef, &e->tab_t12, &e->tab_talf, &e->tab_eof, &e->xcd_slots, &e->edup})
         b->release();
@@ -428,7 +434,27 @@ extern "C" int gort_engine_synchronize(gort_engine *e)
 {
     if (!e) return fail(GORT_EINVAL, "gort_engine_synchronize: null engine");
     GORT_HIP(hipStreamSynchronize(e->aux));
+    if (e->side) GORT_HIP(hipStreamSynchronize(e->side));
     GORT_HIP(hipStreamSynchronize(e->stream));
+    return GORT_OK;
+}
+
+// [r6] The albedo / fAPAR table of an ensemble is fp64-issue and latency bound (1000 members: 2 ms), its hemisphere LUTs are
+// HBM-write bound (75 ms): asked for first and queued on a stream of its own, the table is evaluated under the LUT chunks
+// instead of behind them.  The caller owns the ordering of what it hands in (angles, output) against its own streams, as ever;
+// gort_engine_synchronize waits for this stream too.
+extern "C" int gort_engine_energy_beside_grids(gort_engine *e, int on)
+{
+    if (!e) return fail(GORT_EINVAL, "gort_engine_energy_beside_grids: null engine");
+    if (on && !e->side) GORT_HIP(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    e->energy_on_side = on != 0;
+    return GORT_OK;
+}
+
+extern "C" int gort_engine_time_expand(gort_engine *e, int on)
+{
+    if (!e) return fail(GORT_EINVAL, "gort_engine_time_expand: null engine");
+    e->time_expand = on != 0;
     return GORT_OK;
 }
 
@@ -1013,7 +1039,7 @@ static int grid_rows(gort_engine *e, const gort_grid *g, long row_begin, long ro
     }
     // HIP events on the launch stream bracket the dominant kernel (bench.py roofline); up to
     // 512 launches are kept between two gort_engine_last_expand_ms() calls
-    const bool timed = e->ev_used + 2 <= 1024;
+    const bool timed = e->time_expand && e->ev_used + 2 <= 1024;
     if (timed) {
         while (e->ev.size() < e->ev_used + 2) {
             hipEvent_t ev;
@@ -1452,9 +1478,18 @@ extern "C" int gort_energy_members_dev(gort_engine *e, const double *angles_dev,
     if ((rc = energy_workspace(e, nA, &ws))) return rc;
     int *slots = nullptr;
     if ((rc = xcd_slots_for_launch(e, &slots))) return rc;
+    hipStream_t s = e->stream;
+    if (e->energy_on_side && e->side) {
+        // behind the tables (recorded on the main stream by the setters) and behind whatever the main stream holds now: the
+        // nodes' upload, an earlier call's workspace
+        s = e->side;
+        if (!e->ev_side) GORT_HIP(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
+        GORT_HIP(hipEventRecord(e->ev_side, e->stream));
+        GORT_HIP(hipStreamWaitEvent(s, e->ev_side, 0));
+    }
     return launch_energy(e->canopy.as<gort_canopy>() + member_begin, member_end - member_begin,
                          e->L.as<double>() + (size_t)member_begin * L_NSLOT * e->nw, e->nw, angles_dev, nA,
-                         e->nodes.as<double>(), energy_dev, ws, e->xcd_round_robin == 1, e->stream);
+                         e->nodes.as<double>(), energy_dev, ws, e->xcd_round_robin == 1, s);
 }
 
 extern "C" int gort_energy_stream(gort_engine *e, const double *angles, long nA, double *energy)

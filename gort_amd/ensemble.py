@@ -128,7 +128,7 @@ def gather_member_tables(local, n_members, group=None):
 
 
 def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, group=None, lut_chunk=0, seed=12345,
-                         gather_on_cpu=False, barrier=None):
+                         gather_on_cpu=False, barrier=None, lut_slack_gib=None, warmup_cycles=0):
     """Config 5 on `world` ranks, one GPU each: rank r draws the whole ensemble (same seed everywhere), keeps the
     members row_slab(r, world, n) on its GPU - gap probabilities, PROSPECT-D/Price, band tables on the device,
     optionally every member's hemisphere LUT in chunks of `lut_chunk` members (into a gort_lut_alloc buffer) - and all
@@ -149,59 +149,83 @@ def sharded_albedo_table(n_members, wavelengths, rank, world, sun_zenith=30.0, g
         # buffers, and the ONE chunk buffer the LUTs pass through - placed by the C ABI's allocator (a 14 GB slab lies on a
         # fast stretch of HBM about half the time)
         eng.reserve_members(m1 - m0, wl.size)
+        # the ensemble as C arrays, like the engine's buffers before the clock: a driver that cycles keeps it so (marshalling a
+        # thousand records out of Python objects cost 0.6 ms of every cycle)
+        member_arrays = api.member_arrays(canopies[m0:m1], leaf[m0:m1])
         if lut_chunk:
             g = c5_grid()
             chunk = min(lut_chunk, m1 - m0)
             per_member = g.nvza * g.nphi * wl.size
-            lut = eng.lut_alloc(chunk * per_member, max_draws=3)
+            # [r6] WHERE the chunk buffer lies decides 10-13 % of the LUTs' time (the same 40 chunks into a plain allocation 84-86
+            # ms, now and then 74.6; into the best of three draws 74.3-74.6, now and then not; into a window placed by the
+            # allocator's scan 74.3-74.6 five times of five: profiles/r06/c5_placement.log).  So the chunks go into the first
+            # half of a buffer twice their size, which gort_lut_alloc places by its scan through slack -
+            # 14 GB used of the ~76 GB held while the ensemble is evaluated
+            if lut_slack_gib is not None:
+                eng.set_lut_slack_gib(lut_slack_gib)
+            lut = eng.lut_alloc(2 * chunk * per_member, window=(0, chunk * per_member), max_draws=5)
     sync = barrier or (lambda: None)
-    t = {"members": [m0, m1]}
-    torch.cuda.synchronize()
-    sync()
-    t_start = t0 = time.perf_counter()
-    if m1 > m0:
-        eng.set_members_leaf(canopies[m0:m1], leaf[m0:m1], wl, compute_gaps=True)
-        eng.synchronize()
-    t["setup_s"] = time.perf_counter() - t0
-    t["lut_s"], t["lut_chunk_ms"], t["lut_samples"] = 0.0, [], 0
-    if lut is not None:
-        eng.last_expand_ms()
-        t0 = time.perf_counter()
-        # The LUTs are a product that is consumed on the device and dropped (what leaves is the reduced table): the chunks
-        # go into ONE buffer back to back, no host wait between them.  With records of <= 64 MB per chunk (25 members) the
-        # engine runs geometry and sun table of chunk i+1 on its second stream under the expansion of chunk i.
-        n_chunks = 0
-        for a in range(0, m1 - m0, chunk):
-            eng.rsurf_members_grid_dev(g, a, min(m1 - m0, a + chunk), lut)
-            n_chunks += 1
-        eng.synchronize()
-        t["lut_s"] = time.perf_counter() - t0
-        t["lut_chunk_ms"] = [t["lut_s"] * 1e3 / n_chunks] * n_chunks          # mean: the chunks are not timed one by one any more
-        t["lut_kernel_ms"] = eng.last_expand_ms()                            # mean duration of the expansion kernel (HIP events)
-        t["lut_samples"] = (m1 - m0) * per_member
-        t["lut_alloc"] = lut.placement
-        lut.free()
-    t0 = time.perf_counter()
     energy = torch.empty((m1 - m0, 1, wl.size, 3), dtype=torch.float64, device="cuda")
-    if m1 > m0:
-        sun = torch.tensor([[0.0, 0.0, float(sun_zenith), 0.0]], dtype=torch.float64, device="cuda")
-        torch.cuda.synchronize()                 # torch fills on its stream, the engine reads on its own
-        eng.energy_members_dev(sun, 0, m1 - m0, energy)
-        eng.synchronize()
-    torch.cuda.synchronize()
-    t["energy_s"] = time.perf_counter() - t0
-    sync()
-    t0 = time.perf_counter()
-    local = energy.view(m1 - m0, wl.size, 3)
-    if world > 1:
-        full = gather_member_tables(local.cpu() if gather_on_cpu else local, n_members, group)
-    else:
-        full = local
-    torch.cuda.synchronize()
-    sync()
-    t["gather_s"] = time.perf_counter() - t0
-    t["gather_bytes_received"] = int((n_members - (m1 - m0)) * wl.size * 3 * 8) if world > 1 else 0
-    t["total_s"] = time.perf_counter() - t_start
+    sun = torch.tensor([[0.0, 0.0, float(sun_zenith), 0.0]], dtype=torch.float64, device="cuda")
+
+    def cycle():
+        """One cycle of a filter's forward model on this rank: members -> gap probabilities, spectra, band tables -> the members'
+        LUTs (chunks into the one buffer) -> the albedo table -> the all-gather.  Returns (table on every rank, timings)."""
+        t = {"members": [m0, m1]}
+        torch.cuda.synchronize()
+        sync()
+        t_start = t0 = time.perf_counter()
+        if m1 > m0:
+            eng.set_members_leaf(member_arrays[0], member_arrays[1], wl, compute_gaps=True)
+            eng.synchronize()
+        t["setup_s"] = time.perf_counter() - t0
+        t["lut_s"], t["lut_chunk_ms"], t["lut_samples"] = 0.0, [], 0
+        if lut is not None:
+            eng.last_expand_ms()
+            t0 = time.perf_counter()
+            # The LUTs are a product that is consumed on the device and dropped (what leaves is the reduced table): the chunks
+            # go into ONE buffer back to back, no host wait between them.  With records of <= 64 MB per chunk (25 members) the
+            # engine runs geometry and sun table of chunk i+1 on its second stream under the expansion of chunk i.
+            n_chunks = 0
+            for a in range(0, m1 - m0, chunk):
+                eng.rsurf_members_grid_dev(g, a, min(m1 - m0, a + chunk), lut)
+                n_chunks += 1
+            eng.synchronize()
+            t["lut_s"] = time.perf_counter() - t0
+            t["lut_chunk_ms"] = [t["lut_s"] * 1e3 / n_chunks] * n_chunks          # mean: the chunks are not timed one by one any more
+            t["lut_kernel_ms"] = eng.last_expand_ms()                            # mean duration of the expansion kernel (HIP events)
+            t["lut_samples"] = (m1 - m0) * per_member
+            t["lut_alloc"] = lut.placement
+        t0 = time.perf_counter()
+        if m1 > m0:
+            torch.cuda.synchronize()                 # torch fills on its stream, the engine reads on its own
+            eng.energy_members_dev(sun, 0, m1 - m0, energy)
+            eng.synchronize()
+        torch.cuda.synchronize()
+        t["energy_s"] = time.perf_counter() - t0
+        sync()
+        t0 = time.perf_counter()
+        local = energy.view(m1 - m0, wl.size, 3)
+        if world > 1:
+            full = gather_member_tables(local.cpu() if gather_on_cpu else local, n_members, group)
+        else:
+            full = local
+        torch.cuda.synchronize()
+        sync()
+        t["gather_s"] = time.perf_counter() - t0
+        t["gather_bytes_received"] = int((n_members - (m1 - m0)) * wl.size * 3 * 8) if world > 1 else 0
+        t["total_s"] = time.perf_counter() - t_start
+        return full, t
+
+    # a filter cycles many times: `warmup_cycles` whole cycles run untimed first (the first one meets what a process meets once -
+    # the chunks' record and sun-table buffers, a size class's XCD calibration, code objects: 2 ms of the 82), the next is the
+    # one whose times are returned
+    for _ in range(max(0, int(warmup_cycles))):
+        cycle()
+    full, t = cycle()
+    t["warmup_cycles"] = max(0, int(warmup_cycles))
+    if lut is not None:
+        lut.free()
     out = full.cpu().numpy()
     eng.close()
     return out, t

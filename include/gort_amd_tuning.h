@@ -24,6 +24,15 @@ double gort_engine_last_expand_ms(gort_engine *e);
  * launch + synchronisation 12.1 us, with an event in front and behind 18.2, tools/probes/clock_probe.hip) - a third of a
  * short call like BASELINE config 2 - so they are recorded only after gort_engine_time_streams(e, 1) */
 int    gort_engine_time_streams(gort_engine *e, int on);
+/* the two events around every LUT expansion launch (gort_engine_last_expand_ms) on / off; on when the engine is created.  A
+ * caller that queues many launches back to back (the chunks of an ensemble's LUTs) and does not read the timer saves their
+ * share of the gap between two launches */
+int    gort_engine_time_expand(gort_engine *e, int on);
+/* ---- ensembles: the albedo / fAPAR table beside the LUT chunks ----
+ * on: gort_energy_members_dev queues its kernels on a stream of its own (behind everything the engine's stream holds at the
+ * time of the call) instead of the engine's stream, so that a table asked for BEFORE the LUT chunks of the same members is
+ * evaluated under them (fp64-issue bound beside HBM-write bound); gort_engine_synchronize waits for it.  No result changes. */
+int    gort_engine_energy_beside_grids(gort_engine *e, int on);
 double gort_engine_last_stream_ms(gort_engine *e);
 
 /* ---- which kernel family expanded the last gort_rsurf_stream[_dev] call ----
