@@ -159,6 +159,13 @@ __device__ __forceinline__ void load_line_terms(double (&rec)[WRAP ? 2 : 1][LINE
 // them at the top of the next step; the other waves of the SIMD fill that gap.  (One step is read beyond the last:
 // expand_stream_tail_pad_records().)  A hand-made double buffer (loads of step k+1 in front of the arithmetic of step
 // k, two SGPR sets) cost a wave of occupancy and ran 30 % SLOWER in round 2: this kernel lives on thread-level parallelism.
+// [r6] Tried once more as the round-5 review spelled it out - request and wait written in asm as in stream_lines_kernel, two named
+// SGPR sets, the wait behind the store's issue, non-wrapping waves only: the loop itself comes out clean (52 vector instructions,
+// the next record in flight under them), but with 2 x 24 SGPRs pinned beside the wrapping path's 2 x 24 the allocator either drops
+// to four waves per SIMD (124 VGPRs) or, held to seven, spills the wrapping path to scratch: 1 048 576 x 2101 in 4.70 ms against
+// 3.02, 65 536 lines 338 us against 194-201 (profiles/r06/flat_stream_record_ahead.log, the patch beside it).  And there is little
+// to win: seven waves cover the record's round trip already (7 x 240 issue cycles per round against ~800 ns of latency + 100 of
+// arithmetic), the kernel sits at 0.71-0.73 beside 0.75 for its bare store pattern.  Stopped.
 template <bool NT, bool WRAP>
 __device__ __forceinline__ void flat_stream_loop(const StreamBand (&t)[EPL], const bool (&second)[EPL], int first_off,
                                                  int last_step, int last_off, int da, long step, int k_wave,
