@@ -460,7 +460,15 @@ int launch_geometry_stream_fused(const gort_canopy *canopy_dev, int n_members, c
 {
     if (nA <= 0 || nw < 0 || n_members <= 0 || (nw == 0 && !K_dev)) return GORT_OK;      // nw = 0: the proportions K alone
     if (n_members > 65535) return fail(GORT_EINVAL, "geometry: %d members in one launch (max 65535)", n_members);
-    hipLaunchKernelGGL(geometry_stream_kernel<true>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), 0,
+#ifndef GORT_PROBE_GEOM_LDS_PAD
+#define GORT_PROBE_GEOM_LDS_PAD 0      // probe builds: bytes of unused LDS per workgroup = fewer resident waves (tools/probes/geometry_occupancy.sh)
+#endif
+#if GORT_PROBE_GEOM_LDS_PAD > 0
+    static const hipError_t pad_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&geometry_stream_kernel<true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, GORT_PROBE_GEOM_LDS_PAD);
+    if (pad_ok != hipSuccess) return fail(GORT_ENODEVICE, "probe build: %d bytes of LDS padding refused", GORT_PROBE_GEOM_LDS_PAD);
+#endif
+    hipLaunchKernelGGL(geometry_stream_kernel<true>, dim3((unsigned)((nA + 255) / 256), 1, (unsigned)n_members), dim3(256), GORT_PROBE_GEOM_LDS_PAD,
                        (hipStream_t)stream, canopy_dev, angles_dev, nA, (double *)nullptr, K_dev, 0, L_dev, nw, rsurf_dev, 0);
     return check_launch("geometry_stream_kernel<fused>");
 }
