@@ -398,12 +398,15 @@ bool stream_takes_lines_kernel(int nw, long nA, bool want_scomp)
 
 // the same lines for several members: the flat-panel kernel has no member dimension, so the line kernel keeps every band count
 // from 17 (a thousand members x 1000 lines x 2101 bands: 0.60 of HBM against 0.11 through records + one thread per sample).  A wave
-// is 64 lines of ONE member (its band constants come through the scalar unit): with few lines per member the waves are mostly idle
-// lanes, and the narrow path - a thread per sample - keeps the machine busier
-constexpr long MEMBERS_MIN_LINES = 24;
+// is 64 lines of ONE member (its band constants come through the scalar unit), so with few lines per member its time is one wave's
+// walk over the bands whatever the number of live lanes - 1000 members x 8 ... 64 lines x 100 / 640 bands: 34 / 200 us - where the
+// narrow path's grows with the samples: x 100 bands 42 ... 80 us (slower from 8 lines on), x 640 bands 79 / 110 / 151 / 199 / 287 us
+// at 8 / 16 / 24 / 32 / 48 lines (faster up to 24).  ADVICE r5; profiles/r06/members_small_lines.log
+constexpr long MEMBERS_MIN_LINES_WIDE = 32;          // lines per member from which spectra of >= MEMBERS_WIDE_BANDS take this kernel
+constexpr int MEMBERS_WIDE_BANDS = 256;
 bool members_stream_takes_lines_kernel(int nw, long lines_per_member, int n_members)
 {
-    long min_lines = MEMBERS_MIN_LINES;
+    long min_lines = nw >= MEMBERS_WIDE_BANDS ? MEMBERS_MIN_LINES_WIDE : 1;
     if (const char *v = ab_env("GORT_MEMBERS_MIN_LINES")) min_lines = atol(v);      // measuring build: tools/probes/members_stream.py
     return nw >= LINES_MIN_BANDS && lines_per_member >= min_lines && lines_per_member * n_members * (long)nw >= (1L << 18);
 }
