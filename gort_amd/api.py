@@ -91,6 +91,7 @@ TUNING_SYMBOLS = [
     "gort_engine_last_expand_ms", "gort_engine_last_stream_ms", "gort_engine_time_streams", "gort_engine_stream_form",
     "gort_engine_xcd_mapping", "gort_engine_xcd_weights", "gort_engine_set_xcd_weights", "gort_engine_store_pattern_gbs",
     "gort_engine_probe_store_pattern", "gort_selftest_index_math", "gort_engine_set_lut_slack_gib",
+    "gort_engine_time_expand", "gort_engine_energy_beside_grids",
 ]
 
 _lib = None
