@@ -1489,6 +1489,45 @@ def test_member_grids_of_any_band_count(golden, nw):
     e.close(); single.close()
 
 
+@pytest.mark.ab
+@pytest.mark.parametrize("nw", [33, 64, 100, 127])
+def test_member_grids_through_the_aligned_chunk_kernel(golden, nw, monkeypatch):
+    """expand_flat_few_kernel (LUTs of 33 ... 127 bands in aligned chunks; the product takes it from 65 bands for grids of 8M samples)
+    FORCED onto grids it would never get (GORT_GRID_FEW_FLAT=1, measuring build): 12 nodes per member - the sun row changes several
+    times inside one step of a wave, a launch of a few chunks, elements in front of and behind the slab in the same chunk - a grid of
+    999 nodes and a mirrored full circle, 32 members in one call, a member sub-range, the LUT 40 bytes off a chunk boundary: bit for
+    bit the fused form (=0) every time."""
+    import torch
+    g, canopies, leaf = _members(golden)
+    n = len(canopies)
+    pick = np.unique(np.linspace(0, g["wl"].size - 1, nw).round().astype(int))
+    wl = g["wl"][pick]
+    sp = np.stack([np.stack(api.spectra(wl, l)) for l in leaf])
+    members = [api.gap_probabilities(c) for c in canopies]
+    e = api.Engine()
+    e.set_members(members, sp)
+    for grid in (_grid((30.0, 1.0, 1), (0.0, 45.0, 3), (0.0, 90.0, 4)), _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 10.0, 37)),
+                 _grid((0.0, 40.0, 3), (0.0, 11.0, 9), (0.0, 1.0, 361))):
+        nodes = grid.nsza * grid.nvza * grid.nphi
+        outs = {}
+        for form in ("0", "1"):
+            monkeypatch.setenv("GORT_GRID_FEW_FLAT", form)
+            buf = torch.full((n * nodes * nw + 64,), -7.0, dtype=torch.float64, device="cuda")
+            lut = buf[5:5 + n * nodes * nw]
+            torch.cuda.synchronize()
+            e.rsurf_members_grid_dev(grid, 0, n, lut)
+            e.synchronize()
+            assert float(buf[:5].max()) == -7.0 and float(buf[5 + n * nodes * nw:].max()) == -7.0 and not bool((lut == -7.0).any())
+            part = torch.full((3 * nodes * nw + 8,), -7.0, dtype=torch.float64, device="cuda")
+            e.rsurf_members_grid_dev(grid, 5, 8, part[:3 * nodes * nw]); e.synchronize()
+            assert float(part[3 * nodes * nw:].max()) == -7.0
+            assert torch.equal(part[:3 * nodes * nw].view(torch.int64), lut.view(n, nodes * nw)[5:8].reshape(-1).view(torch.int64)), (nw, form)
+            outs[form] = lut.cpu().numpy()
+        a, b = outs["0"], outs["1"]
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.int64), b[~np.isnan(b)].view(np.int64)), (nw, nodes)
+    e.close()
+
+
 def test_ensemble_energy_table(golden):
     """Per-member albedo/fAPAR for a member range in one launch == the single-canopy energy path == the oracle."""
     import torch
