@@ -269,15 +269,19 @@ __device__ inline SunTerms sun_terms(const double *__restrict__ L, int nw, int i
 //   rsurf = [ n1 (alpha - t0 S) + n2 (W - R_ff S) ] / (1 - x^2) + (Q1 mgk + Q2 rs + Q3 Zf + Q4 Tf + Q5 p_ff + Q6 B)
 //   x = 2 gamma mu,  n1 = (1-gamma)(1-x),  n2 = (1+2mu) (omega/2) (T_ff - t0),  W = P1 mgk + P2 rs,  S = alpha t_ff + W p_ff
 //
-// with TWELVE scalars per line (alpha .. Q6, mu, t0, 1+2mu: line_terms) and twelve band constants: 24 instructions +
-// one reciprocal (28 issue slots) per sample, where sun_terms() + dot5() take ~54 and the round-2 form of this
-// regrouping (p_df and t'_df formed explicitly) took 32: the stream kernels are bound by fp64 issue or close to it.
+// Round 6: the factor m = 1 + 2 mu of n2 is a number of the LINE, so it rides on the line's weights instead of being
+// multiplied into every sample - W_m = m W = (m P1) mgk + (m P2) rs, S_m = m S = (m alpha) t_ff + W_m p_ff,
+// n2 (W - R_ff S) = n2' (W_m - R_ff S_m) with n2' = (omega/2)(T_ff - t0), alpha - t0 S = alpha - (t0 / m) S_m - and
+// n1 = c1 - c1 x is one fused operation: THIRTEEN scalars per line (alpha, m alpha, m P1, m P2, Q1 .. Q6, mu, t0, t0 / m:
+// line_terms) and twelve band constants, 22 instructions + one reciprocal (26 issue slots) per sample (rounds 3-5: 24 + 1;
+// sun_terms() + dot5() take ~54; the round-2 form of this regrouping, p_df and t'_df formed explicitly, took 32): the
+// stream kernels are bound by fp64 issue or close to it, and an instruction less per sample is an instruction less per sample.
 // Every kernel that expands a STREAM (flat panels, band-major, per sample, fused with the geometry) evaluates exactly
 // these functions, written with explicit FMAs and without contraction so that all of them produce the same bits;
 // the LUT family keeps the five (sun zenith, band) terms and dot5().  The two families differ by rounding only
 // (a few 1e-16 relative; both are held to 1e-9 against the reference).
-struct LineTerms { double alpha, P1, P2, Q1, Q2, Q3, Q4, Q5, Q6, mu, t0, m2; };
-constexpr int LINE_NTERMS = 12;                // <= GORT_COEF_STRIDE: a LineTerms record is what layout 1 of the stream records holds
+struct LineTerms { double alpha, am, P1m, P2m, Q1, Q2, Q3, Q4, Q5, Q6, mu, t0, t0m; };
+constexpr int LINE_NTERMS = 13;                // <= GORT_COEF_STRIDE: a LineTerms record is what layout 1 of the stream records holds
 
 __device__ inline LineTerms line_terms(double aC, double aB, double aZ, double aG, double aT, double fd, double mu,
                                        double t0, double tp0, double eps, double kep, double kk)
@@ -290,9 +294,11 @@ __device__ inline LineTerms line_terms(double aC, double aB, double aZ, double a
     const double sCT = aC + aT;
     const double p1 = fd * sCT, p2 = Zc * fd;             // the weights of t'_df: mgk and rs
     const double omtp0 = 1.0 - tp0;
+    const double m = 1.0 + 2.0 * mu;                      // 1 ... 3
     l.alpha = aC * fd;
-    l.P1 = p1 * omtp0;                                    // (1 - t'_0) of gortt_brdf.c:361 folded into the line
-    l.P2 = p2 * omtp0;
+    l.am = l.alpha * m;
+    l.P1m = (p1 * omtp0) * m;                             // (1 - t'_0) of gortt_brdf.c:361 folded into the line
+    l.P2m = (p2 * omtp0) * m;
     l.Q1 = tp0 * p1;
     l.Q2 = __builtin_fma(p2, eps, __builtin_fma(cfk, kk, aG));
     l.Q3 = Zc * omfd;
@@ -301,7 +307,7 @@ __device__ inline LineTerms line_terms(double aC, double aB, double aZ, double a
     l.Q6 = aB;
     l.mu = mu;
     l.t0 = t0;
-    l.m2 = 1.0 + 2.0 * mu;
+    l.t0m = gm::quot_finite(t0, m);
     return l;
 }
 
@@ -339,18 +345,18 @@ __device__ __forceinline__ double stream_reciprocal(double den)
 #endif
 }
 
-__device__ __forceinline__ double stream_sample(double alpha, double P1, double P2, double Q1, double Q2, double Q3,
-                                                double Q4, double Q5, double Q6, double mu, double t0, double m2,
+__device__ __forceinline__ double stream_sample(double alpha, double am, double P1m, double P2m, double Q1, double Q2,
+                                                double Q3, double Q4, double Q5, double Q6, double mu, double t0, double t0m,
                                                 const StreamBand &b)
 {
 #pragma clang fp contract(off)
     const double x = b.g2 * mu;
     const double inv = stream_reciprocal(__builtin_fma(-x, x, 1.0));
-    const double n1 = b.c1 * (1.0 - x);
-    const double n2 = m2 * __builtin_fma(-b.c2, t0, b.cT);
-    const double W = __builtin_fma(P2, b.rs, P1 * b.mgk);
-    const double S = __builtin_fma(W, b.pff, alpha * b.tff);
-    const double A = __builtin_fma(-t0, S, alpha);
+    const double n1 = __builtin_fma(-b.c1, x, b.c1);
+    const double n2 = __builtin_fma(-b.c2, t0, b.cT);           // without its factor 1 + 2 mu: that one is in W, S
+    const double W = __builtin_fma(P2m, b.rs, P1m * b.mgk);
+    const double S = __builtin_fma(W, b.pff, am * b.tff);
+    const double A = __builtin_fma(-t0m, S, alpha);
     const double Bc = __builtin_fma(-b.Rff, S, W);
     const double num = __builtin_fma(n1, A, n2 * Bc);
     const double lin = __builtin_fma(Q6, b.B, __builtin_fma(Q5, b.pff, __builtin_fma(Q4, b.Tf, __builtin_fma(Q3, b.Zf,
@@ -360,7 +366,7 @@ __device__ __forceinline__ double stream_sample(double alpha, double P1, double 
 
 __device__ __forceinline__ double stream_sample(const LineTerms &l, const StreamBand &b)
 {
-    return stream_sample(l.alpha, l.P1, l.P2, l.Q1, l.Q2, l.Q3, l.Q4, l.Q5, l.Q6, l.mu, l.t0, l.m2, b);
+    return stream_sample(l.alpha, l.am, l.P1m, l.P2m, l.Q1, l.Q2, l.Q3, l.Q4, l.Q5, l.Q6, l.mu, l.t0, l.t0m, b);
 }
 
 // the line terms of a classic record (narrow kernels derive them on the fly; the wide ones read them precomputed)

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256) void geometry_stream_kernel(const gort_canopy 
         store_coef(rec, c, g);
         const LineTerms l = line_terms_of_record(rec, c.k_openep, c.k_open);
         double *o = coef + (member * nA + a) * GORT_COEF_STRIDE;
-        o[0] = l.alpha;  o[1] = l.P1;  o[2] = l.P2;  o[3] = l.Q1;  o[4] = l.Q2;  o[5] = l.Q3;  o[6] = l.Q4;  o[7] = l.Q5;
-        o[8] = l.Q6;  o[9] = l.mu;  o[10] = l.t0;  o[11] = l.m2;  o[12] = 0.0;  o[13] = 0.0;  o[14] = 0.0;  o[15] = 0.0;
+        o[0] = l.alpha;  o[1] = l.am;  o[2] = l.P1m;  o[3] = l.P2m;  o[4] = l.Q1;  o[5] = l.Q2;  o[6] = l.Q3;  o[7] = l.Q4;
+        o[8] = l.Q5;  o[9] = l.Q6;  o[10] = l.mu;  o[11] = l.t0;  o[12] = l.t0m;  o[13] = 0.0;  o[14] = 0.0;  o[15] = 0.0;
     }
     if (K && live) {
         double *k = K + 4 * (member * nA + a);

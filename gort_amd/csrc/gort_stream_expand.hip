@@ -137,7 +137,7 @@ __device__ __forceinline__ void flat_stream_step(const StreamBand (&t)[EPL], con
 #pragma unroll
         for (int w = 0; w < (WRAP ? 2 : 1); ++w) {
             vv[w] = stream_sample(rec[w][0], rec[w][1], rec[w][2], rec[w][3], rec[w][4], rec[w][5], rec[w][6], rec[w][7],
-                                  rec[w][8], rec[w][9], rec[w][10], rec[w][11], t[j]);
+                                  rec[w][8], rec[w][9], rec[w][10], rec[w][11], rec[w][12], t[j]);
         }
         v[j] = (WRAP && second[j]) ? vv[1] : vv[0];
     }
