@@ -58,8 +58,13 @@ __device__ __forceinline__ void band_wait(BandRegs &r)
 __device__ __forceinline__ StreamBand band_of(const BandRegs &r)
 {
     StreamBand b;
-    b.g2 = r.lo[0];  b.c1 = r.lo[1];  b.c2 = r.lo[2];  b.Rff = r.lo[3];  b.cT = r.lo[4];  b.tff = r.lo[5];  b.pff = r.lo[6];
+    b.g2 = r.lo[0];  b.c1 = r.lo[1];  b.c2 = r.lo[2];  b.Rff = r.lo[3];  b.tff = r.lo[5];  b.pff = r.lo[6];
     b.rs = r.lo[7];  b.mgk = r.hi[0];  b.Zf = r.hi[1];  b.Tf = r.hi[2];  b.B = r.hi[3];
+    // cT - c2 t0 (stream_sample's n2) reads TWO band constants, and a vector instruction of gfx9 reads one scalar operand: the
+    // compiler copies cT into vector registers with two 32-bit moves, each an issue slot of four cycles like a whole fp64 FMA;
+    // the 64-bit move is one
+    const double cT = r.lo[4];
+    asm("v_mov_b64 %0, %1" : "=v"(b.cT) : "s"(cT));
     return b;
 }
 
@@ -434,8 +439,10 @@ int launch_stream_lines(const gort_canopy *canopy_dev, int n_members, const doub
                            pitch, rsurf_dev, K_dev, (unsigned)blocks, total);
         return check_launch("stream_lines_kernel<members>");
     }
-    const size_t lds = sizeof(double) * 65 * (size_t)pitch;
+    size_t lds = sizeof(double) * 65 * (size_t)pitch;
 #ifdef GORT_AB
+    if (const char *v = ab_env("GORT_LINES_LDS_BYTES"))        // occupancy probe: a larger allocation = fewer resident waves per CU
+        if ((size_t)atol(v) > lds) lds = (size_t)atol(v);
     static const bool nt = !(ab_env("GORT_EXPAND_NT") && atoi(ab_env("GORT_EXPAND_NT")) == 0);
     if (!nt)
         hipLaunchKernelGGL((stream_lines_kernel<false, false>), dim3((unsigned)blocks), dim3(64), lds, s, canopy_dev, angles_dev, nA, tb, nw,
