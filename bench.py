@@ -363,12 +363,14 @@ def configs_block(quick=False):
                  "bound": "fp64_valu", "frac": None, "hbm_frac": rows * g.nphi * 8 / t / 8e12}
     del lut
     # the same hemisphere as a LUT of 7 bands (MODIS land bands: the ensemble use the reference's README names) and of 100 (the band
-    # counts its command line can read): below 128 bands the geometry kernel writes the samples itself, whole rows per store
+    # counts its command line can read): up to 64 bands the geometry kernel writes the samples itself, whole rows per store; from 65
+    # compact records + expand_flat_few_kernel (the aligned chunks of the headline kernel)
     for nw, key in () if quick else ((7, "lut_hemisphere_x_7"), (100, "lut_hemisphere_x_100")):      # (not under the counters: C3's kernel again)
         eng.set_spectra(*api.spectra(np.linspace(400.0, 2500.0, nw)))
         lut = torch.empty((rows * g.nphi, nw), dtype=torch.float64, device="cuda")
         t = best(lambda: eng.rsurf_grid_dev(g, 0, rows, lut), eng)
-        out[key] = {"workload": "91x91x361 angles x %d bands, LUT entry point (geometry kernel writes the samples)" % nw, "us": t * 1e6,
+        form = "geometry kernel writes the samples" if nw <= 64 else "records + expand_flat_few_kernel"
+        out[key] = {"workload": "91x91x361 angles x %d bands, LUT entry point (%s)" % (nw, form), "us": t * 1e6,
                     "samples_per_s": rows * g.nphi * nw / t, "bound": "fp64_valu" if nw < 32 else "hbm",
                     "hbm_frac": rows * g.nphi * nw * 8 / t / 8e12}
         del lut
