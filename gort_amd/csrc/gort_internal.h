@@ -137,7 +137,7 @@ bool expand_wants_xcd_slots(bool dispatch_round_robin);
 // expand_stream_tail_pad_records() behind the last line; xcd_slots_dev: XCD_SLOT_BYTES zeroed on `stream` before the
 // call, or nullptr for the static XCD mapping.
 // Large streams without component spectra (stream_is_large: >= 128 bands and >= 4M samples) have their records in layout 1
-// (the twelve LineTerms) and are expanded by expand_flat_stream_kernel (aligned flat panels).
+// (the thirteen LineTerms) and are expanded by expand_flat_stream_kernel (aligned flat panels).
 // grid_form: the "lines" are the nodes of a few-band LUT (classic records): narrow kernels, LUT family's
 // five-term sample, so that every LUT path writes the same bits.
 long expand_stream_tail_pad_records(int nw, long nA);

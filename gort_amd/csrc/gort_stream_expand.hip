@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void expand_stream_bands_kernel(const gort_can
 // The aligned flat form for ARBITRARY angle lines (every line has its own sun zenith): the chunking, the
 // band-preserving stride, the PANELS (K steps x W waves, each XCD one contiguous run of panels) and the slab-edge
 // handling of expand_flat_kernel; but a lane keeps the 12 band constants of its two bands in registers and forms
-// the sample per step from the line's 12 LineTerms (records in layout 1, scalar loads, one step ahead): 24 instructions
+// the sample per step from the line's 13 LineTerms (records in layout 1, scalar loads, one step ahead): 22 instructions
 // + one reciprocal per sample (gort_device.h, stream family).
 // coef: stream records (GORT_COEF_STRIDE doubles), one pad record in front, tail pad behind.
 // one step of a wave: the samples of the chunk from the record(s) `rec`, stored with the slab-edge handling

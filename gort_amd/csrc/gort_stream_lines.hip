@@ -3,7 +3,7 @@
 // reflectances (the per-line loop of main(), gortt.c:232-329, with gortt_rsurf, gortt.c:385-578).
 //
 // A wave takes 64 consecutive LINES, lane = line.  The lane evaluates its line's geometry (gort_geometry.h) and keeps
-// the twelve LineTerms of the stream family's sample in registers - no 128-B record per line written and read back -
+// the thirteen LineTerms of the stream family's sample in registers - no 128-B record per line written and read back -
 // then walks the bands: their twelve constants are wave-uniform (scalar loads off the StreamBand table), so a sample
 // costs its 28 fp64 issue slots and nothing else.
 //
