@@ -11,12 +11,20 @@
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 // RUN = cache lines of a row per store instruction (1: the kernel's pattern; 2, 4: longer runs per row, fewer rows per instruction)
-template <int RUN>
+// XCD_RANGES: workgroups b, b + 8, ... run on one XCD (round-robin dispatch); give XCD x the contiguous range x of the row groups
+// (eight write windows, one per L2, as the flat kernels and the members stream have them) instead of every eighth group
+template <int RUN, bool XCD_RANGES>
 __global__ __launch_bounds__(64) void pattern(double *out, long n_rows, int nw, int spin)
 {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const long r0 = (long)blockIdx.x * 64;
+    long group = blockIdx.x;
+    if (XCD_RANGES) {
+        const long groups = (n_rows + 63) / 64, per_xcd = (groups + 7) >> 3;
+        group = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (group >= groups) return;
+    }
+    const long r0 = group * 64;
     if (r0 >= n_rows) return;
     constexpr int ROWS_PER_STORE = 8 / RUN;            // 64 lanes x 16 B = 8 lines
     const int sub = lane / (8 * RUN), q = lane % (8 * RUN);
@@ -38,41 +46,41 @@ __global__ __launch_bounds__(64) void pattern(double *out, long n_rows, int nw, 
     }
 }
 
-template <int RUN>
+template <int RUN, bool XCD_RANGES = false>
 static void run(double *buf, long n_rows, int nw, int lds_bytes, int spin)
 {
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const unsigned grid = (unsigned)((n_rows + 63) / 64);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pattern<RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    const unsigned grid = (unsigned)(((n_rows + 63) / 64 + 7) / 8 * 8);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pattern<RUN, XCD_RANGES>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     float best = 1e30f;
     for (int rep = 0; rep < 6; ++rep) {
         CK(hipEventRecord(a));
-        hipLaunchKernelGGL(pattern<RUN>, dim3(grid), dim3(64), lds_bytes, 0, buf, n_rows, nw, spin);
+        hipLaunchKernelGGL((pattern<RUN, XCD_RANGES>), dim3(grid), dim3(64), lds_bytes, 0, buf, n_rows, nw, spin);
         CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b));
         if (rep > 0 && ms < best) best = ms;
     }
     const double bytes = (double)n_rows * (nw / (16 * RUN)) * (16 * RUN) * 8.0;
-    printf("rows %8ld x %4d bands, %d line(s) of a row per store, LDS %5d B per wave (%2d waves per CU), %3d FMAs per block: %8.1f us  %6.0f GB/s\n",
-           n_rows, nw, RUN, lds_bytes, lds_bytes ? 163840 / lds_bytes : 32, spin, best * 1e3, bytes / best / 1e6);
+    printf("rows %8ld x %4d bands, %s, %d line(s) of a row per store, LDS %5d B per wave (%2d waves per CU), %3d FMAs per block: %8.1f us  %6.0f GB/s\n",
+           n_rows, nw, XCD_RANGES ? "a range per XCD  " : "groups interleaved", RUN, lds_bytes, lds_bytes ? 163840 / lds_bytes : 32, spin, best * 1e3, bytes / best / 1e6);
 }
 
 int main(int argc, char **argv)
 {
     const long n_rows = argc > 1 ? atol(argv[1]) : 1000000;
     double *buf;
-    const int bands[] = {64, 96, 128, 192, 256, 512};
+    const int bands[] = {96, 128, 256};
     CK(hipMalloc(&buf, sizeof(double) * (size_t)(n_rows + 2) * 512));
     CK(hipMemset(buf, 0, sizeof(double) * (size_t)(n_rows + 2) * 512));
     for (int nw : bands) {
         for (int lds : {17680, 8192, 0}) {
             run<1>(buf, n_rows, nw, lds, 0);
         }
-        run<1>(buf, n_rows, nw, 17680, 470);          // 16 bands x 29.5 instructions
-        run<2>(buf, n_rows, nw, 17680, 0);
         run<4>(buf, n_rows, nw, 17680, 0);
-        run<2>(buf, n_rows, nw, 0, 0);
+        run<1, true>(buf, n_rows, nw, 17680, 0);
+        run<1, true>(buf, n_rows, nw, 0, 0);
+        run<4, true>(buf, n_rows, nw, 17680, 0);
     }
     CK(hipFree(buf));
     return 0;
